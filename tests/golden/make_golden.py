@@ -1,0 +1,325 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by RUNNING THE REFERENCE in the build
+container (it cannot travel to the GPU box; only these data files do).
+
+    python tests/golden/make_golden.py        # needs /root/reference
+
+What runs: the reference's own sig.phash (phash/dhash/_to_grayscale, src/sig/phash.py)
+and dup.scanner (src/dup/scanner.py) imported from /root/reference/src.  `cv2.dct` is the
+SciPy stand-in in _standins/cv2.py (OpenCV absent -> pHash values are labelled
+dct_backend=scipy).  dup.refine cannot be imported (cv2 + skimage absent), so the SSIM
+vectors come from a scipy.ndimage restatement of skimage's published algorithm and are
+labelled as such.
+"""
+from __future__ import annotations
+
+import hashlib
+import json
+import logging
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.normpath(os.path.join(HERE, "..", ".."))
+sys.path.insert(0, os.path.join(HERE, "_standins"))
+sys.path.insert(0, "/root/reference/src")
+sys.path.insert(0, ROOT)
+
+from PIL import Image  # noqa: E402
+
+import sig.phash as ref_sig  # noqa: E402
+from dup.scanner import DuplicateFile, DuplicateScanConfig, DuplicateScanner  # noqa: E402
+import dup.scanner as ref_scanner  # noqa: E402
+
+from oracle import oracle as O  # noqa: E402  (only for the synthetic generators = inputs)
+
+U64 = (1 << 64) - 1
+
+
+def sha(a: np.ndarray) -> str:
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def ref_hashes(img: Image.Image):
+    t32 = np.asarray(ref_sig._to_grayscale(img, (32, 32))).astype(np.uint8)
+    t98 = np.asarray(ref_sig._to_grayscale(img, (9, 8))).astype(np.uint8)
+    ph = ref_sig.phash(img) & U64
+    dh = ref_sig.dhash(img) & U64
+    # tie margin of the stand-in DCT, for the record
+    import cv2
+    flat = cv2.dct(t32.astype(np.float32))[:8, :8].flatten()
+    margin = float(np.abs(flat - flat[1:].mean()).min())
+    return t32, t98, ph, dh, margin
+
+
+def make_sig():
+    cases = []   # (name, kind, params)
+    pixels = {}  # stored pixel arrays for 'stored' kind
+    # reference test images: tests/core/test_image_signature.py:24-27
+    for seed in list(range(20)) + [123]:
+        rng = np.random.default_rng(seed)
+        arr = (rng.random((64, 64, 3)) * 255).astype("uint8")
+        cases.append((f"ref_random64_seed{seed}", "stored", arr))
+    # synthetic corpus images (DESIGN.md "Synthetic data"), BASELINE configs 1, 2 and 5 shapes
+    for i in range(24):
+        cases.append((f"synth256_{i}", "synth", (i, 256, 256)))
+    for i in [0, 1, 9, 19, 29, 99]:
+        cases.append((f"synth512_{i}", "synth", (i, 512, 512)))
+    for (i, w, h) in [(3, 300, 451), (4, 1000, 37), (5, 33, 31), (6, 16, 16), (7, 32, 32), (8, 384, 768),
+                      (9, 1024, 256), (10, 2, 500), (11, 5, 500), (12, 640, 480), (13, 9, 8), (14, 31, 33),
+                      (15, 2048, 64), (16, 100, 1536), (17, 7, 7), (18, 1, 1), (19, 36, 36), (20, 510, 514)]:
+        cases.append((f"synth{w}x{h}_{i}", "synth", (i, w, h)))
+    # flats, ramps, symmetric: the tie cases
+    for v in (0, 128, 255):
+        cases.append((f"flat{v}", "stored", np.full((64, 64, 3), v, np.uint8)))
+    yy, xx = np.indices((96, 128))
+    cases.append(("ramp_x", "stored", np.repeat(((xx * 2) % 256).astype(np.uint8)[:, :, None], 3, 2)))
+    cases.append(("ramp_y", "stored", np.repeat(((yy * 2) % 256).astype(np.uint8)[:, :, None], 3, 2)))
+    cases.append(("checker8", "stored", np.repeat(((((yy // 8) + (xx // 8)) % 2) * 255).astype(np.uint8)[:, :, None], 3, 2)))
+    sym = np.random.default_rng(7).integers(0, 256, (64, 32, 3), dtype=np.uint8)
+    cases.append(("mirror_lr", "stored", np.concatenate([sym, sym[:, ::-1]], axis=1)))
+    # other PIL modes reach the path too: L and RGBA (alpha ignored by convert("L"))
+    cases.append(("mode_L", "stored", np.random.default_rng(8).integers(0, 256, (80, 100), dtype=np.uint8)))
+    cases.append(("mode_RGBA", "stored", np.random.default_rng(9).integers(0, 256, (70, 90, 4), dtype=np.uint8)))
+
+    out = {"names": [], "kind": [], "params": [], "sha256": [], "tile32": [], "tile98": [], "phash": [], "dhash": [],
+           "margin": []}
+    for name, kind, payload in cases:
+        if kind == "synth":
+            i, w, h = payload
+            arr = O.synth_rgb(i, w, h)
+            params = [i, w, h]
+        else:
+            arr = payload
+            params = [0, arr.shape[1], arr.shape[0]]
+            pixels["px_" + name] = arr
+        img = Image.fromarray(arr)  # mode L / RGB / RGBA by shape
+        t32, t98, ph, dh, margin = ref_hashes(img)
+        out["names"].append(name); out["kind"].append(kind); out["params"].append(params); out["sha256"].append(sha(arr))
+        out["tile32"].append(t32); out["tile98"].append(t98); out["phash"].append(ph); out["dhash"].append(dh)
+        out["margin"].append(margin)
+    np.savez_compressed(
+        os.path.join(HERE, "sig_golden.npz"),
+        names=np.array(out["names"]), kind=np.array(out["kind"]), params=np.array(out["params"], np.int64),
+        sha256=np.array(out["sha256"]), tile32=np.array(out["tile32"], np.uint8), tile98=np.array(out["tile98"], np.uint8),
+        phash=np.array(out["phash"], np.uint64), dhash=np.array(out["dhash"], np.uint64),
+        margin=np.array(out["margin"], np.float64), dct_backend=np.array("scipy.fft.dctn(type=2,norm=ortho) float32"),
+        pillow_version=np.array(Image.__version__), **pixels)
+    print("sig cases:", len(cases), "min margin", min(out["margin"]))
+
+
+# ------------------------------------------------------------------ scanner
+class _Capture:
+    """Grab build_clusters' local `edges` dict and funnel counters when it returns."""
+
+    def __init__(self):
+        self.edges = None
+        self.counters = None
+
+    def __call__(self, frame, event, arg):
+        if event == "return" and frame.f_code.co_name == "build_clusters":
+            loc = frame.f_locals
+            if "edges" in loc:
+                self.edges = [(e.file_id_a, e.file_id_b, e.hamming) for e in loc["edges"].values()]
+                self.counters = [loc.get("pair_total", 0), loc.get("pair_after_size", 0), loc.get("pair_after_ham", 0),
+                                 loc.get("pair_after_cos", 0)]
+
+
+def run_scanner(files, cfg_kwargs, cap=None):
+    if cap is None:
+        os.environ.pop("KE_DUP_BUCKET_PAIR_CAP", None)
+    else:
+        os.environ["KE_DUP_BUCKET_PAIR_CAP"] = str(cap)
+    dfs = [DuplicateFile(file_id=f["file_id"], path=Path(f["path"]), size=f["size"], width=f["width"],
+                         height=f["height"], phash=f["phash"], embedding=None) for f in files]
+    cap_obj = _Capture()
+    sys.setprofile(cap_obj)
+    try:
+        clusters = DuplicateScanner(DuplicateScanConfig(**cfg_kwargs)).build_clusters(dfs)
+    finally:
+        sys.setprofile(None)
+        os.environ.pop("KE_DUP_BUCKET_PAIR_CAP", None)
+    return {
+        "config": cfg_kwargs, "bucket_pair_cap": cap,
+        "files": {k: [(str(f[k]) if k == "phash" else f[k]) for f in files]
+                  for k in ("file_id", "path", "size", "width", "height", "phash")},
+        "edges": sorted([[min(a, b), max(a, b), h] for a, b, h in (cap_obj.edges or [])]),
+        "counters": cap_obj.counters,
+        "clusters": [{"keeper_id": c.keeper_id, "entries": [[e.file.file_id, e.best_hamming] for e in c.files]} for c in clusters],
+    }
+
+
+def synth_files(hashes, ext_cycle=("png", "jpg", "webp", "jpeg", "bmp", "tif")):
+    files = []
+    for i, hv in enumerate(hashes):
+        files.append({"file_id": i + 1, "path": f"dir{i % 3}/img_{i:07d}.{ext_cycle[i % len(ext_cycle)]}",
+                      "size": 1000 + (i % 7), "width": 512 - (i % 5), "height": 512, "phash": int(hv)})
+    return files
+
+
+def make_scan():
+    scen = {}
+    # tests/dup/test_scanner.py:31-69
+    base = 0xFFFF_FFFF_0000_0000
+    scen["ref_test_keeper"] = run_scanner(
+        [{"file_id": 1, "path": "a.jpg", "size": 1000, "width": 640, "height": 480, "phash": base},
+         {"file_id": 2, "path": "b.png", "size": 2000, "width": 640, "height": 480, "phash": base ^ 1},
+         {"file_id": 3, "path": "c.jpg", "size": 1500, "width": 800, "height": 600, "phash": base ^ 2}],
+        {"hamming_threshold": 4})
+    # tests/dup/test_scanner.py:72-117 without embeddings (from_row never populates them, scanner.py:110-117)
+    b2 = 0xAAAA_AAAA_AAAA_AAAA
+    scen["ref_test_ratio"] = run_scanner(
+        [{"file_id": 1, "path": "small.jpg", "size": 100, "width": 100, "height": 100, "phash": b2},
+         {"file_id": 2, "path": "large.jpg", "size": 1000, "width": 100, "height": 100, "phash": b2},
+         {"file_id": 3, "path": "cosine_a.jpg", "size": 800, "width": 200, "height": 200, "phash": b2 ^ 1},
+         {"file_id": 4, "path": "cosine_b.jpg", "size": 820, "width": 200, "height": 200, "phash": b2 ^ 2},
+         {"file_id": 5, "path": "cosine_bad.jpg", "size": 830, "width": 200, "height": 200, "phash": b2 ^ 3}],
+        {"hamming_threshold": 4, "size_ratio": 0.5})
+    # tests/dup/test_scanner.py:153-163 (T=0 identical hashes)
+    scen["ref_test_t0"] = run_scanner(
+        [{"file_id": 1, "path": "a.jpg", "size": 100, "width": 10, "height": 10, "phash": 0x1234_5678_0000_0000},
+         {"file_id": 2, "path": "b.jpg", "size": 100, "width": 10, "height": 10, "phash": 0x1234_5678_0000_0000}],
+        {"hamming_threshold": 0})
+    # banding != all-pairs: SURVEY finding 3 (N=1000 planted corpus, T=8)
+    h1000 = O.synth_hashes(1000)
+    scen["synth1000_t8"] = run_scanner(synth_files(h1000), {"hamming_threshold": 8})
+    scen["synth1000_t10"] = run_scanner(synth_files(h1000), {"hamming_threshold": 10})
+    scen["synth1000_t3"] = run_scanner(synth_files(h1000), {"hamming_threshold": 3})
+    scen["synth1000_t8_ratio"] = run_scanner(synth_files(h1000), {"hamming_threshold": 8, "size_ratio": 0.9985})
+    scen["synth1000_t8_bands8x8"] = run_scanner(synth_files(h1000), {"hamming_threshold": 8, "band_bits": 8, "band_count": 8})
+    scen["synth1000_t8_bands32x2"] = run_scanner(synth_files(h1000), {"hamming_threshold": 8, "band_bits": 32, "band_count": 2})
+    scen["synth1000_t8_bands12x3"] = run_scanner(synth_files(h1000), {"hamming_threshold": 8, "band_bits": 12, "band_count": 3})
+    scen["no_bucket_ge2"] = run_scanner(synth_files(h1000[:200]), {"hamming_threshold": 64})
+    # bucket cap: many files share the low band -> that bucket is skipped, others still link
+    rng = np.random.default_rng(5)
+    hot = [(int(rng.integers(0, 1 << 48)) << 16) | 0xBEEF for _ in range(40)]
+    for k in range(0, 40, 2):
+        hot[k + 1] = hot[k] ^ (1 << 20)  # near-dup partner sharing 3 bands
+    scen["bucket_cap"] = run_scanner(synth_files(hot + [int(v) for v in h1000[:100]]), {"hamming_threshold": 8}, cap=100)
+    scen["bucket_cap_off"] = run_scanner(synth_files(hot + [int(v) for v in h1000[:100]]), {"hamming_threshold": 8})
+    # duplicate file ids + signed hash inputs (readers re-mask, scanner.py:81,229).  Sources of the
+    # planted tail live in [0,900); give some planted copies the id of an unrelated file and of
+    # their own source, so "same id -> skip" (:266) and "first writer wins" (:287-290) both fire.
+    dup_files = synth_files([int(v) for v in h1000])
+    t8_edges = scen["synth1000_t8"]["edges"]
+    (a0, b0, _), (a1, b1, _), (a2, b2_, _) = t8_edges[0], t8_edges[1], t8_edges[2]
+    dup_files[b0 - 1]["file_id"] = a0            # edge endpoints share an id -> pair skipped
+    dup_files[5]["file_id"] = a1                 # unrelated hash carries the id of an edge endpoint
+    dup_files[b2_ - 1]["file_id"] = dup_files[7]["file_id"]  # edge endpoint renamed to another file's id
+    for f in dup_files[::3]:
+        if f["phash"] >= 1 << 63:
+            f["phash"] -= 1 << 64
+    scen["dup_ids_signed"] = run_scanner(dup_files, {"hamming_threshold": 10})
+    scen["t64_tail"] = run_scanner(synth_files([int(v) for v in h1000[850:1000]]), {"hamming_threshold": 64})
+    # sizes None / zero pass the ratio filter (scanner.py:362-366)
+    nz = synth_files([int(v) for v in h1000[900:1000]])
+    for k, f in enumerate(nz):
+        if k % 4 == 0:
+            f["size"] = None
+        if k % 4 == 1:
+            f["size"] = 0
+        if k % 4 == 2:
+            f["size"] = 10 + k
+    scen["sizes_none_zero"] = run_scanner(nz, {"hamming_threshold": 10, "size_ratio": 0.8})
+    scen["empty"] = run_scanner([], {"hamming_threshold": 8})
+    scen["single"] = run_scanner(synth_files([123]), {"hamming_threshold": 8})
+    with open(os.path.join(HERE, "scan_golden.json"), "w") as fh:
+        json.dump(scen, fh, separators=(",", ":"))
+    for k, v in scen.items():
+        print(f"scan {k}: files={len(v['files']['file_id'])} edges={len(v['edges'])} clusters={len(v['clusters'])} counters={v['counters']}")
+
+
+# ------------------------------------------------------------------ from_row (a7)
+def make_rows():
+    rows = [
+        {"file_id": 10, "path": "blob.png", "size": 12, "width": 3, "height": 4, "phash_bytes": (123).to_bytes(8, "big")},
+        {"id": 11, "file_path": "hex.png", "size": 12, "width": 3, "height": 4, "phash_hex": "ff"},
+        {"file_id": 1, "path": "x.jpg", "phash_u64": -1},
+        {"file_id": 2, "path": "x.JPG", "phash": "0x10", "size": 5.7, "width": "7", "height": None},
+        {"file_id": 3, "path": "y.webp", "phash64": "12345678901234567890"},
+        {"file_id": 4, "path": "z.tif", "signature": " 0b101 "},
+        {"file_id": 5, "path": "q", "sig": (1 << 70) + 5},
+        {"path": "noid.gif", "phash_u64": 7},
+        {"file_id": 6, "path": "bytes9.png", "phash_bytes": bytes(range(1, 10))},
+        {"file_id": 7, "path": "u.apng", "phash_u64": None, "phash": 99},
+    ]
+    bad = [
+        {"file_id": 1, "path": "broken.jpg", "phash_hex": "not-a-hex-value"},
+        {"file_id": 2, "path": "none.jpg"},
+        {"file_id": 3, "path": "empty.jpg", "phash": "   "},
+    ]
+    exp = []
+    for r in rows:
+        f = DuplicateFile.from_row(r)
+        exp.append({"file_id": f.file_id, "path": f.path.as_posix(), "size": f.size, "width": f.width,
+                    "height": f.height, "phash": str(f.phash), "resolution": f.resolution,
+                    "extension_priority": f.extension_priority})
+    for r in bad:
+        try:
+            DuplicateFile.from_row(r)
+            raise SystemExit("expected ValueError")
+        except ValueError as e:
+            assert "missing perceptual hash" in str(e)
+
+    def enc(r):
+        return {k: ({"__bytes__": v.hex()} if isinstance(v, bytes) else (str(v) if isinstance(v, int) and abs(v) > 1 << 53 else v))
+                for k, v in r.items()}
+
+    with open(os.path.join(HERE, "rows_golden.json"), "w") as fh:
+        json.dump({"rows": [enc(r) for r in rows], "expected": exp, "bad_rows": [enc(r) for r in bad]}, fh, indent=1)
+    print("rows:", len(rows), "bad:", len(bad))
+
+
+# ------------------------------------------------------------------ ssim (restatement, NOT the reference)
+def skimage_ssim_restated(a_u8: np.ndarray, b_u8: np.ndarray) -> float:
+    """skimage.metrics.structural_similarity(a/255 f32, b/255 f32, data_range=1.0), as called at
+    src/dup/refine.py:50-52: win 7, uniform_filter, K1=.01, K2=.03, sample covariance, crop 3."""
+    from scipy.ndimage import uniform_filter
+    x = np.asarray(a_u8, np.float32) / np.float32(255.0)
+    y = np.asarray(b_u8, np.float32) / np.float32(255.0)
+    ux, uy = uniform_filter(x, size=7), uniform_filter(y, size=7)
+    uxx, uyy, uxy = uniform_filter(x * x, size=7), uniform_filter(y * y, size=7), uniform_filter(x * y, size=7)
+    cn = np.float32(49.0 / 48.0)
+    vx, vy, vxy = cn * (uxx - ux * ux), cn * (uyy - uy * uy), cn * (uxy - ux * uy)
+    C1, C2 = np.float32(0.01 ** 2), np.float32(0.03 ** 2)
+    A1, A2, B1, B2 = 2 * ux * uy + C1, 2 * vxy + C2, ux ** 2 + uy ** 2 + C1, vx + vy + C2
+    S = (A1 * A2) / (B1 * B2)
+    return float(S[3:-3, 3:-3].mean(dtype=np.float64))
+
+
+def make_ssim():
+    pairs = []
+    from PIL import ImageEnhance
+    # tests/dup/test_refine.py:24-34 : solid (200,10,10) 64x64 vs brightness x1.02
+    a = Image.new("RGB", (64, 64), color=(200, 10, 10))
+    b = ImageEnhance.Brightness(a).enhance(1.02)
+    pairs.append(("ref_solid_bright", np.asarray(a.convert("L")), np.asarray(b.convert("L"))))
+    # tests/dup/test_refine.py:37-46 : green vs blue
+    pairs.append(("ref_green_blue", np.asarray(Image.new("RGB", (64, 64), (0, 255, 0)).convert("L")),
+                  np.asarray(Image.new("RGB", (64, 64), (0, 0, 255)).convert("L"))))
+    for (i, j, w, h) in [(O.synth_info(19)[0], 19, 256, 256), (O.synth_info(29)[0], 29, 512, 512), (0, 1, 256, 256), (19, 29, 128, 96), (2, 2, 64, 64), (3, 4, 7, 7), (5, 6, 40, 9)]:
+        la = np.asarray(Image.fromarray(O.synth_rgb(i, w, h)).convert("L"))
+        lb = np.asarray(Image.fromarray(O.synth_rgb(j, w, h)).convert("L"))
+        pairs.append((f"synth_{i}_{j}_{w}x{h}", la, lb))
+    rng = np.random.default_rng(11)
+    n1 = rng.integers(0, 256, (50, 70), dtype=np.uint8)
+    n2 = np.clip(n1.astype(int) + rng.integers(-6, 7, n1.shape), 0, 255).astype(np.uint8)
+    pairs.append(("noise_pm6", n1, n2))
+    store = {"names": np.array([p[0] for p in pairs]), "ssim": np.array([skimage_ssim_restated(p[1], p[2]) for p in pairs]),
+             "source": np.array("scipy.ndimage.uniform_filter restatement of skimage 0.25 structural_similarity (skimage absent)")}
+    for name, la, lb in pairs:
+        store["a_" + name] = la
+        store["b_" + name] = lb
+    np.savez_compressed(os.path.join(HERE, "ssim_golden.npz"), **store)
+    print("ssim:", dict(zip(store["names"].tolist(), store["ssim"].round(6).tolist())))
+
+
+if __name__ == "__main__":
+    logging.basicConfig(level=logging.WARNING)
+    make_sig()
+    make_scan()
+    make_rows()
+    make_ssim()

@@ -1,0 +1,150 @@
+/*
+ * keyes.h -- C ABI of libkeyes_hip.so, the MI355X (gfx950) replacement for the
+ * src/sig + src/dup hot path of kobato-eyes.
+ *
+ * The reference is pure Python and has no FFI of its own; each entry point below cites the
+ * reference code (paths relative to the reference checkout) whose work it takes over, and
+ * INTEGRATION.md shows the ctypes stub a maintainer would add on the reference side.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative KE_E* code; ke_last_error(ctx)
+ *     returns a human-readable message for the last failure on that context;
+ *   - no exceptions cross the boundary, no torch types appear in any signature;
+ *   - data pointers may be HOST or DEVICE memory (decided with hipPointerGetAttributes);
+ *     host buffers are staged through the context's pinned buffers;
+ *   - all work of a context is ordered on ONE HIP stream (ke_set_stream / ke_get_stream);
+ *     calls return after the work has been ENQUEUED when every pointer is device memory,
+ *     and after it has COMPLETED when any output pointer is host memory or the function
+ *     returns a count (ke_hamming_scan);
+ *   - a context is not re-entrant; use one per thread/device.  The library never falls
+ *     back to the CPU: without a gfx950 device ke_create fails.
+ */
+#ifndef KEYES_H
+#define KEYES_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KE_ABI_VERSION 1
+
+enum {
+    KE_OK = 0,
+    KE_EINVAL = -1,     /* bad argument */
+    KE_ENODEV = -2,     /* no usable HIP device */
+    KE_EHIP = -3,       /* a HIP runtime call failed (see ke_last_error) */
+    KE_ENOMEM = -4,
+    KE_EUNSUPPORTED = -5
+};
+
+/* per-image status written by ke_hash_images (reference: a failed image is dropped,
+ * src/core/fastsig.py:36-37) */
+enum { KE_IMG_OK = 0, KE_IMG_BAD_SHAPE = 1 };
+
+typedef struct ke_ctx ke_ctx;
+
+/* One candidate edge of the Hamming scan.  a < b are POSITIONS in the hash table handed to
+ * ke_hamming_scan (the reference keys edges by file id, src/dup/scanner.py:287-290; the host
+ * maps positions to ids).  bands: bit k set <=> band k of x_a ^ x_b is zero (and its bucket is
+ * under the pair cap), i.e. the pair meets in bucket (k, value) of src/dup/scanner.py:227-233. */
+typedef struct {
+    int64_t a;
+    int64_t b;
+    int32_t h;      /* hamming64(x_a, x_b), src/sig/phash.py:60-63 */
+    int32_t bands;
+} ke_edge;
+
+/* ---- context ------------------------------------------------------------------------- */
+int         ke_abi_version(void);
+ke_ctx     *ke_create(int device_id);               /* NULL on failure; see ke_create_error() */
+const char *ke_create_error(void);
+void        ke_destroy(ke_ctx *ctx);
+const char *ke_last_error(ke_ctx *ctx);
+int         ke_set_stream(ke_ctx *ctx, void *hip_stream);   /* NULL = the context's own stream */
+void       *ke_get_stream(ke_ctx *ctx);
+int         ke_synchronize(ke_ctx *ctx);
+int         ke_device_info(ke_ctx *ctx, char *name, size_t name_len, int32_t *compute_units,
+                           int64_t *total_mem_bytes);
+
+/* device memory helpers for hosts that do not bring their own allocator */
+int ke_malloc(ke_ctx *ctx, size_t bytes, void **dev_ptr_out);
+int ke_free(ke_ctx *ctx, void *dev_ptr);
+int ke_memcpy(ke_ctx *ctx, void *dst, const void *src, size_t bytes);   /* any direction, synchronous */
+
+/* ---- hashing: replaces sig.phash.phash / dhash (src/sig/phash.py:21-57) as driven by
+ * core.fastsig._compute_worker (src/core/fastsig.py:24-37) -------------------------------
+ * n interleaved 8-bit images.  channels: 1 (mode "L"), 3 (RGB) or 4 (RGBX/RGBA; the fourth
+ * byte is ignored, as Pillow's convert("L") ignores it).  Image i starts at
+ * pixels + offsets[i] (offsets == NULL: images are packed back to back) and is
+ * heights[i] rows of widths[i]*channels bytes, no row padding.
+ * phash_out / dhash_out: unsigned 64-bit hashes (either may be NULL).  The signed wrap of
+ * src/sig/phash.py:29-30 / src/core/fastsig.py:19-21 is the host's reinterpretation.
+ * status_out (nullable): KE_IMG_* per image; hashes of failed images are 0. */
+int ke_hash_images(ke_ctx *ctx, const uint8_t *pixels, const uint64_t *offsets, const int32_t *widths,
+                   const int32_t *heights, int32_t channels, int64_t n, uint64_t *phash_out,
+                   uint64_t *dhash_out, int32_t *status_out);
+
+/* Same, n equally sized images packed back to back (the BASELINE configs). */
+int ke_hash_uniform(ke_ctx *ctx, const uint8_t *pixels, int64_t n, int32_t width, int32_t height,
+                    int32_t channels, uint64_t *phash_out, uint64_t *dhash_out);
+
+/* Debug/parity hook: the resampled luma tiles the hashes are computed from
+ * (reference sig.phash._to_grayscale, src/sig/phash.py:21-26).  tile32_out: n*1024 bytes
+ * ([y][x]); tile98_out: n*72 bytes (8 rows x 9 columns); either may be NULL. */
+int ke_luma_tiles_uniform(ke_ctx *ctx, const uint8_t *pixels, int64_t n, int32_t width, int32_t height,
+                          int32_t channels, uint8_t *tile32_out, uint8_t *tile98_out);
+
+/* ---- candidate scan: replaces the bucket + pair loop of DuplicateScanner.build_clusters
+ * (src/dup/scanner.py:227-299) with an all-pairs tiled popcount scan whose predicate is the
+ * closed form of that loop:
+ *   edge(i,j), i<j  <=>  ids[i] != ids[j]  and  popcount(x_i ^ x_j) <= threshold
+ *                        and some band k < band_count has ((x_i ^ x_j) >> k*band_bits) & mask == 0
+ *                            (and, with bucket_pair_cap > 0, that bucket holds <= cap pairs)
+ *                        and size_ok(sizes[i], sizes[j], size_ratio)   (src/dup/scanner.py:358-370)
+ * ids / sizes may be NULL (ids default to positions; no size filter).  size_ratio <= 0 = off.
+ * The pair space is dealt tile-by-tile to `part_count` shards; this call evaluates shard
+ * `part_index` (one shard per GPU; 0/1 = everything).
+ * edges_out: capacity entries (host or device); *n_edges_out = edges found, which may exceed
+ * capacity -- the caller then retries with a larger buffer.  Edge order is unspecified.
+ * counters_out (nullable, 4 x u64, host): [0] pairs evaluated by this shard,
+ * [1] sum over emitted edges of the number of shared bands (the reference's "ham=" funnel
+ * counter, src/dup/scanner.py:292-299), [2] edges emitted, [3] reserved. */
+int ke_hamming_scan(ke_ctx *ctx, const uint64_t *hashes, const int64_t *ids, const int64_t *sizes, int64_t n,
+                    int32_t part_index, int32_t part_count, int32_t threshold, int32_t band_bits,
+                    int32_t band_count, double size_ratio, int64_t bucket_pair_cap, ke_edge *edges_out,
+                    int64_t capacity, int64_t *n_edges_out, uint64_t *counters_out);
+
+/* Connected components of the candidate graph (DisjointSet, src/dup/scanner.py:176-200,
+ * 304-318; ClusterBuilder union-find, src/dup/cluster.py:30-46).  HOST function, no device
+ * work: label_out[v] = smallest node of v's component for v < n_nodes. */
+int ke_cluster_labels(const ke_edge *edges, int64_t n_edges, int64_t n_nodes, int64_t *label_out);
+
+/* ---- SSIM refine: replaces dup.refine._compute_ssim (src/dup/refine.py:44-52 ->
+ * skimage.metrics.structural_similarity, 7x7 uniform window, float32, data_range 1) for
+ * pairs of equally sized images.  images: n_images interleaved images of width x height x
+ * channels (1, 3 or 4; luma is taken exactly as convert("L") does), packed back to back.
+ * pair_a/pair_b index into them.  ssim_out[k] is NaN when width or height < 7. */
+int ke_ssim_pairs_uniform(ke_ctx *ctx, const uint8_t *images, int64_t n_images, int32_t width,
+                          int32_t height, int32_t channels, const int64_t *pair_a, const int64_t *pair_b,
+                          int64_t n_pairs, double *ssim_out);
+
+/* ---- synthetic corpus (BASELINE configs; DESIGN.md "Synthetic data") --------------------
+ * Writes images [first_index, first_index+n) of the counter-based corpus as packed RGB into
+ * device or host memory; ke_synth_hashes writes the scan-only hash table. */
+int ke_synth_rgb(ke_ctx *ctx, uint64_t seed, int64_t first_index, int64_t n, int32_t width, int32_t height,
+                 uint8_t *rgb_out);
+int ke_synth_hashes(ke_ctx *ctx, uint64_t seed, int64_t n, uint64_t *hashes_out);
+
+/* ---- timing hook for bench.py: wall time of the kernels enqueued by the LAST call of the
+ * named kind on this context, measured with hipEvents on the context's stream.
+ * kind: 0 = hash kernel(s), 1 = scan kernel, 2 = ssim kernel, 3 = synth kernel.
+ * Returns milliseconds, or a negative value if nothing was recorded.  Blocks until done. */
+double ke_last_kernel_ms(ke_ctx *ctx, int32_t kind);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KEYES_H */

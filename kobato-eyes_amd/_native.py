@@ -1,0 +1,291 @@
+"""ctypes binding of libkeyes_hip.so (include/keyes.h).
+
+The product path has NO CPU fallback: if the shared library is missing, or no gfx950 device
+is visible, every entry point raises ``RuntimeError`` -- the same way the reference's
+``phash`` raises when OpenCV is missing (src/sig/phash.py:35-36).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+from typing import Optional, Sequence
+
+import numpy as np
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG_DIR, "libkeyes_hip.so")
+
+KE_OK = 0
+EDGE_DTYPE = np.dtype([("a", "<i8"), ("b", "<i8"), ("h", "<i4"), ("bands", "<i4")])
+
+# every symbol include/keyes.h declares (tests check the library exports all of them)
+EXPORTS = (
+    "ke_abi_version", "ke_create", "ke_create_error", "ke_destroy", "ke_last_error", "ke_set_stream",
+    "ke_get_stream", "ke_synchronize", "ke_device_info", "ke_malloc", "ke_free", "ke_memcpy",
+    "ke_hash_images", "ke_hash_uniform", "ke_luma_tiles_uniform", "ke_hamming_scan", "ke_cluster_labels",
+    "ke_ssim_pairs_uniform", "ke_synth_rgb", "ke_synth_hashes", "ke_last_kernel_ms",
+)
+
+_lib: Optional[C.CDLL] = None
+_lib_lock = threading.Lock()
+
+
+class NativeUnavailable(RuntimeError):
+    """libkeyes_hip.so (or a gfx950 device) is not available."""
+
+
+def load_library() -> C.CDLL:
+    """Load libkeyes_hip.so and declare the prototypes.  Does not touch the GPU."""
+    global _lib
+    with _lib_lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise NativeUnavailable(
+                f"{LIB_PATH} is missing: build it with kobato-eyes_amd/build.sh (hipcc, gfx950). "
+                "There is no CPU fallback for the hash/scan path."
+            )
+        try:
+            lib = C.CDLL(LIB_PATH)
+        except OSError as exc:  # e.g. libamdhip64 not found
+            raise NativeUnavailable(f"cannot load {LIB_PATH}: {exc}") from exc
+        vp, i32, i64, u64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_double
+        lib.ke_abi_version.restype = C.c_int
+        lib.ke_create.argtypes = [C.c_int]
+        lib.ke_create.restype = vp
+        lib.ke_create_error.restype = C.c_char_p
+        lib.ke_destroy.argtypes = [vp]
+        lib.ke_destroy.restype = None
+        lib.ke_last_error.argtypes = [vp]
+        lib.ke_last_error.restype = C.c_char_p
+        lib.ke_set_stream.argtypes = [vp, vp]
+        lib.ke_get_stream.argtypes = [vp]
+        lib.ke_get_stream.restype = vp
+        lib.ke_synchronize.argtypes = [vp]
+        lib.ke_device_info.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(i32), C.POINTER(i64)]
+        lib.ke_malloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+        lib.ke_free.argtypes = [vp, vp]
+        lib.ke_memcpy.argtypes = [vp, vp, vp, C.c_size_t]
+        lib.ke_hash_images.argtypes = [vp, vp, vp, vp, vp, i32, i64, vp, vp, vp]
+        lib.ke_hash_uniform.argtypes = [vp, vp, i64, i32, i32, i32, vp, vp]
+        lib.ke_luma_tiles_uniform.argtypes = [vp, vp, i64, i32, i32, i32, vp, vp]
+        lib.ke_hamming_scan.argtypes = [vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, dbl, i64, vp, i64,
+                                        C.POINTER(i64), vp]
+        lib.ke_cluster_labels.argtypes = [vp, i64, i64, vp]
+        lib.ke_ssim_pairs_uniform.argtypes = [vp, vp, i64, i32, i32, i32, vp, vp, i64, vp]
+        lib.ke_synth_rgb.argtypes = [vp, u64, i64, i64, i32, i32, vp]
+        lib.ke_synth_hashes.argtypes = [vp, u64, i64, vp]
+        lib.ke_last_kernel_ms.argtypes = [vp, i32]
+        lib.ke_last_kernel_ms.restype = dbl
+        for name in ("ke_set_stream", "ke_synchronize", "ke_device_info", "ke_malloc", "ke_free", "ke_memcpy",
+                     "ke_hash_images", "ke_hash_uniform", "ke_luma_tiles_uniform", "ke_hamming_scan",
+                     "ke_cluster_labels", "ke_ssim_pairs_uniform", "ke_synth_rgb", "ke_synth_hashes"):
+            getattr(lib, name).restype = C.c_int
+        _lib = lib
+        return lib
+
+
+def _addr(buf) -> Optional[int]:
+    """Address of a host ndarray, a raw device pointer (int) or None."""
+    if buf is None:
+        return None
+    if isinstance(buf, np.ndarray):
+        return buf.ctypes.data
+    if isinstance(buf, int):
+        return buf
+    if hasattr(buf, "data_ptr"):  # torch tensor (host or device): plumbing only
+        return int(buf.data_ptr())
+    raise TypeError(f"unsupported buffer type {type(buf)!r}")
+
+
+class Context:
+    """One ke_ctx: a device, a stream, scratch buffers.  Not re-entrant."""
+
+    def __init__(self, device: int = 0) -> None:
+        self._lib = load_library()
+        self._h = self._lib.ke_create(int(device))
+        if not self._h:
+            msg = self._lib.ke_create_error().decode("utf-8", "replace")
+            raise NativeUnavailable(f"ke_create({device}) failed: {msg}")
+        self.device = int(device)
+        self._lock = threading.Lock()
+
+    # -- lifetime ---------------------------------------------------------------------------
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.ke_destroy(self._h)
+            self._h = None
+
+    def __del__(self) -> None:  # pragma: no cover - interpreter shutdown order
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int, what: str) -> None:
+        if rc != KE_OK:
+            msg = self._lib.ke_last_error(self._h).decode("utf-8", "replace")
+            if rc == -1:
+                raise ValueError(f"{what}: {msg}")
+            raise RuntimeError(f"{what} failed (rc={rc}): {msg}")
+
+    # -- plumbing ---------------------------------------------------------------------------
+    def set_stream(self, hip_stream: Optional[int]) -> None:
+        self._check(self._lib.ke_set_stream(self._h, hip_stream), "ke_set_stream")
+
+    def synchronize(self) -> None:
+        self._check(self._lib.ke_synchronize(self._h), "ke_synchronize")
+
+    def device_info(self) -> dict:
+        name = C.create_string_buffer(256)
+        cus, mem = C.c_int32(), C.c_int64()
+        self._check(self._lib.ke_device_info(self._h, name, 256, C.byref(cus), C.byref(mem)), "ke_device_info")
+        return {"name": name.value.decode(), "compute_units": cus.value, "total_mem": mem.value}
+
+    def malloc(self, nbytes: int) -> int:
+        p = C.c_void_p()
+        self._check(self._lib.ke_malloc(self._h, nbytes, C.byref(p)), "ke_malloc")
+        return int(p.value)
+
+    def free(self, ptr: int) -> None:
+        self._check(self._lib.ke_free(self._h, ptr), "ke_free")
+
+    def memcpy(self, dst, src, nbytes: int) -> None:
+        self._check(self._lib.ke_memcpy(self._h, _addr(dst), _addr(src), nbytes), "ke_memcpy")
+
+    def last_kernel_ms(self, kind: int) -> float:
+        return float(self._lib.ke_last_kernel_ms(self._h, kind))
+
+    # -- hashing ----------------------------------------------------------------------------
+    def hash_uniform(self, pixels, n: int, width: int, height: int, channels: int, *, want_phash=True,
+                     want_dhash=True, phash_out=None, dhash_out=None):
+        """pixels: host ndarray (n,h,w[,c]) u8 or a device pointer.  Returns (phash u64[n] | None, dhash | None)
+        as host arrays unless explicit output buffers (host arrays or device pointers) are given."""
+        if isinstance(pixels, np.ndarray):
+            pixels = np.ascontiguousarray(pixels, dtype=np.uint8)
+            if pixels.size != n * width * height * channels:
+                raise ValueError("pixel buffer does not match n*h*w*c")
+        ph = phash_out if phash_out is not None else (np.empty(n, np.uint64) if want_phash else None)
+        dh = dhash_out if dhash_out is not None else (np.empty(n, np.uint64) if want_dhash else None)
+        with self._lock:
+            self._check(self._lib.ke_hash_uniform(self._h, _addr(pixels), n, width, height, channels, _addr(ph),
+                                                  _addr(dh)), "ke_hash_uniform")
+        return ph, dh
+
+    def luma_tiles_uniform(self, pixels, n: int, width: int, height: int, channels: int, *, want32=True, want98=True):
+        if isinstance(pixels, np.ndarray):
+            pixels = np.ascontiguousarray(pixels, dtype=np.uint8)
+        t32 = np.empty((n, 32, 32), np.uint8) if want32 else None
+        t98 = np.empty((n, 8, 9), np.uint8) if want98 else None
+        with self._lock:
+            self._check(self._lib.ke_luma_tiles_uniform(self._h, _addr(pixels), n, width, height, channels, _addr(t32),
+                                                        _addr(t98)), "ke_luma_tiles_uniform")
+        return t32, t98
+
+    def hash_images(self, images: Sequence[np.ndarray], *, want_dhash=True):
+        """Ragged batch of host images sharing one channel count.  Returns (phash, dhash|None, status)."""
+        n = len(images)
+        if n == 0:
+            return np.empty(0, np.uint64), (np.empty(0, np.uint64) if want_dhash else None), np.empty(0, np.int32)
+        chans = {1 if im.ndim == 2 else im.shape[2] for im in images}
+        if len(chans) != 1:
+            raise ValueError("all images of one call must share the channel count")
+        ch = chans.pop()
+        widths = np.array([im.shape[1] for im in images], np.int32)
+        heights = np.array([im.shape[0] for im in images], np.int32)
+        sizes = widths.astype(np.int64) * heights * ch
+        offsets = np.zeros(n, np.uint64)
+        offsets[1:] = np.cumsum(sizes[:-1]).astype(np.uint64)
+        flat = np.empty(int(sizes.sum()), np.uint8)
+        for im, off, sz in zip(images, offsets, sizes):
+            flat[int(off):int(off) + int(sz)] = np.ascontiguousarray(im, dtype=np.uint8).reshape(-1)
+        ph = np.empty(n, np.uint64)
+        dh = np.empty(n, np.uint64) if want_dhash else None
+        status = np.empty(n, np.int32)
+        with self._lock:
+            self._check(self._lib.ke_hash_images(self._h, _addr(flat), _addr(offsets), _addr(widths), _addr(heights), ch, n,
+                                                 _addr(ph), _addr(dh), _addr(status)), "ke_hash_images")
+        return ph, dh, status
+
+    # -- scan -------------------------------------------------------------------------------
+    def hamming_scan(self, hashes, n: int, *, ids=None, sizes=None, threshold=8, band_bits=16, band_count=4,
+                     size_ratio: float = 0.0, bucket_pair_cap: int = 0, part_index=0, part_count=1,
+                     capacity: Optional[int] = None):
+        """Returns (edges[EDGE_DTYPE] on the host, counters u64[4]).  hashes/ids/sizes: host arrays or device ptrs."""
+        def host(a, dt):
+            return np.ascontiguousarray(a, dtype=dt) if isinstance(a, (np.ndarray, list, tuple)) else a
+
+        hashes, ids, sizes = host(hashes, np.uint64), host(ids, np.int64), host(sizes, np.int64)
+        cap = int(capacity) if capacity else max(1 << 16, 2 * int(n))
+        counters = np.zeros(4, np.uint64)
+        n_edges = C.c_int64(0)
+        while True:
+            edges = np.empty(cap, EDGE_DTYPE)
+            with self._lock:
+                self._check(self._lib.ke_hamming_scan(self._h, _addr(hashes), _addr(ids), _addr(sizes), n, part_index,
+                                                      part_count, threshold, band_bits, band_count, float(size_ratio),
+                                                      int(bucket_pair_cap), _addr(edges), cap, C.byref(n_edges),
+                                                      _addr(counters)), "ke_hamming_scan")
+            if n_edges.value <= cap:
+                return edges[: n_edges.value], counters
+            cap = int(n_edges.value)  # overflow protocol: retry with the reported size
+
+    def cluster_labels(self, edges: np.ndarray, n_nodes: int) -> np.ndarray:
+        edges = np.ascontiguousarray(edges, dtype=EDGE_DTYPE)
+        labels = np.empty(n_nodes, np.int64)
+        rc = self._lib.ke_cluster_labels(_addr(edges), len(edges), n_nodes, _addr(labels))
+        if rc != KE_OK:
+            raise ValueError("ke_cluster_labels: edge endpoint outside [0, n_nodes)")
+        return labels
+
+    # -- ssim -------------------------------------------------------------------------------
+    def ssim_pairs_uniform(self, images, n_images: int, width: int, height: int, channels: int, pair_a, pair_b):
+        if isinstance(images, np.ndarray):
+            images = np.ascontiguousarray(images, dtype=np.uint8)
+        pa = np.ascontiguousarray(pair_a, dtype=np.int64)
+        pb = np.ascontiguousarray(pair_b, dtype=np.int64)
+        out = np.empty(len(pa), np.float64)
+        with self._lock:
+            self._check(self._lib.ke_ssim_pairs_uniform(self._h, _addr(images), n_images, width, height, channels, _addr(pa),
+                                                        _addr(pb), len(pa), _addr(out)), "ke_ssim_pairs_uniform")
+        return out
+
+    # -- synthetic corpus ---------------------------------------------------------------------
+    def synth_rgb(self, seed: int, first: int, n: int, width: int, height: int, out=None):
+        if out is None:
+            out = np.empty((n, height, width, 3), np.uint8)
+        with self._lock:
+            self._check(self._lib.ke_synth_rgb(self._h, seed, first, n, width, height, _addr(out)), "ke_synth_rgb")
+        return out
+
+    def synth_hashes(self, seed: int, n: int, out=None):
+        if out is None:
+            out = np.empty(n, np.uint64)
+        with self._lock:
+            self._check(self._lib.ke_synth_hashes(self._h, seed, n, _addr(out)), "ke_synth_hashes")
+        return out
+
+
+_default: dict[int, Context] = {}
+_default_lock = threading.Lock()
+
+
+def get_context(device: int = 0) -> Context:
+    """Process-wide context per device (created on first use)."""
+    with _default_lock:
+        ctx = _default.get(device)
+        if ctx is None:
+            ctx = _default[device] = Context(device)
+        return ctx
+
+
+def cluster_labels(edges: np.ndarray, n_nodes: int) -> np.ndarray:
+    """Host-only entry point (no device needed): connected-component labels."""
+    lib = load_library()
+    edges = np.ascontiguousarray(edges, dtype=EDGE_DTYPE)
+    labels = np.empty(n_nodes, np.int64)
+    rc = lib.ke_cluster_labels(_addr(edges), len(edges), n_nodes, _addr(labels))
+    if rc != KE_OK:
+        raise ValueError("ke_cluster_labels: edge endpoint outside [0, n_nodes)")
+    return labels

@@ -1,0 +1,539 @@
+// ke_api.hip -- C ABI of libkeyes_hip.so: context, memory staging, argument checking and
+// dispatch into the kernel launchers.  See include/keyes.h for the contract and the
+// reference lines each entry point replaces.
+#include <cstdarg>
+#include <cstdio>
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+
+#include "ke_internal.h"
+
+static thread_local std::string g_create_err;
+
+int ke_fail(ke_ctx *ctx, int code, const char *fmt, ...) {
+    char msg[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(msg, sizeof msg, fmt, ap);
+    va_end(ap);
+    if (ctx)
+        ctx->err = msg;
+    else
+        g_create_err = msg;
+    (void)hipGetLastError();  // clear the sticky error so later calls can proceed
+    return code;
+}
+
+bool ke_is_device_ptr(const void *p) {
+    if (!p) return false;
+    hipPointerAttribute_t a;
+    std::memset(&a, 0, sizeof a);
+    hipError_t e = hipPointerGetAttributes(&a, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return false;  // plain host memory
+    }
+    return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
+}
+
+int ke_reserve(ke_ctx *ctx, int which, size_t bytes, void **out) {
+    KeDevBuf &b = ctx->buf[which];
+    if (bytes == 0) bytes = 16;
+    if (b.bytes < bytes) {
+        if (b.ptr) {
+            KE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            KE_HIP(ctx, hipFree(b.ptr));
+            b.ptr = nullptr;
+            b.bytes = 0;
+        }
+        size_t want = (bytes + 255) & ~(size_t)255;
+        KE_HIP(ctx, hipMalloc(&b.ptr, want));
+        b.bytes = want;
+    }
+    *out = b.ptr;
+    return KE_OK;
+}
+
+int ke_to_device(ke_ctx *ctx, const void *p, size_t bytes, int which, const void **dev) {
+    if (!p) {
+        *dev = nullptr;
+        return KE_OK;
+    }
+    if (ke_is_device_ptr(p)) {
+        *dev = p;
+        return KE_OK;
+    }
+    void *d = nullptr;
+    KE_TRY(ke_reserve(ctx, which, bytes, &d));
+    if (bytes) KE_HIP(ctx, hipMemcpyAsync(d, p, bytes, hipMemcpyHostToDevice, ctx->stream));
+    *dev = d;
+    return KE_OK;
+}
+
+static int upload_i32(ke_ctx *ctx, const std::vector<int32_t> &v, int32_t **out) {
+    KE_HIP(ctx, hipMalloc((void **)out, std::max<size_t>(v.size(), 4) * sizeof(int32_t)));
+    if (!v.empty())
+        KE_HIP(ctx, hipMemcpy(*out, v.data(), v.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    return KE_OK;
+}
+
+const KeAxisCoeffs *ke_get_coeffs(ke_ctx *ctx, int in_size, int out_size) {
+    auto key = std::make_pair(in_size, out_size);
+    auto it = ctx->coeffs.find(key);
+    if (it != ctx->coeffs.end()) return it->second;
+    auto *c = new KeAxisCoeffs();
+    ke_build_axis_coeffs(in_size, out_size, *c);
+    if (upload_i32(ctx, c->bounds, &c->d_bounds) || upload_i32(ctx, c->kk, &c->d_kk) ||
+        upload_i32(ctx, c->start, &c->d_start) || upload_i32(ctx, c->bias, &c->d_bias) ||
+        upload_i32(ctx, c->packed, &c->d_packed)) {
+        delete c;
+        return nullptr;
+    }
+    ctx->coeffs[key] = c;
+    return c;
+}
+
+void ke_time_begin(ke_ctx *ctx, int kind) {
+    ctx->ev_valid[kind] = false;
+    (void)hipEventRecord(ctx->ev0[kind], ctx->stream);
+}
+
+void ke_time_end(ke_ctx *ctx, int kind) {
+    if (hipEventRecord(ctx->ev1[kind], ctx->stream) == hipSuccess) ctx->ev_valid[kind] = true;
+}
+
+// ---- context -------------------------------------------------------------------------------
+KE_API int ke_abi_version(void) { return KE_ABI_VERSION; }
+
+KE_API const char *ke_create_error(void) { return g_create_err.c_str(); }
+
+KE_API ke_ctx *ke_create(int device_id) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+        ke_fail(nullptr, KE_ENODEV, "no HIP device visible (libkeyes_hip has no CPU fallback)");
+        return nullptr;
+    }
+    if (device_id < 0 || device_id >= count) {
+        ke_fail(nullptr, KE_EINVAL, "device_id %d out of range [0,%d)", device_id, count);
+        return nullptr;
+    }
+    if (hipSetDevice(device_id) != hipSuccess) {
+        ke_fail(nullptr, KE_EHIP, "hipSetDevice(%d) failed", device_id);
+        return nullptr;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) {
+        ke_fail(nullptr, KE_EHIP, "hipGetDeviceProperties failed");
+        return nullptr;
+    }
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        ke_fail(nullptr, KE_ENODEV, "device %d is %s; this library is built for gfx950 only", device_id,
+                prop.gcnArchName);
+        return nullptr;
+    }
+    auto *ctx = new ke_ctx();
+    ctx->device = device_id;
+    ctx->cu_count = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        ke_fail(nullptr, KE_EHIP, "hipStreamCreate failed");
+        delete ctx;
+        return nullptr;
+    }
+    ctx->stream = ctx->own_stream;
+    for (int k = 0; k < KE_T_COUNT; ++k) {
+        (void)hipEventCreate(&ctx->ev0[k]);
+        (void)hipEventCreate(&ctx->ev1[k]);
+    }
+    return ctx;
+}
+
+KE_API void ke_destroy(ke_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &b : ctx->buf)
+        if (b.ptr) (void)hipFree(b.ptr);
+    for (auto &kv : ctx->coeffs) {
+        KeAxisCoeffs *c = kv.second;
+        for (int32_t *p : {c->d_bounds, c->d_kk, c->d_start, c->d_bias, c->d_packed})
+            if (p) (void)hipFree(p);
+        delete c;
+    }
+    for (int k = 0; k < KE_T_COUNT; ++k) {
+        (void)hipEventDestroy(ctx->ev0[k]);
+        (void)hipEventDestroy(ctx->ev1[k]);
+    }
+    (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+KE_API const char *ke_last_error(ke_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+KE_API int ke_set_stream(ke_ctx *ctx, void *hip_stream) {
+    if (!ctx) return KE_EINVAL;
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return KE_OK;
+}
+
+KE_API void *ke_get_stream(ke_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+KE_API int ke_synchronize(ke_ctx *ctx) {
+    if (!ctx) return KE_EINVAL;
+    KE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return KE_OK;
+}
+
+KE_API int ke_device_info(ke_ctx *ctx, char *name, size_t name_len, int32_t *compute_units, int64_t *total_mem) {
+    if (!ctx) return KE_EINVAL;
+    hipDeviceProp_t prop;
+    KE_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
+    if (name && name_len) std::snprintf(name, name_len, "%s (%s)", prop.name, prop.gcnArchName);
+    if (compute_units) *compute_units = prop.multiProcessorCount;
+    if (total_mem) *total_mem = (int64_t)prop.totalGlobalMem;
+    return KE_OK;
+}
+
+KE_API int ke_malloc(ke_ctx *ctx, size_t bytes, void **out) {
+    if (!ctx || !out) return KE_EINVAL;
+    KE_HIP(ctx, hipMalloc(out, bytes ? bytes : 16));
+    return KE_OK;
+}
+
+KE_API int ke_free(ke_ctx *ctx, void *p) {
+    if (!ctx) return KE_EINVAL;
+    KE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    KE_HIP(ctx, hipFree(p));
+    return KE_OK;
+}
+
+KE_API int ke_memcpy(ke_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    if (!ctx || (!dst && bytes) || (!src && bytes)) return KE_EINVAL;
+    if (!bytes) return KE_OK;
+    KE_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, ctx->stream));
+    KE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return KE_OK;
+}
+
+KE_API double ke_last_kernel_ms(ke_ctx *ctx, int32_t kind) {
+    if (!ctx || kind < 0 || kind >= KE_T_COUNT || !ctx->ev_valid[kind]) return -1.0;
+    if (hipEventSynchronize(ctx->ev1[kind]) != hipSuccess) return -1.0;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, ctx->ev0[kind], ctx->ev1[kind]) != hipSuccess) return -1.0;
+    return (double)ms;
+}
+
+// ---- hashing -------------------------------------------------------------------------------
+namespace {
+
+struct HashOutputs {
+    uint64_t *d_phash = nullptr, *d_dhash = nullptr;
+    uint8_t *d_t32 = nullptr, *d_t98 = nullptr;
+    bool stage_p = false, stage_d = false, stage_t32 = false, stage_t98 = false;
+};
+
+// Chunk size for host-resident pixel input: bounded staging buffer.
+constexpr size_t kStageBytes = (size_t)1 << 30;
+
+int hash_uniform_impl(ke_ctx *ctx, const uint8_t *pixels, int64_t n, int w, int h, int ch, uint64_t *phash_out,
+                      uint64_t *dhash_out, uint8_t *t32_out, uint8_t *t98_out) {
+    if (!ctx) return KE_EINVAL;
+    if (n < 0 || (n > 0 && !pixels)) return ke_fail(ctx, KE_EINVAL, "pixels is NULL");
+    if (w <= 0 || h <= 0) return ke_fail(ctx, KE_EINVAL, "width/height must be positive (got %dx%d)", w, h);
+    if (ch != 1 && ch != 3 && ch != 4) return ke_fail(ctx, KE_EINVAL, "channels must be 1, 3 or 4 (got %d)", ch);
+    if (n == 0) return KE_OK;
+    KE_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t img_bytes = (size_t)w * h * ch;
+    const bool in_dev = ke_is_device_ptr(pixels);
+    HashOutputs o;
+    o.stage_p = phash_out && !ke_is_device_ptr(phash_out);
+    o.stage_d = dhash_out && !ke_is_device_ptr(dhash_out);
+    o.stage_t32 = t32_out && !ke_is_device_ptr(t32_out);
+    o.stage_t98 = t98_out && !ke_is_device_ptr(t98_out);
+    const int64_t chunk = in_dev ? n : std::max<int64_t>(1, (int64_t)(kStageBytes / img_bytes));
+    ke_time_begin(ctx, KE_T_HASH);
+    for (int64_t first = 0; first < n; first += chunk) {
+        const int64_t m = std::min(chunk, n - first);
+        const void *d_px = nullptr;
+        KE_TRY(ke_to_device(ctx, pixels + (size_t)first * img_bytes, (size_t)m * img_bytes, KE_BUF_PIXELS, &d_px));
+        void *tmp;
+        o.d_phash = phash_out ? phash_out + first : nullptr;
+        o.d_dhash = dhash_out ? dhash_out + first : nullptr;
+        o.d_t32 = t32_out ? t32_out + (size_t)first * 1024 : nullptr;
+        o.d_t98 = t98_out ? t98_out + (size_t)first * 72 : nullptr;
+        if (o.stage_p) { KE_TRY(ke_reserve(ctx, KE_BUF_OUT0, (size_t)m * 8, &tmp)); o.d_phash = (uint64_t *)tmp; }
+        if (o.stage_d) { KE_TRY(ke_reserve(ctx, KE_BUF_OUT1, (size_t)m * 8, &tmp)); o.d_dhash = (uint64_t *)tmp; }
+        // tiles requested by a host caller are produced straight into the scratch tile buffers
+        KeHashGroup g{(const uint8_t *)d_px, nullptr, img_bytes, nullptr, m, w, h, ch};
+        uint8_t *d_t32 = o.stage_t32 ? nullptr : o.d_t32, *d_t98 = o.stage_t98 ? nullptr : o.d_t98;
+        if (o.stage_t32) { KE_TRY(ke_reserve(ctx, KE_BUF_SSIM_IN, (size_t)m * 1024, &tmp)); d_t32 = (uint8_t *)tmp; }
+        if (o.stage_t98) { KE_TRY(ke_reserve(ctx, KE_BUF_SSIM_AUX, (size_t)m * 72, &tmp)); d_t98 = (uint8_t *)tmp; }
+        KE_TRY(ke_launch_hash_group(ctx, g, o.d_phash, o.d_dhash, d_t32, d_t98));
+        if (o.stage_p)
+            KE_HIP(ctx, hipMemcpyAsync(phash_out + first, o.d_phash, (size_t)m * 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (o.stage_d)
+            KE_HIP(ctx, hipMemcpyAsync(dhash_out + first, o.d_dhash, (size_t)m * 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (o.stage_t32)
+            KE_HIP(ctx, hipMemcpyAsync(t32_out + (size_t)first * 1024, d_t32, (size_t)m * 1024, hipMemcpyDeviceToHost, ctx->stream));
+        if (o.stage_t98)
+            KE_HIP(ctx, hipMemcpyAsync(t98_out + (size_t)first * 72, d_t98, (size_t)m * 72, hipMemcpyDeviceToHost, ctx->stream));
+        if (!in_dev || o.stage_p || o.stage_d || o.stage_t32 || o.stage_t98)
+            KE_HIP(ctx, hipStreamSynchronize(ctx->stream));  // staging buffers are reused by the next chunk
+    }
+    ke_time_end(ctx, KE_T_HASH);
+    return KE_OK;
+}
+
+}  // namespace
+
+KE_API int ke_hash_uniform(ke_ctx *ctx, const uint8_t *pixels, int64_t n, int32_t width, int32_t height,
+                           int32_t channels, uint64_t *phash_out, uint64_t *dhash_out) {
+    return hash_uniform_impl(ctx, pixels, n, width, height, channels, phash_out, dhash_out, nullptr, nullptr);
+}
+
+KE_API int ke_luma_tiles_uniform(ke_ctx *ctx, const uint8_t *pixels, int64_t n, int32_t width, int32_t height,
+                                 int32_t channels, uint8_t *tile32_out, uint8_t *tile98_out) {
+    return hash_uniform_impl(ctx, pixels, n, width, height, channels, nullptr, nullptr, tile32_out, tile98_out);
+}
+
+KE_API int ke_hash_images(ke_ctx *ctx, const uint8_t *pixels, const uint64_t *offsets, const int32_t *widths,
+                          const int32_t *heights, int32_t channels, int64_t n, uint64_t *phash_out,
+                          uint64_t *dhash_out, int32_t *status_out) {
+    if (!ctx) return KE_EINVAL;
+    if (n < 0 || (n > 0 && (!pixels || !widths || !heights)))
+        return ke_fail(ctx, KE_EINVAL, "pixels/widths/heights must be non-NULL");
+    if (channels != 1 && channels != 3 && channels != 4)
+        return ke_fail(ctx, KE_EINVAL, "channels must be 1, 3 or 4 (got %d)", channels);
+    if (ke_is_device_ptr(widths) || ke_is_device_ptr(heights) || ke_is_device_ptr(offsets) ||
+        ke_is_device_ptr(status_out))
+        return ke_fail(ctx, KE_EINVAL, "offsets/widths/heights/status are metadata and must be host arrays");
+    if (n == 0) return KE_OK;
+    KE_HIP(ctx, hipSetDevice(ctx->device));
+    // byte offset of every image, then group equal shapes (one launch group per distinct size)
+    std::vector<uint64_t> off((size_t)n);
+    uint64_t run = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        off[i] = offsets ? offsets[i] : run;
+        if (widths[i] > 0 && heights[i] > 0) run += (uint64_t)widths[i] * heights[i] * channels;
+    }
+    std::map<std::pair<int, int>, std::vector<int64_t>> groups;
+    for (int64_t i = 0; i < n; ++i) {
+        const bool ok = widths[i] > 0 && heights[i] > 0;
+        if (status_out) status_out[i] = ok ? KE_IMG_OK : KE_IMG_BAD_SHAPE;
+        if (ok) groups[{widths[i], heights[i]}].push_back(i);
+    }
+    const bool in_dev = ke_is_device_ptr(pixels);
+    const bool p_dev = phash_out && ke_is_device_ptr(phash_out), d_dev = dhash_out && ke_is_device_ptr(dhash_out);
+    // outputs are produced in a device array of n slots, then copied out once
+    void *tmp;
+    uint64_t *d_ph = nullptr, *d_dh = nullptr;
+    if (phash_out) {
+        if (p_dev) d_ph = phash_out;
+        else { KE_TRY(ke_reserve(ctx, KE_BUF_OUT0, (size_t)n * 8, &tmp)); d_ph = (uint64_t *)tmp; }
+        KE_HIP(ctx, hipMemsetAsync(d_ph, 0, (size_t)n * 8, ctx->stream));
+    }
+    if (dhash_out) {
+        if (d_dev) d_dh = dhash_out;
+        else { KE_TRY(ke_reserve(ctx, KE_BUF_OUT1, (size_t)n * 8, &tmp)); d_dh = (uint64_t *)tmp; }
+        KE_HIP(ctx, hipMemsetAsync(d_dh, 0, (size_t)n * 8, ctx->stream));
+    }
+    ke_time_begin(ctx, KE_T_HASH);
+    for (auto &kv : groups) {
+        const int w = kv.first.first, h = kv.first.second;
+        const size_t img_bytes = (size_t)w * h * channels;
+        const std::vector<int64_t> &idx = kv.second;
+        const int64_t chunk = std::max<int64_t>(1, (int64_t)(kStageBytes / img_bytes));
+        for (size_t first = 0; first < idx.size(); first += (size_t)chunk) {
+            const int64_t m = (int64_t)std::min<size_t>((size_t)chunk, idx.size() - first);
+            std::vector<uint64_t> goff((size_t)m);
+            std::vector<int64_t> gidx(idx.begin() + first, idx.begin() + first + m);
+            const uint8_t *d_px = pixels;
+            if (in_dev) {
+                for (int64_t k = 0; k < m; ++k) goff[k] = off[gidx[k]];
+            } else {
+                // pack this chunk of host images into the staging buffer
+                KE_TRY(ke_reserve(ctx, KE_BUF_PIXELS, (size_t)m * img_bytes, &tmp));
+                for (int64_t k = 0; k < m; ++k) {
+                    goff[k] = (uint64_t)k * img_bytes;
+                    KE_HIP(ctx, hipMemcpyAsync((uint8_t *)tmp + goff[k], pixels + off[gidx[k]], img_bytes,
+                                               hipMemcpyHostToDevice, ctx->stream));
+                }
+                d_px = (const uint8_t *)tmp;
+            }
+            void *meta;
+            KE_TRY(ke_reserve(ctx, KE_BUF_META, (size_t)m * 16, &meta));
+            KE_HIP(ctx, hipMemcpyAsync(meta, goff.data(), (size_t)m * 8, hipMemcpyHostToDevice, ctx->stream));
+            KE_HIP(ctx, hipMemcpyAsync((uint8_t *)meta + (size_t)m * 8, gidx.data(), (size_t)m * 8,
+                                       hipMemcpyHostToDevice, ctx->stream));
+            KeHashGroup g{d_px, (const uint64_t *)meta, img_bytes, (const int64_t *)((uint8_t *)meta + (size_t)m * 8),
+                          m, w, h, channels};
+            KE_TRY(ke_launch_hash_group(ctx, g, d_ph, d_dh, nullptr, nullptr));
+            KE_HIP(ctx, hipStreamSynchronize(ctx->stream));  // goff/gidx and the staging buffers are reused
+        }
+    }
+    ke_time_end(ctx, KE_T_HASH);
+    if (phash_out && !p_dev)
+        KE_HIP(ctx, hipMemcpyAsync(phash_out, d_ph, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (dhash_out && !d_dev)
+        KE_HIP(ctx, hipMemcpyAsync(dhash_out, d_dh, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    KE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return KE_OK;
+}
+
+// ---- scan ------------------------------------------------------------------------------------
+KE_API int ke_hamming_scan(ke_ctx *ctx, const uint64_t *hashes, const int64_t *ids, const int64_t *sizes, int64_t n,
+                           int32_t part_index, int32_t part_count, int32_t threshold, int32_t band_bits,
+                           int32_t band_count, double size_ratio, int64_t bucket_pair_cap, ke_edge *edges_out,
+                           int64_t capacity, int64_t *n_edges_out, uint64_t *counters_out) {
+    if (!ctx) return KE_EINVAL;
+    if (n < 0 || (n > 0 && !hashes)) return ke_fail(ctx, KE_EINVAL, "hashes is NULL");
+    if (!n_edges_out) return ke_fail(ctx, KE_EINVAL, "n_edges_out is NULL");
+    // DuplicateScanConfig.__post_init__ / DuplicateScanner.__init__ (src/dup/scanner.py:155-166, 208)
+    if (band_bits <= 0) return ke_fail(ctx, KE_EINVAL, "band_bits must be positive");
+    if (band_count <= 0) return ke_fail(ctx, KE_EINVAL, "band_count must be positive");
+    if ((int64_t)band_bits * band_count > 64) return ke_fail(ctx, KE_EINVAL, "band config too large");
+    if (threshold < 0 || threshold > 64) return ke_fail(ctx, KE_EINVAL, "hamming_threshold must be in [0, 64]");
+    if (part_count <= 0 || part_index < 0 || part_index >= part_count)
+        return ke_fail(ctx, KE_EINVAL, "bad shard %d/%d", part_index, part_count);
+    if (capacity < 0 || (capacity > 0 && !edges_out)) return ke_fail(ctx, KE_EINVAL, "edges_out is NULL");
+    if (bucket_pair_cap > 0 && band_bits > 24)
+        return ke_fail(ctx, KE_EUNSUPPORTED, "bucket_pair_cap needs band_bits <= 24 (got %d)", band_bits);
+    *n_edges_out = 0;
+    if (counters_out) std::memset(counters_out, 0, 4 * sizeof(uint64_t));
+    if (n < 2) return KE_OK;
+    KE_HIP(ctx, hipSetDevice(ctx->device));
+    const void *d_h, *d_ids, *d_sizes;
+    // three inputs share one staging buffer when they come from the host
+    const bool any_host = !ke_is_device_ptr(hashes) || (ids && !ke_is_device_ptr(ids)) || (sizes && !ke_is_device_ptr(sizes));
+    if (any_host) {
+        void *base;
+        KE_TRY(ke_reserve(ctx, KE_BUF_SCAN_IN, (size_t)n * 24, &base));
+        auto stage = [&](const void *src, size_t slot, const void **dst) -> int {
+            if (!src) { *dst = nullptr; return KE_OK; }
+            if (ke_is_device_ptr(src)) { *dst = src; return KE_OK; }
+            void *d = (uint8_t *)base + slot * (size_t)n * 8;
+            KE_HIP(ctx, hipMemcpyAsync(d, src, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+            *dst = d;
+            return KE_OK;
+        };
+        KE_TRY(stage(hashes, 0, &d_h));
+        KE_TRY(stage(ids, 1, &d_ids));
+        KE_TRY(stage(sizes, 2, &d_sizes));
+    } else {
+        d_h = hashes; d_ids = ids; d_sizes = sizes;
+    }
+    const bool edges_dev = capacity > 0 && ke_is_device_ptr(edges_out);
+    ke_edge *d_edges = edges_out;
+    void *tmp;
+    if (capacity > 0 && !edges_dev) {
+        KE_TRY(ke_reserve(ctx, KE_BUF_SCAN_EDGES, (size_t)capacity * sizeof(ke_edge), &tmp));
+        d_edges = (ke_edge *)tmp;
+    }
+    KE_TRY(ke_reserve(ctx, KE_BUF_SCAN_CNT, 4 * sizeof(unsigned long long), &tmp));
+    unsigned long long *d_cnt = (unsigned long long *)tmp;
+    KE_HIP(ctx, hipMemsetAsync(d_cnt, 0, 4 * sizeof(unsigned long long), ctx->stream));
+    unsigned long long pairs = 0;
+    KE_TRY(ke_launch_scan(ctx, (const uint64_t *)d_h, (const int64_t *)d_ids, (const int64_t *)d_sizes, n, part_index,
+                          part_count, threshold, band_bits, band_count, size_ratio, bucket_pair_cap, d_edges, capacity,
+                          d_cnt, &pairs));
+    unsigned long long h_cnt[4];
+    KE_HIP(ctx, hipMemcpyAsync(h_cnt, d_cnt, sizeof h_cnt, hipMemcpyDeviceToHost, ctx->stream));
+    KE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *n_edges_out = (int64_t)h_cnt[2];
+    if (counters_out)
+    {
+        for (int k = 0; k < 4; ++k) counters_out[k] = h_cnt[k];
+        counters_out[0] = pairs;
+    }
+    if (capacity > 0 && !edges_dev) {
+        const int64_t m = std::min<int64_t>(capacity, (int64_t)h_cnt[2]);
+        if (m > 0) {
+            KE_HIP(ctx, hipMemcpyAsync(edges_out, d_edges, (size_t)m * sizeof(ke_edge), hipMemcpyDeviceToHost, ctx->stream));
+            KE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        }
+    }
+    return KE_OK;
+}
+
+// ---- ssim ------------------------------------------------------------------------------------
+KE_API int ke_ssim_pairs_uniform(ke_ctx *ctx, const uint8_t *images, int64_t n_images, int32_t width, int32_t height,
+                                 int32_t channels, const int64_t *pair_a, const int64_t *pair_b, int64_t n_pairs,
+                                 double *ssim_out) {
+    if (!ctx) return KE_EINVAL;
+    if (n_pairs < 0 || n_images < 0) return ke_fail(ctx, KE_EINVAL, "negative count");
+    if (n_pairs == 0) return KE_OK;
+    if (!images || !pair_a || !pair_b || !ssim_out) return ke_fail(ctx, KE_EINVAL, "NULL argument");
+    if (width <= 0 || height <= 0) return ke_fail(ctx, KE_EINVAL, "width/height must be positive");
+    if (channels != 1 && channels != 3 && channels != 4) return ke_fail(ctx, KE_EINVAL, "channels must be 1, 3 or 4");
+    KE_HIP(ctx, hipSetDevice(ctx->device));
+    if (!ke_is_device_ptr(pair_a) && !ke_is_device_ptr(pair_b)) {
+        for (int64_t k = 0; k < n_pairs; ++k)
+            if (pair_a[k] < 0 || pair_a[k] >= n_images || pair_b[k] < 0 || pair_b[k] >= n_images)
+                return ke_fail(ctx, KE_EINVAL, "pair %lld indexes outside [0,%lld)", (long long)k, (long long)n_images);
+    }
+    const void *d_img, *d_pa, *d_pb;
+    KE_TRY(ke_to_device(ctx, images, (size_t)n_images * width * height * channels, KE_BUF_SSIM_IN, &d_img));
+    void *aux;
+    KE_TRY(ke_reserve(ctx, KE_BUF_SSIM_AUX, (size_t)n_pairs * 24, &aux));
+    auto stage = [&](const int64_t *src, int slot, const void **dst) -> int {
+        if (ke_is_device_ptr(src)) { *dst = src; return KE_OK; }
+        void *d = (uint8_t *)aux + (size_t)slot * n_pairs * 8;
+        KE_HIP(ctx, hipMemcpyAsync(d, src, (size_t)n_pairs * 8, hipMemcpyHostToDevice, ctx->stream));
+        *dst = d;
+        return KE_OK;
+    };
+    KE_TRY(stage(pair_a, 0, &d_pa));
+    KE_TRY(stage(pair_b, 1, &d_pb));
+    const bool out_dev = ke_is_device_ptr(ssim_out);
+    double *d_out = out_dev ? ssim_out : (double *)((uint8_t *)aux + (size_t)2 * n_pairs * 8);
+    ke_time_begin(ctx, KE_T_SSIM);
+    KE_TRY(ke_launch_ssim(ctx, (const uint8_t *)d_img, width, height, channels, (const int64_t *)d_pa,
+                          (const int64_t *)d_pb, n_pairs, d_out));
+    ke_time_end(ctx, KE_T_SSIM);
+    if (!out_dev) {
+        KE_HIP(ctx, hipMemcpyAsync(ssim_out, d_out, (size_t)n_pairs * 8, hipMemcpyDeviceToHost, ctx->stream));
+        KE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return KE_OK;
+}
+
+// ---- synthetic corpus --------------------------------------------------------------------------
+KE_API int ke_synth_rgb(ke_ctx *ctx, uint64_t seed, int64_t first_index, int64_t n, int32_t width, int32_t height,
+                        uint8_t *rgb_out) {
+    if (!ctx) return KE_EINVAL;
+    if (n < 0 || width <= 0 || height <= 0 || first_index < 0 || (n > 0 && !rgb_out))
+        return ke_fail(ctx, KE_EINVAL, "bad synth arguments");
+    if (n == 0) return KE_OK;
+    KE_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t img_bytes = (size_t)width * height * 3;
+    if (ke_is_device_ptr(rgb_out)) {
+        ke_time_begin(ctx, KE_T_SYNTH);
+        KE_TRY(ke_launch_synth_rgb(ctx, seed, first_index, n, width, height, rgb_out));
+        ke_time_end(ctx, KE_T_SYNTH);
+        return KE_OK;
+    }
+    const int64_t chunk = std::max<int64_t>(1, (int64_t)(kStageBytes / img_bytes));
+    for (int64_t f = 0; f < n; f += chunk) {
+        const int64_t m = std::min(chunk, n - f);
+        void *d;
+        KE_TRY(ke_reserve(ctx, KE_BUF_PIXELS, (size_t)m * img_bytes, &d));
+        KE_TRY(ke_launch_synth_rgb(ctx, seed, first_index + f, m, width, height, (uint8_t *)d));
+        KE_HIP(ctx, hipMemcpyAsync(rgb_out + (size_t)f * img_bytes, d, (size_t)m * img_bytes, hipMemcpyDeviceToHost, ctx->stream));
+        KE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return KE_OK;
+}
+
+KE_API int ke_synth_hashes(ke_ctx *ctx, uint64_t seed, int64_t n, uint64_t *hashes_out) {
+    if (!ctx) return KE_EINVAL;
+    if (n < 0 || (n > 0 && !hashes_out)) return ke_fail(ctx, KE_EINVAL, "bad synth arguments");
+    if (n == 0) return KE_OK;
+    KE_HIP(ctx, hipSetDevice(ctx->device));
+    if (ke_is_device_ptr(hashes_out)) return ke_launch_synth_hashes(ctx, seed, n, hashes_out);
+    void *d;
+    KE_TRY(ke_reserve(ctx, KE_BUF_SCAN_IN, (size_t)n * 8, &d));
+    KE_TRY(ke_launch_synth_hashes(ctx, seed, n, (uint64_t *)d));
+    KE_HIP(ctx, hipMemcpyAsync(hashes_out, d, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    KE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return KE_OK;
+}

@@ -1,0 +1,109 @@
+// ke_coeffs.cpp -- host-side LANCZOS(a=3) tap tables for the resampler kernels.
+//
+// Replaces the coefficient set-up that Pillow performs inside
+// image.convert("L").resize(size, LANCZOS) (reference call site: src/sig/phash.py:24-25):
+// per output sample a window [first, first+count) of the input axis, weights
+// sinc(t)*sinc(t/3) evaluated at tap centres, normalised to sum 1 in double precision and
+// quantised to 22-bit fixed point with round-half-away-from-zero.  An unchanged axis gets
+// identity taps (one tap of weight 2^22), which reproduces Pillow's "skip this pass" exactly.
+#include <cmath>
+
+#include "ke_internal.h"
+
+namespace {
+
+constexpr int kPrecisionBits = 22;
+constexpr double kPi = 3.14159265358979323846;
+
+inline double sinc_pi(double x) {
+    if (x == 0.0) return 1.0;
+    const double a = x * kPi;
+    return std::sin(a) / a;
+}
+
+inline double lanczos3(double x) {
+    return (x >= -3.0 && x < 3.0) ? sinc_pi(x) * sinc_pi(x / 3.0) : 0.0;
+}
+
+}  // namespace
+
+void ke_build_axis_coeffs(int in_size, int out_size, KeAxisCoeffs &c) {
+    c.in_size = in_size;
+    c.out_size = out_size;
+    c.bounds.assign(2 * (size_t)out_size, 0);
+    if (in_size == out_size) {
+        c.ksize = 1;
+        c.kk.assign((size_t)out_size, 1 << kPrecisionBits);
+        for (int o = 0; o < out_size; ++o) {
+            c.bounds[2 * o] = o;
+            c.bounds[2 * o + 1] = 1;
+        }
+    } else {
+        const double scale = (double)in_size / (double)out_size;
+        const double fscale = scale < 1.0 ? 1.0 : scale;
+        const double support = 3.0 * fscale;
+        const double inv = 1.0 / fscale;
+        c.ksize = (int)std::ceil(support) * 2 + 1;
+        c.kk.assign((size_t)out_size * c.ksize, 0);
+        std::vector<double> w((size_t)c.ksize);
+        for (int o = 0; o < out_size; ++o) {
+            const double center = (o + 0.5) * scale;
+            int lo = (int)(center - support + 0.5);
+            if (lo < 0) lo = 0;
+            int hi = (int)(center + support + 0.5);
+            if (hi > in_size) hi = in_size;
+            const int cnt = hi - lo;
+            double total = 0.0;
+            for (int t = 0; t < cnt; ++t) {
+                w[t] = lanczos3((t + lo - center + 0.5) * inv);
+                total += w[t];
+            }
+            int32_t *k = &c.kk[(size_t)o * c.ksize];
+            for (int t = 0; t < cnt; ++t) {
+                const double v = total != 0.0 ? w[t] / total : w[t];
+                k[t] = v < 0 ? (int32_t)(v * (double)(1 << kPrecisionBits) - 0.5)
+                             : (int32_t)(v * (double)(1 << kPrecisionBits) + 0.5);
+            }
+            c.bounds[2 * o] = lo;
+            c.bounds[2 * o + 1] = cnt;
+        }
+    }
+
+    // ---- packed byte-plane layout for the fused kernel -----------------------------------
+    int ndw = 0;
+    c.start.assign((size_t)out_size, 0);
+    for (int o = 0; o < out_size; ++o) {
+        const int lo = c.bounds[2 * o], cnt = c.bounds[2 * o + 1];
+        const int st = lo & ~7;
+        c.start[o] = st;
+        const int need = (lo + cnt - st + 3) / 4;
+        if (need > ndw) ndw = need;
+    }
+    ndw = (ndw + 3) & ~3;
+    c.ndw = ndw;
+    c.span = 0;
+    c.bias.assign((size_t)out_size, 0);
+    c.packed.assign((size_t)out_size * ndw * 3, 0);
+    for (int o = 0; o < out_size; ++o) {
+        const int lo = c.bounds[2 * o], cnt = c.bounds[2 * o + 1], st = c.start[o];
+        if (st + 4 * ndw > c.span) c.span = st + 4 * ndw;
+        int64_t ksum = 0;
+        for (int j = 0; j < ndw; ++j) {
+            uint32_t plane[3] = {0, 0, 0};
+            for (int e = 0; e < 4; ++e) {
+                const int t = st + 4 * j + e - lo;
+                const int32_t k = (t >= 0 && t < cnt) ? c.kk[(size_t)o * c.ksize + t] : 0;
+                ksum += k;
+                const int32_t b0 = ((k + 128) & 255) - 128;
+                const int32_t r1 = (k - b0) >> 8;
+                const int32_t b1 = ((r1 + 128) & 255) - 128;
+                const int32_t b2 = (r1 - b1) >> 8;  // |k| <= 2^22 keeps this inside int8
+                plane[0] |= (uint32_t)(b0 & 255) << (8 * e);
+                plane[1] |= (uint32_t)(b1 & 255) << (8 * e);
+                plane[2] |= (uint32_t)(b2 & 255) << (8 * e);
+            }
+            for (int p = 0; p < 3; ++p) c.packed[((size_t)o * ndw + j) * 3 + p] = (int32_t)plane[p];
+        }
+        c.bias[o] = (int32_t)(128 * ksum + (1 << (kPrecisionBits - 1)));
+    }
+}

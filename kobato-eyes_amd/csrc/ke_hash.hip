@@ -1,0 +1,456 @@
+// ke_hash.hip -- pHash / dHash kernels for gfx950.
+//
+// Replaces, per image: sig.phash._to_grayscale (Pillow convert("L") + LANCZOS resize,
+// src/sig/phash.py:21-26), phash (cv2.dct + mean threshold, :33-46) and dhash (:49-57).
+//
+//   K1  luma + horizontal LANCZOS  -- integer, bit-exact with Pillow
+//   K1' vertical LANCZOS            -- integer, bit-exact with Pillow
+//   K2  8x8 corner of the 32x32 DCT in fp64 (folded, fixed fma order), float32 mean in
+//       NumPy's pairwise order, 64 compare bits MSB first
+//   K3  dHash from the 9x8 tile
+//
+// Two paths, same arithmetic:
+//   * ke_phash_fused<W64,NDWH>: one workgroup per image, the whole chain in one launch; the
+//     image is streamed once from HBM (12 B/lane coalesced loads), luma goes to LDS as
+//     signed bytes, both resample passes run on v_dot4_i32_i8 with the 22-bit tap weights
+//     split into three signed byte planes.  HBM-bound by design: 3*W*H bytes in, 8 out.
+//   * generic passes (ke_resample_pass) for every other shape, channel count and for dHash.
+#include "ke_internal.h"
+#include "dct_table.h"
+
+namespace {
+
+constexpr int kPrecisionBits = 22;
+
+__device__ __forceinline__ int clip8_fixed(int acc) {
+    int v = acc >> kPrecisionBits;
+    return v < 0 ? 0 : (v > 255 ? 255 : v);
+}
+
+__device__ __forceinline__ int luma_of(const uint8_t *p, int ch) {
+    if (ch == 1) return p[0];
+    return (int)((19595u * p[0] + 38470u * p[1] + 7471u * p[2] + 0x8000u) >> 16);
+}
+
+// ---------------------------------------------------------------------------------------
+// Generic single-axis resample pass.  AXIS 0: dst[y][o] over x taps (dst is h x out_size);
+// AXIS 1: dst[o][x] over y taps (dst is out_size x w).  Source may be interleaved (ch 3/4:
+// luma taken on the fly) or single channel.
+// ---------------------------------------------------------------------------------------
+template <int AXIS>
+__global__ __launch_bounds__(256) void ke_resample_pass(const uint8_t *__restrict__ src,
+                                                         const uint64_t *__restrict__ offsets, uint64_t stride,
+                                                         int ch, int w, int h, const int32_t *__restrict__ bounds,
+                                                         const int32_t *__restrict__ kk, int ksize, int out_size,
+                                                         uint8_t *__restrict__ dst, int blocks_per_image) {
+    const int64_t img = blockIdx.x / blocks_per_image;
+    const int blk = blockIdx.x % blocks_per_image;
+    const int ow = AXIS == 0 ? out_size : w;
+    const int oh = AXIS == 0 ? h : out_size;
+    const int e = blk * 256 + threadIdx.x;
+    if (e >= ow * oh) return;
+    const int oy = e / ow, ox = e % ow;
+    const uint8_t *base = src + (offsets ? offsets[img] : (uint64_t)img * stride);
+    const int o = AXIS == 0 ? ox : oy;
+    const int first = bounds[2 * o], cnt = bounds[2 * o + 1];
+    const int32_t *k = kk + (size_t)o * ksize;
+    int acc = 1 << (kPrecisionBits - 1);
+    if (AXIS == 0) {
+        const uint8_t *row = base + ((size_t)oy * w + first) * ch;
+        for (int t = 0; t < cnt; ++t) acc += luma_of(row + (size_t)t * ch, ch) * k[t];
+    } else {
+        const uint8_t *col = base + ((size_t)first * w + ox) * ch;
+        for (int t = 0; t < cnt; ++t) acc += luma_of(col + (size_t)t * w * ch, ch) * k[t];
+    }
+    dst[(size_t)img * ow * oh + e] = (uint8_t)clip8_fixed(acc);
+}
+
+// ---------------------------------------------------------------------------------------
+// K2: folded DCT.  One output of the length-32 orthonormal DCT-II (unnormalised), k in 0..7.
+//   even k recurse on the folded sums, odd k are a short cosine dot product on the folded
+//   differences; every sum is a single add, every dot product an fma chain in ascending n,
+//   so flat and mirror-symmetric inputs give exact zeros.
+// ---------------------------------------------------------------------------------------
+__constant__ double c_C32[4][16];
+__constant__ double c_C16[2][8];
+__constant__ double c_C8[4];
+
+__device__ double dct32_one(const double *x, int k) {
+    if (k & 1) {
+        const int q = k >> 1;
+        double acc = 0.0;
+#pragma unroll
+        for (int n = 0; n < 16; ++n) acc = fma(x[n] - x[31 - n], c_C32[q][n], acc);
+        return acc;
+    }
+    double u[16];
+#pragma unroll
+    for (int n = 0; n < 16; ++n) u[n] = x[n] + x[31 - n];
+    if (k & 2) {
+        const int q = k >> 2;  // k = 2 -> 0, k = 6 -> 1
+        double acc = 0.0;
+#pragma unroll
+        for (int n = 0; n < 8; ++n) acc = fma(u[n] - u[15 - n], c_C16[q][n], acc);
+        return acc;
+    }
+    double v[8];
+#pragma unroll
+    for (int n = 0; n < 8; ++n) v[n] = u[n] + u[15 - n];
+    if (k == 4) {
+        double acc = 0.0;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc = fma(v[n] - v[7 - n], c_C8[n], acc);
+        return acc;
+    }
+    const double w0 = v[0] + v[7], w1 = v[1] + v[6], w2 = v[2] + v[5], w3 = v[3] + v[4];
+    return (w0 + w1) + (w2 + w3);
+}
+
+// tile: 32x32 u8 in LDS; Td: 256 doubles in LDS; cf: 64 floats in LDS.  All 256 threads of
+// the workgroup call this; the hash is returned in thread 0 (undefined elsewhere).
+__device__ uint64_t tile32_to_phash(const uint8_t *tile, double *Td, float *cf, int tid) {
+    {
+        const int y = tid >> 3, kx = tid & 7;
+        double x[32];
+#pragma unroll
+        for (int n = 0; n < 32; ++n) x[n] = (double)tile[y * 32 + n];
+        Td[y * 8 + kx] = dct32_one(x, kx);
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const int ky = tid >> 3, kx = tid & 7;
+        double x[32];
+#pragma unroll
+        for (int n = 0; n < 32; ++n) x[n] = Td[n * 8 + kx];
+        const double s = (ky == 0 && kx == 0) ? KE_SCALE00 : ((ky == 0 || kx == 0) ? KE_SCALE0K : KE_SCALEKK);
+        cf[tid] = (float)(dct32_one(x, ky) * s);  // cv2.dct hands back float32
+    }
+    __syncthreads();
+    uint64_t hash = 0;
+    if (tid < 64) {
+        // flat[1:].mean() in float32, NumPy pairwise order for 63 items (src/sig/phash.py:41):
+        // eight running lanes over the first 56, balanced combine, then the 7-item tail.
+        const float *a = cf + 1;
+        float r[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = a[j];
+#pragma unroll
+        for (int i = 8; i < 56; i += 8)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r[j] = r[j] + a[i + j];
+        float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+#pragma unroll
+        for (int i = 56; i < 63; ++i) res = res + a[i];
+        const float mean = res / 63.0f;
+        const unsigned long long m = __ballot(cf[tid] > mean);  // lane i <-> flat[i]
+        hash = __brevll(m);                                     // flat[0] is the MSB (:43-45)
+    }
+    return hash;
+}
+
+__global__ __launch_bounds__(256) void ke_tiles_to_hashes(const uint8_t *__restrict__ tile32,
+                                                           const uint8_t *__restrict__ tile98,
+                                                           const int64_t *__restrict__ out_idx,
+                                                           uint64_t *__restrict__ phash, uint64_t *__restrict__ dhash) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_tile[1024];
+    __shared__ double s_T[256];
+    __shared__ float s_cf[64];
+    const int tid = threadIdx.x;
+    const int64_t img = blockIdx.x;
+    const int64_t slot = out_idx ? out_idx[img] : img;
+    if (phash) {
+        reinterpret_cast<uint32_t *>(s_tile)[tid] = reinterpret_cast<const uint32_t *>(tile32 + (size_t)img * 1024)[tid];
+        __syncthreads();
+        const uint64_t hv = tile32_to_phash(s_tile, s_T, s_cf, tid);
+        if (tid == 0) phash[slot] = hv;
+    }
+    if (dhash && tid < 64) {
+        // src/sig/phash.py:49-57: 8 rows x 9 columns, bit = right > left, row-major, MSB first
+        const uint8_t *t = tile98 + (size_t)img * 72;
+        const int r = tid >> 3, c = tid & 7;
+        const unsigned long long m = __ballot(t[r * 9 + c + 1] > t[r * 9 + c]);
+        if (tid == 0) dhash[slot] = __brevll(m);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Fused pHash kernel.  Template: W = 64*W64 pixels per row (RGB, 3 bytes/pixel), NDWH =
+// window dwords of the horizontal taps (multiple of 4).  One workgroup (256 threads) per
+// image; rows are streamed in tiles of RT = 16.
+// ---------------------------------------------------------------------------------------
+constexpr int kRT = 16;
+
+__device__ __forceinline__ uint32_t luma4_biased(uint32_t d0, uint32_t d1, uint32_t d2) {
+    // 19595 = 76*256+139, 38470 = 150*256+70, 7471 = 29*256+47: two u8 dot products per pixel.
+    // The accumulator start folds in the +0x8000 rounding and the -128 bias of the signed
+    // luma byte, which ends up in bits 16..23.
+    constexpr uint32_t CHI = 0x001D964Cu, CLO = 0x002F468Bu, START = 0x8000u - 0x800000u;
+    const uint32_t p0 = d0;
+    const uint32_t p1 = __builtin_amdgcn_alignbyte(d1, d0, 3);
+    const uint32_t p2 = __builtin_amdgcn_alignbyte(d2, d1, 2);
+    const uint32_t p3 = d2 >> 8;
+    const uint32_t s0 = (__builtin_amdgcn_udot4(p0, CHI, 0u, false) << 8) + __builtin_amdgcn_udot4(p0, CLO, START, false);
+    const uint32_t s1 = (__builtin_amdgcn_udot4(p1, CHI, 0u, false) << 8) + __builtin_amdgcn_udot4(p1, CLO, START, false);
+    const uint32_t s2 = (__builtin_amdgcn_udot4(p2, CHI, 0u, false) << 8) + __builtin_amdgcn_udot4(p2, CLO, START, false);
+    const uint32_t s3 = (__builtin_amdgcn_udot4(p3, CHI, 0u, false) << 8) + __builtin_amdgcn_udot4(p3, CLO, START, false);
+    return ((s0 >> 16) & 0xFFu) | ((s1 >> 8) & 0xFF00u) | (s2 & 0xFF0000u) | ((s3 << 8) & 0xFF000000u);
+}
+
+__device__ __forceinline__ int combine_planes(int d0, int d1, int d2, int bias) {
+    return (int)((uint32_t)d0 + ((uint32_t)d1 << 8) + ((uint32_t)d2 << 16) + (uint32_t)bias);
+}
+
+struct KeFusedArgs {
+    const uint8_t *pixels;
+    const uint64_t *offsets;
+    uint64_t stride;
+    const int64_t *out_idx;
+    int h;
+    const int32_t *h_packed, *h_start, *h_bias;          // 32 outputs, NDWH dwords
+    const int32_t *v_packed, *v_start, *v_bias;          // 32 outputs, ndwv dwords
+    int ndwv;
+    int lt_bytes;   // LDS bytes of the luma tile region (>= 3584)
+    int hp;         // pitch of one HT column (bytes, multiple of 8)
+    uint64_t *phash;
+    uint8_t *tile32_out;  // nullable debug output
+};
+
+template <int W64, int NDWH>
+__global__ __launch_bounds__(256, 3) void ke_phash_fused(const KeFusedArgs a) {
+    constexpr int W = 64 * W64;
+    constexpr int QPT = W64;                 // 12-byte quads per thread per 16-row tile
+    constexpr int QUADS_PER_TILE = kRT * W / 4;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t *Lt = smem;
+    uint8_t *HT = smem + a.lt_bytes;
+    const int tid = threadIdx.x;
+    const int64_t img = blockIdx.x;
+    const uint8_t *src = a.pixels + (a.offsets ? a.offsets[img] : (uint64_t)img * a.stride);
+    const int h = a.h;
+    const int total_quads = h * (W / 4);
+
+    // horizontal tap planes of this thread's output column -> registers
+    const int o = tid & 31, rg = tid >> 5;
+    const int rot = (o >> 4) & 1;  // lanes o and o+16 would hit the same LDS banks: swap dword pairs
+    int ck[NDWH][3];
+#pragma unroll
+    for (int p = 0; p < NDWH / 2; ++p) {
+        const int pp = p ^ rot;
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) ck[2 * p + e][c] = a.h_packed[((size_t)o * NDWH + 2 * pp + e) * 3 + c];
+    }
+    const int hst = a.h_start[o];
+    const int hbias = a.h_bias[o];
+
+    uint32_t raw[QPT][3];
+    auto load_tile = [&](int t) {
+#pragma unroll
+        for (int q = 0; q < QPT; ++q) {
+            const int gq = t * QUADS_PER_TILE + q * 256 + tid;
+            if (gq < total_quads) {
+                const uint32_t *p = reinterpret_cast<const uint32_t *>(src + (size_t)gq * 12);
+                raw[q][0] = p[0];
+                raw[q][1] = p[1];
+                raw[q][2] = p[2];
+            } else {
+                raw[q][0] = raw[q][1] = raw[q][2] = 0;
+            }
+        }
+    };
+
+    const int ntiles = (h + kRT - 1) / kRT;
+    load_tile(0);
+    for (int t = 0; t < ntiles; ++t) {
+        // ---- K1a: luma of the tile already in registers -> signed bytes in LDS
+#pragma unroll
+        for (int q = 0; q < QPT; ++q)
+            reinterpret_cast<uint32_t *>(Lt)[q * 256 + tid] = luma4_biased(raw[q][0], raw[q][1], raw[q][2]);
+        if (t + 1 < ntiles) load_tile(t + 1);  // next tile's HBM reads fly during the dot products
+        __syncthreads();
+        // ---- K1b: horizontal taps: thread = (output column o, rows 2rg, 2rg+1)
+        uint32_t packed2 = 0;
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const uint8_t *lrow = Lt + (2 * rg + rr) * W + hst;
+            int d0 = 0, d1 = 0, d2 = 0;
+#pragma unroll
+            for (int p = 0; p < NDWH / 2; ++p) {
+                const int pp = p ^ rot;
+                const uint2 v = *reinterpret_cast<const uint2 *>(__builtin_assume_aligned(lrow + 8 * pp, 8));
+                d0 = __builtin_amdgcn_sdot4((int)v.x, ck[2 * p][0], d0, false);
+                d1 = __builtin_amdgcn_sdot4((int)v.x, ck[2 * p][1], d1, false);
+                d2 = __builtin_amdgcn_sdot4((int)v.x, ck[2 * p][2], d2, false);
+                d0 = __builtin_amdgcn_sdot4((int)v.y, ck[2 * p + 1][0], d0, false);
+                d1 = __builtin_amdgcn_sdot4((int)v.y, ck[2 * p + 1][1], d1, false);
+                d2 = __builtin_amdgcn_sdot4((int)v.y, ck[2 * p + 1][2], d2, false);
+            }
+            const int r = clip8_fixed(combine_planes(d0, d1, d2, hbias));
+            packed2 |= (uint32_t)(r ^ 0x80) << (8 * rr);  // signed byte again for the vertical dot products
+        }
+        *reinterpret_cast<uint16_t *>(HT + (size_t)o * a.hp + t * kRT + 2 * rg) = (uint16_t)packed2;
+        __syncthreads();
+    }
+
+    // ---- K1': vertical taps: thread = (output row yy, columns og + 8m)
+    uint8_t *T32 = Lt;
+    double *Td = reinterpret_cast<double *>(Lt + 1024);
+    float *cf = reinterpret_cast<float *>(Lt + 1024 + 2048);
+    {
+        const int yy = tid & 31, og = tid >> 5;
+        const int rotv = (yy >> 4) & 1;
+        const int vst = a.v_start[yy];
+        const int ndwv = a.ndwv;
+        int acc[4][3];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[m][0] = acc[m][1] = acc[m][2] = 0;
+        for (int j = 0; j < ndwv; j += 2) {
+            const int jj = j ^ (2 * rotv);
+            const int32_t *cp = a.v_packed + ((size_t)yy * ndwv + jj) * 3;
+            const int c00 = cp[0], c01 = cp[1], c02 = cp[2], c10 = cp[3], c11 = cp[4], c12 = cp[5];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const uint2 v = *reinterpret_cast<const uint2 *>(
+                    __builtin_assume_aligned(HT + (size_t)(og + 8 * m) * a.hp + vst + 4 * jj, 8));
+                acc[m][0] = __builtin_amdgcn_sdot4((int)v.x, c00, acc[m][0], false);
+                acc[m][1] = __builtin_amdgcn_sdot4((int)v.x, c01, acc[m][1], false);
+                acc[m][2] = __builtin_amdgcn_sdot4((int)v.x, c02, acc[m][2], false);
+                acc[m][0] = __builtin_amdgcn_sdot4((int)v.y, c10, acc[m][0], false);
+                acc[m][1] = __builtin_amdgcn_sdot4((int)v.y, c11, acc[m][1], false);
+                acc[m][2] = __builtin_amdgcn_sdot4((int)v.y, c12, acc[m][2], false);
+            }
+        }
+        const int vbias = a.v_bias[yy];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+            T32[yy * 32 + og + 8 * m] = (uint8_t)clip8_fixed(combine_planes(acc[m][0], acc[m][1], acc[m][2], vbias));
+    }
+    __syncthreads();
+    if (a.tile32_out)
+        reinterpret_cast<uint32_t *>(a.tile32_out + (size_t)img * 1024)[tid] = reinterpret_cast<const uint32_t *>(T32)[tid];
+    // ---- K2: DCT corner, mean, bits
+    const uint64_t hv = tile32_to_phash(T32, Td, cf, tid);
+    if (tid == 0 && a.phash) a.phash[a.out_idx ? a.out_idx[img] : img] = hv;
+}
+
+bool g_tables_ready = false;
+
+int upload_dct_tables(ke_ctx *ctx) {
+    if (g_tables_ready) return KE_OK;
+    KE_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(c_C32), KE_C32, sizeof(KE_C32)));
+    KE_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(c_C16), KE_C16, sizeof(KE_C16)));
+    KE_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(c_C8), KE_C8, sizeof(KE_C8)));
+    g_tables_ready = true;
+    return KE_OK;
+}
+
+template <int W64, int NDWH>
+int launch_fused(ke_ctx *ctx, const KeHashGroup &g, const KeAxisCoeffs *ch, const KeAxisCoeffs *cv, uint64_t *d_phash,
+                 uint8_t *d_tile32) {
+    constexpr int W = 64 * W64;
+    KeFusedArgs a;
+    a.pixels = g.pixels; a.offsets = g.offsets; a.stride = g.stride; a.out_idx = g.out_idx; a.h = g.h;
+    a.h_packed = ch->d_packed; a.h_start = ch->d_start; a.h_bias = ch->d_bias;
+    a.v_packed = cv->d_packed; a.v_start = cv->d_start; a.v_bias = cv->d_bias;
+    a.ndwv = cv->ndw;
+    int lt = kRT * W + std::max(0, ch->span - W) + 16;
+    if (lt < 3584) lt = 3584;
+    a.lt_bytes = (lt + 15) & ~15;
+    const int rows_padded = ((g.h + kRT - 1) / kRT) * kRT;
+    a.hp = ((std::max(cv->span, rows_padded) + 7) & ~7) + 8;
+    a.phash = d_phash; a.tile32_out = d_tile32;
+    const size_t lds = (size_t)a.lt_bytes + (size_t)32 * a.hp;
+    if (lds > 64 * 1024) return KE_EUNSUPPORTED;
+    hipLaunchKernelGGL((ke_phash_fused<W64, NDWH>), dim3((unsigned)g.n), dim3(256), lds, ctx->stream, a);
+    KE_HIP(ctx, hipGetLastError());
+    return KE_OK;
+}
+
+// Generic target: src images -> (oh x ow) u8 tiles, two single-axis passes in Pillow's order.
+int resample_generic(ke_ctx *ctx, const KeHashGroup &g, int ow, int oh, uint8_t *d_tiles) {
+    const KeAxisCoeffs *chz = ke_get_coeffs(ctx, g.w, ow);
+    const KeAxisCoeffs *cvt = ke_get_coeffs(ctx, g.h, oh);
+    if (!chz || !cvt) return ke_fail(ctx, KE_EHIP, "coefficient upload failed");
+    // Pillow's Image.resize shrinks very tall, narrow images vertically first (PIL/Image.py).
+    const bool vertical_first = (int64_t)g.h > (int64_t)g.w * 100 && oh < g.h;
+    const int mid_w = vertical_first ? g.w : ow, mid_h = vertical_first ? oh : g.h;
+    const size_t mid_bytes = (size_t)mid_w * mid_h;
+    void *tmp;
+    KE_TRY(ke_reserve(ctx, KE_BUF_TMP, (size_t)g.n * mid_bytes, &tmp));
+    const int b0 = (int)((mid_bytes + 255) / 256), b1 = (ow * oh + 255) / 256;
+    if ((int64_t)g.n * b0 > 0x7fffffffLL) return ke_fail(ctx, KE_EUNSUPPORTED, "group too large for one launch");
+    if (!vertical_first) {
+        hipLaunchKernelGGL(ke_resample_pass<0>, dim3((unsigned)(g.n * b0)), dim3(256), 0, ctx->stream, g.pixels, g.offsets,
+                           g.stride, g.channels, g.w, g.h, chz->d_bounds, chz->d_kk, chz->ksize, ow, (uint8_t *)tmp, b0);
+        hipLaunchKernelGGL(ke_resample_pass<1>, dim3((unsigned)(g.n * b1)), dim3(256), 0, ctx->stream, (const uint8_t *)tmp,
+                           (const uint64_t *)nullptr, (uint64_t)mid_bytes, 1, mid_w, mid_h, cvt->d_bounds, cvt->d_kk,
+                           cvt->ksize, oh, d_tiles, b1);
+    } else {
+        hipLaunchKernelGGL(ke_resample_pass<1>, dim3((unsigned)(g.n * b0)), dim3(256), 0, ctx->stream, g.pixels, g.offsets,
+                           g.stride, g.channels, g.w, g.h, cvt->d_bounds, cvt->d_kk, cvt->ksize, oh, (uint8_t *)tmp, b0);
+        hipLaunchKernelGGL(ke_resample_pass<0>, dim3((unsigned)(g.n * b1)), dim3(256), 0, ctx->stream, (const uint8_t *)tmp,
+                           (const uint64_t *)nullptr, (uint64_t)mid_bytes, 1, mid_w, mid_h, chz->d_bounds, chz->d_kk,
+                           chz->ksize, ow, d_tiles, b1);
+    }
+    KE_HIP(ctx, hipGetLastError());
+    return KE_OK;
+}
+
+}  // namespace
+
+int ke_launch_hash_group(ke_ctx *ctx, const KeHashGroup &g, uint64_t *d_phash, uint64_t *d_dhash, uint8_t *d_tile32_out,
+                         uint8_t *d_tile98_out) {
+    KE_TRY(upload_dct_tables(ctx));
+    const bool want_p = d_phash || d_tile32_out, want_d = d_dhash || d_tile98_out;
+    bool p_done = false;
+    // ---- fused fast path: packed RGB, 4-byte aligned rows, width 256/384/512, both axes resampled
+    if (want_p && g.channels == 3 && g.w % 64 == 0 && g.h != 32 && g.h >= 16 && g.h <= 1536 &&
+        !((int64_t)g.h > (int64_t)g.w * 100) && ((uintptr_t)g.pixels % 4 == 0) && (g.offsets || g.stride % 4 == 0)) {
+        const KeAxisCoeffs *ch = ke_get_coeffs(ctx, g.w, 32);
+        const KeAxisCoeffs *cv = ke_get_coeffs(ctx, g.h, 32);
+        if (!ch || !cv) return ke_fail(ctx, KE_EHIP, "coefficient upload failed");
+        int rc = KE_EUNSUPPORTED;
+        // offsets (ragged groups) are only 4-byte aligned when every image size is; w % 64 == 0 makes it so
+        if (g.w == 256 && ch->ndw == 16) rc = launch_fused<4, 16>(ctx, g, ch, cv, d_phash, d_tile32_out);
+        else if (g.w == 384 && ch->ndw == 20) rc = launch_fused<6, 20>(ctx, g, ch, cv, d_phash, d_tile32_out);
+        else if (g.w == 512 && ch->ndw == 24) rc = launch_fused<8, 24>(ctx, g, ch, cv, d_phash, d_tile32_out);
+        if (rc == KE_OK) p_done = true;
+        else if (rc != KE_EUNSUPPORTED) return rc;
+    }
+    // ---- generic path, chunked so the first-pass scratch stays bounded
+    if ((want_p && !p_done) || want_d) {
+        const size_t per_img = (size_t)std::max(g.w, 32) * std::max(g.h, 32);
+        const int64_t chunk = std::max<int64_t>(1, (int64_t)(((size_t)512 << 20) / per_img));
+        for (int64_t f = 0; f < g.n; f += chunk) {
+            KeHashGroup s = g;
+            s.n = std::min(chunk, g.n - f);
+            uint64_t sub_off = 0;
+            if (g.offsets) s.offsets = g.offsets + f; else sub_off = (uint64_t)f * g.stride;
+            if (!g.offsets) s.pixels = g.pixels + sub_off;
+            // out_idx == NULL means "slot = position in this group": keep that true for the sub-chunk
+            // by offsetting the output pointers instead.
+            const int64_t slot0 = g.out_idx ? 0 : f;
+            if (g.out_idx) s.out_idx = g.out_idx + f;
+            void *t32 = nullptr, *t98 = nullptr;
+            if (want_p && !p_done) {
+                if (d_tile32_out) t32 = d_tile32_out + (size_t)f * 1024;
+                else KE_TRY(ke_reserve(ctx, KE_BUF_TILE32, (size_t)s.n * 1024, &t32));
+                KE_TRY(resample_generic(ctx, s, 32, 32, (uint8_t *)t32));
+            }
+            if (want_d) {
+                if (d_tile98_out) t98 = d_tile98_out + (size_t)f * 72;
+                else KE_TRY(ke_reserve(ctx, KE_BUF_TILE98, (size_t)s.n * 72, &t98));
+                KE_TRY(resample_generic(ctx, s, 9, 8, (uint8_t *)t98));
+            }
+            uint64_t *ph = (d_phash && !p_done) ? d_phash + slot0 : nullptr;
+            uint64_t *dh = d_dhash ? d_dhash + slot0 : nullptr;
+            if (ph || dh) {
+                hipLaunchKernelGGL(ke_tiles_to_hashes, dim3((unsigned)s.n), dim3(256), 0, ctx->stream, (const uint8_t *)t32,
+                                   (const uint8_t *)t98, s.out_idx, ph, dh);
+                KE_HIP(ctx, hipGetLastError());
+            }
+        }
+    }
+    return KE_OK;
+}

@@ -1,0 +1,121 @@
+// ke_internal.h -- shared declarations of libkeyes_hip.so (gfx950 only, no CPU fallback).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/keyes.h"
+
+#define KE_API extern "C" __attribute__((visibility("default")))
+
+// ---------------------------------------------------------------------------------------
+// Lanczos coefficient tables (host side: ke_coeffs.cpp).
+// plain  : Pillow's own layout, bounds[o] = (first tap, tap count), kk[o][ksize] 22-bit ints.
+// packed : the layout the fused kernel eats.  For output o the window starts at byte
+//          start[o] (multiple of 8) and spans 4*ndw bytes; tap weight k is split into three
+//          balanced signed bytes k = b0 + 256*b1 + 65536*b2, stored per window dword as three
+//          packed i8x4 words (one per byte plane) so a v_dot4_i32_i8 against four signed luma
+//          bytes (L-128) accumulates each plane; bias[o] = 128*sum(k) + 2^21.
+// ---------------------------------------------------------------------------------------
+struct KeAxisCoeffs {
+    int in_size = 0, out_size = 0;
+    int ksize = 0;
+    std::vector<int32_t> bounds;  // 2*out
+    std::vector<int32_t> kk;      // out*ksize
+    int ndw = 0;                  // window dwords (multiple of 4)
+    int span = 0;                 // max(start[o] + 4*ndw)
+    std::vector<int32_t> start;   // out
+    std::vector<int32_t> bias;    // out
+    std::vector<int32_t> packed;  // out*ndw*3
+    // device copies
+    int32_t *d_bounds = nullptr, *d_kk = nullptr, *d_start = nullptr, *d_bias = nullptr, *d_packed = nullptr;
+};
+
+void ke_build_axis_coeffs(int in_size, int out_size, KeAxisCoeffs &out);
+
+struct KeDevBuf {
+    void *ptr = nullptr;
+    size_t bytes = 0;
+};
+
+enum { KE_T_HASH = 0, KE_T_SCAN = 1, KE_T_SSIM = 2, KE_T_SYNTH = 3, KE_T_COUNT = 4 };
+enum {
+    KE_BUF_PIXELS = 0,   // staged input images
+    KE_BUF_TMP,          // first-pass output of the generic resampler
+    KE_BUF_TILE32,
+    KE_BUF_TILE98,
+    KE_BUF_OUT0,         // staged outputs
+    KE_BUF_OUT1,
+    KE_BUF_META,         // offsets / out_idx arrays
+    KE_BUF_SCAN_IN,
+    KE_BUF_SCAN_AUX,
+    KE_BUF_SCAN_EDGES,
+    KE_BUF_SCAN_CNT,
+    KE_BUF_SCAN_HIST,
+    KE_BUF_SSIM_IN,
+    KE_BUF_SSIM_AUX,
+    KE_BUF_COUNT
+};
+
+struct ke_ctx {
+    int device = 0;
+    int cu_count = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::string err;
+    KeDevBuf buf[KE_BUF_COUNT];
+    std::map<std::pair<int, int>, KeAxisCoeffs *> coeffs;
+    hipEvent_t ev0[KE_T_COUNT] = {}, ev1[KE_T_COUNT] = {};
+    bool ev_valid[KE_T_COUNT] = {};
+};
+
+// error helpers ------------------------------------------------------------------------------
+int ke_fail(ke_ctx *ctx, int code, const char *fmt, ...);
+#define KE_HIP(ctx, call)                                                                        \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return ke_fail((ctx), KE_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                           __FILE__, __LINE__);                                                  \
+    } while (0)
+#define KE_TRY(expr)            \
+    do {                        \
+        int rc_ = (expr);       \
+        if (rc_ != KE_OK) return rc_; \
+    } while (0)
+
+// memory helpers (ke_api.hip) ------------------------------------------------------------------
+bool ke_is_device_ptr(const void *p);
+int ke_reserve(ke_ctx *ctx, int which, size_t bytes, void **out);
+// Returns in *dev a device pointer holding `bytes` of `p` (p itself if it already is device memory,
+// else a staged copy in buffer `which`).
+int ke_to_device(ke_ctx *ctx, const void *p, size_t bytes, int which, const void **dev);
+const KeAxisCoeffs *ke_get_coeffs(ke_ctx *ctx, int in_size, int out_size);
+void ke_time_begin(ke_ctx *ctx, int kind);
+void ke_time_end(ke_ctx *ctx, int kind);
+
+// kernel launchers (one per .hip file) ------------------------------------------------------------
+struct KeHashGroup {
+    const uint8_t *pixels;     // device
+    const uint64_t *offsets;   // device, nullable (then image k is at k*stride)
+    uint64_t stride;
+    const int64_t *out_idx;    // device, nullable (then output slot k)
+    int64_t n;
+    int w, h, channels;
+};
+int ke_launch_hash_group(ke_ctx *ctx, const KeHashGroup &g, uint64_t *d_phash, uint64_t *d_dhash,
+                         uint8_t *d_tile32_out, uint8_t *d_tile98_out);
+int ke_launch_scan(ke_ctx *ctx, const uint64_t *d_hashes, const int64_t *d_ids, const int64_t *d_sizes, int64_t n,
+                   int part_index, int part_count, int threshold, int band_bits, int band_count, double size_ratio,
+                   int64_t bucket_pair_cap, ke_edge *d_edges, int64_t capacity, unsigned long long *d_counters,
+                   unsigned long long *pairs_evaluated);
+int ke_launch_ssim(ke_ctx *ctx, const uint8_t *d_images, int w, int h, int channels, const int64_t *d_pa,
+                   const int64_t *d_pb, int64_t n_pairs, double *d_out);
+int ke_launch_synth_rgb(ke_ctx *ctx, uint64_t seed, int64_t first, int64_t n, int w, int h, uint8_t *d_out);
+int ke_launch_synth_hashes(ke_ctx *ctx, uint64_t seed, int64_t n, uint64_t *d_out);

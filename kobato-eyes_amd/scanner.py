@@ -1,0 +1,324 @@
+"""Duplicate scanning on the MI355X: drop-in for the reference's ``dup.scanner``.
+
+Same public surface as src/dup/scanner.py:430-436 -- ``DuplicateFile``, ``DuplicateCluster``,
+``DuplicateClusterEntry``, ``DuplicateScanConfig``, ``DuplicateScanner`` -- so it plugs into
+``DupViewModel(scanner_factory=...)`` (src/ui/viewmodels/dup_view_model.py:31,41).
+
+Candidate generation (src/dup/scanner.py:227-299) runs as one all-pairs popcount scan on the
+GPU (csrc/ke_scan.hip) with the closed form of the reference's bucket loop as predicate;
+connected components come from the library's host union-find; keeper choice and every sort
+key follow src/dup/scanner.py:320-356, 402-415.
+"""
+from __future__ import annotations
+
+import logging
+import math
+import os
+from dataclasses import dataclass
+from pathlib import Path
+from typing import Iterable, Mapping, Optional, Sequence
+
+import numpy as np
+
+from . import _native
+
+logger = logging.getLogger("dup.scanner")
+
+_MASK64 = (1 << 64) - 1
+_EXT_RANK = {"png": 4, "apng": 4, "webp": 3, "tiff": 2, "tif": 2, "bmp": 1, "gif": 1,
+             "jpeg": 0, "jpg": 0, "jpe": 0, "jfif": 0}
+
+PHASH_KEYS = ("phash_u64", "phash", "phash64", "phash_hex", "phash_bytes", "signature", "sig")
+
+
+def _row_get(row, key, default=None):
+    """Field of a dict / sqlite3.Row / attribute bag; malformed access yields the default."""
+    try:
+        if isinstance(row, dict):
+            return row.get(key, default)
+        keys = getattr(row, "keys", None)
+        if keys is not None and key in keys():
+            return row[key]
+        return getattr(row, key, default)
+    except (AttributeError, KeyError, TypeError):
+        return default
+
+
+def _parse_phash_any(raw) -> Optional[int]:
+    """Any stored representation -> unsigned 64-bit int, or None (src/dup/scanner.py:44-81)."""
+    if raw is None:
+        return None
+    if isinstance(raw, (bytes, bytearray, memoryview)):
+        return int.from_bytes(bytes(raw), "big", signed=False) & _MASK64
+    if isinstance(raw, str):
+        text = raw.strip()
+        if not text:
+            return None
+        for base in (0, 16):
+            try:
+                return int(text, base) & _MASK64
+            except ValueError:
+                continue
+        return None
+    try:
+        return int(raw) & _MASK64
+    except (OverflowError, TypeError, ValueError):
+        return None
+
+
+def _int_or_none(value):
+    return int(value) if isinstance(value, (int, float)) else None
+
+
+@dataclass(frozen=True)
+class DuplicateFile:
+    """What the scan needs to know about one file (src/dup/scanner.py:87-128)."""
+
+    file_id: int
+    path: Path
+    size: Optional[int]
+    width: Optional[int]
+    height: Optional[int]
+    phash: int
+    embedding: Optional[tuple] = None
+
+    @classmethod
+    def from_row(cls, row: Mapping[str, object]) -> "DuplicateFile":
+        raw = None
+        for key in PHASH_KEYS:
+            raw = _row_get(row, key)
+            if raw is not None:
+                break
+        value = _parse_phash_any(raw)
+        if value is None:
+            raise ValueError("Row is missing perceptual hash information")
+        return cls(
+            file_id=int(_row_get(row, "file_id", _row_get(row, "id", -1))),
+            path=Path(str(_row_get(row, "path", _row_get(row, "file_path", "")))),
+            size=_int_or_none(_row_get(row, "size")),
+            width=_int_or_none(_row_get(row, "width")),
+            height=_int_or_none(_row_get(row, "height")),
+            phash=value,
+        )
+
+    @property
+    def resolution(self) -> int:
+        return (self.width or 0) * (self.height or 0)
+
+    @property
+    def extension_priority(self) -> int:
+        return _EXT_RANK.get(self.path.suffix.lower().lstrip("."), 0)
+
+
+@dataclass(frozen=True)
+class DuplicateClusterEntry:
+    file: DuplicateFile
+    best_hamming: Optional[int]
+
+
+@dataclass(frozen=True)
+class DuplicateCluster:
+    files: list
+    keeper_id: int
+
+
+@dataclass(frozen=True)
+class DuplicateScanConfig:
+    """Thresholds of the scan; validation as src/dup/scanner.py:147-166."""
+
+    hamming_threshold: int = 8
+    size_ratio: Optional[float] = None
+    band_bits: int = 16
+    band_count: int = 4
+    cosine_threshold: Optional[float] = None
+
+    def __post_init__(self) -> None:
+        if self.band_bits <= 0:
+            raise ValueError("band_bits must be positive")
+        if self.band_count <= 0:
+            raise ValueError("band_count must be positive")
+        if not 0 <= self.hamming_threshold <= 64:
+            raise ValueError("hamming_threshold must be in [0, 64]")
+        if self.cosine_threshold is not None and not -1.0 <= self.cosine_threshold <= 1.0:
+            raise ValueError("cosine_threshold must be between -1.0 and 1.0")
+
+
+@dataclass
+class DuplicateEdge:
+    file_id_a: int
+    file_id_b: int
+    hamming: Optional[int]
+
+
+def _safe_positive_int(value: Optional[str]) -> Optional[int]:
+    if value is None or not value.strip():
+        return None
+    try:
+        parsed = int(value)
+    except ValueError:
+        return None
+    return parsed if parsed > 0 else None
+
+
+def _cosine(left: DuplicateFile, right: DuplicateFile) -> Optional[float]:
+    """float64 cosine of two embeddings; None = "cannot tell, let it pass" (src/dup/scanner.py:383-400)."""
+    u, v = left.embedding, right.embedding
+    if u is None or v is None or len(u) == 0 or len(v) == 0 or len(u) != len(v):
+        return None
+    dot = sum(p * q for p, q in zip(u, v))
+    nu, nv = math.sqrt(sum(p * p for p in u)), math.sqrt(sum(q * q for q in v))
+    if nu == 0.0 or nv == 0.0:
+        return None
+    return dot / (nu * nv)
+
+
+class DuplicateScanner:
+    """GPU-backed replacement of the reference scanner (same constructor, same method)."""
+
+    def __init__(self, config: DuplicateScanConfig, *, device: int = 0, part_index: int = 0, part_count: int = 1) -> None:
+        assert config.band_bits * config.band_count <= 64, "band config too large"
+        self._config = config
+        self._device = device
+        self._part = (part_index, part_count)
+        self.last_counters: Optional[dict] = None
+
+    # -- candidate edges ---------------------------------------------------------------------
+    def candidate_edges(self, candidates: Sequence[DuplicateFile]) -> dict:
+        """{(id_lo, id_hi): DuplicateEdge} exactly as the reference's ``edges`` dict ends up."""
+        cfg = self._config
+        n = len(candidates)
+        hashes = np.fromiter((f.phash & _MASK64 for f in candidates), dtype=np.uint64, count=n)
+        ids = np.fromiter((f.file_id for f in candidates), dtype=np.int64, count=n)
+        sizes = np.fromiter(((f.size or 0) for f in candidates), dtype=np.int64, count=n)
+        cap = _safe_positive_int(os.environ.get("KE_DUP_BUCKET_PAIR_CAP"))
+        self._log_bucket_stats(hashes, cap)
+        ratio = cfg.size_ratio if (cfg.size_ratio is not None and cfg.size_ratio > 0) else 0.0
+        ctx = _native.get_context(self._device)
+        raw, counters = ctx.hamming_scan(
+            hashes, n, ids=ids, sizes=sizes if ratio > 0 else None, threshold=cfg.hamming_threshold,
+            band_bits=cfg.band_bits, band_count=cfg.band_count, size_ratio=ratio, bucket_pair_cap=cap or 0,
+            part_index=self._part[0], part_count=self._part[1])
+        return self._edges_from_raw(candidates, hashes, ids, raw, counters)
+
+    def _edges_from_raw(self, candidates, hashes, ids, raw, counters) -> dict:
+        cfg = self._config
+        order = np.lexsort((raw["b"], raw["a"]))
+        raw = raw[order]
+        after_cos = 0
+        keyed: dict[tuple[int, int], list] = {}
+        for a, b, h, bands in zip(raw["a"].tolist(), raw["b"].tolist(), raw["h"].tolist(), raw["bands"].tolist()):
+            if cfg.cosine_threshold is not None:
+                cos = _cosine(candidates[a], candidates[b])
+                if cos is not None and cos < cfg.cosine_threshold:
+                    continue
+            after_cos += bin(bands & 0xFFFFFFFF).count("1")
+            ia, ib = int(ids[a]), int(ids[b])
+            keyed.setdefault((ia, ib) if ia < ib else (ib, ia), []).append((a, b, h, bands))
+        edges: dict[tuple[int, int], DuplicateEdge] = {}
+        first_idx_cache: dict[tuple[int, int], int] = {}
+        mask = (1 << cfg.band_bits) - 1
+
+        def bucket_rank(pos: int, bands: int) -> int:
+            # dict insertion order of the reference's buckets: (first position holding the value, band)
+            best = None
+            for band in range(min(cfg.band_count, 32)):
+                if not (bands >> band) & 1:
+                    continue
+                val = (int(hashes[pos]) >> (band * cfg.band_bits)) & mask
+                key = (band, val)
+                if key not in first_idx_cache:
+                    col = (hashes >> np.uint64(band * cfg.band_bits)) & np.uint64(mask)
+                    first_idx_cache[key] = int(np.argmax(col == np.uint64(val)))
+                rank = first_idx_cache[key] * cfg.band_count + band
+                best = rank if best is None or rank < best else best
+            return best if best is not None else 0
+
+        for key, hits in keyed.items():
+            if len(hits) > 1:  # duplicate file ids: the first writer wins (src/dup/scanner.py:287-290)
+                hits.sort(key=lambda t: (bucket_rank(t[0], t[3]), t[0], t[1]))
+            a, b, h, _ = hits[0]
+            edges[key] = DuplicateEdge(int(ids[a]), int(ids[b]), int(h))
+        self.last_counters = {"pairs_evaluated": int(counters[0]), "after_ham": int(counters[1]),
+                              "after_cosine": after_cos, "edges": len(edges)}
+        logger.info("dup: pairs evaluated=%d -> ham=%d -> cosine=%d -> edges=%d", int(counters[0]), int(counters[1]),
+                    after_cos, len(edges))
+        return edges
+
+    def _log_bucket_stats(self, hashes: np.ndarray, cap: Optional[int]) -> None:
+        if not logger.isEnabledFor(logging.INFO) and cap is None:
+            return
+        cfg = self._config
+        mask = np.uint64((1 << cfg.band_bits) - 1)
+        n_buckets = ge2 = max_bucket = 0
+        for band in range(cfg.band_count):
+            _, counts = np.unique((hashes >> np.uint64(band * cfg.band_bits)) & mask, return_counts=True)
+            n_buckets += len(counts)
+            ge2 += int((counts >= 2).sum())
+            max_bucket = max(max_bucket, int(counts.max()) if len(counts) else 0)
+        max_pairs = max_bucket * (max_bucket - 1) // 2
+        logger.info("dup: buckets=%d (>=2:%d) max_bucket=%d max_bucket_pairs=%d pair_cap=%s", n_buckets, ge2, max_bucket,
+                    max_pairs, cap)
+        if cap is not None and max_pairs > cap:
+            logger.warning("dup: largest bucket has %d pair(s), above KE_DUP_BUCKET_PAIR_CAP=%d; large buckets will be skipped",
+                           max_pairs, cap)
+
+    # -- the seam ----------------------------------------------------------------------------
+    def build_clusters(self, files: Iterable[DuplicateFile]) -> list:
+        cfg = self._config
+        candidates = [f for f in files if f.phash is not None]
+        logger.info("dup: candidates=%d band_bits=%d band_count=%d ham_th=%d size_ratio=%s cosine_th=%s", len(candidates),
+                    cfg.band_bits, cfg.band_count, cfg.hamming_threshold, cfg.size_ratio, cfg.cosine_threshold)
+        if len(candidates) < 2:
+            return []
+        edges = self.candidate_edges(candidates)
+        if not edges:
+            return []
+        return assemble_clusters(candidates, edges.values())
+
+    @staticmethod
+    def _choose_keeper(entries: Sequence[DuplicateClusterEntry]) -> int:
+        return min(entries, key=_keeper_key).file.file_id
+
+
+def _keeper_key(entry: DuplicateClusterEntry) -> tuple:
+    f = entry.file
+    return (-(f.size or 0), -f.resolution, -f.extension_priority, f.path.suffix.lower(), f.path.name.lower(), f.file_id)
+
+
+def assemble_clusters(candidates: Sequence[DuplicateFile], edges: Iterable[DuplicateEdge]) -> list:
+    """Edges -> ordered clusters (src/dup/scanner.py:304-356).  Components come from the
+    library's host union-find over compacted file ids."""
+    edges = list(edges)
+    by_id = {f.file_id: f for f in candidates}          # later duplicates of an id win, as in the reference
+    node_ids = sorted({fid for e in edges for fid in (e.file_id_a, e.file_id_b)})
+    node_of = {fid: k for k, fid in enumerate(node_ids)}
+    raw = np.zeros(len(edges), _native.EDGE_DTYPE)
+    raw["a"] = [node_of[e.file_id_a] for e in edges]
+    raw["b"] = [node_of[e.file_id_b] for e in edges]
+    labels = _native.cluster_labels(raw, len(node_ids))
+    best: dict[int, int] = {}
+    for e in edges:
+        if e.hamming is None:
+            continue
+        for fid in (e.file_id_a, e.file_id_b):
+            if fid not in best or e.hamming < best[fid]:
+                best[fid] = e.hamming
+    groups: dict[int, list[int]] = {}
+    for fid, lab in zip(node_ids, labels.tolist()):
+        groups.setdefault(lab, []).append(fid)           # node_ids ascending -> members ascending
+    clusters = []
+    for members in groups.values():
+        if len(members) < 2:
+            continue
+        entries = [DuplicateClusterEntry(by_id[m], best.get(m)) for m in members if m in by_id]
+        if len(entries) < 2:
+            continue
+        keeper = min(entries, key=_keeper_key).file.file_id
+        entries.sort(key=lambda en: (0 if en.file.file_id == keeper else 1, -(en.file.size or 0), -en.file.resolution,
+                                     -en.file.extension_priority, en.file.path.name.lower(), en.file.file_id))
+        clusters.append(DuplicateCluster(files=entries, keeper_id=keeper))
+    clusters.sort(key=lambda c: (-max((en.file.size or 0) for en in c.files), c.files[0].file.path.as_posix().lower()))
+    return clusters
+
+
+__all__ = ["DuplicateFile", "DuplicateCluster", "DuplicateClusterEntry", "DuplicateScanConfig", "DuplicateScanner"]

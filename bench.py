@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the hot path: images/s for "pHash every image, then
+all-pairs Hamming scan + cluster membership" on synthetic 512x512 RGB (BASELINE.json configs[1]
+at N=1, configs[2] -- the same 100 000 images split over the ranks -- at N>1).
+
+    python bench.py [--gpus N --steps K --warmup W]            # N=1: plain python
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One step = one pass of the hot path over the whole corpus, inputs already resident in HBM:
+  1. ke_hash_uniform   : fused pHash kernel over this rank's images (device in, device out)
+  2. all-gather (N>1)  : ONE RCCL all_gather_into_tensor of the 64-bit hash shards
+  3. ke_hamming_scan   : this rank's share of the tile triangle, edges compacted on the device
+  4. edge merge (N>1)  : all-gather of counts + padded edge lists
+  5. ke_cluster_labels : host union-find -> cluster membership
+PyTorch only provides device memory, the stream and the process group.
+Rank 0 prints ONE JSON line (contract in the task statement).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+SEED = 20260604
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+VALU_LANE_OPS = 256 * 4 * 32 * 2.4e9   # CUs x SIMDs x lanes/clk x Hz
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--images", type=int, default=100_000, help="corpus size (BASELINE configs[1]/[2]: 100000)")
+    ap.add_argument("--side", type=int, default=512)
+    ap.add_argument("--threshold", type=int, default=8)
+    ap.add_argument("--dhash", action="store_true", help="also compute dHash in the hash step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=4000, help="images hashed by the CPU oracle for the baseline")
+    return ap.parse_args()
+
+
+def cpu_baseline(ctx, args, table_host):
+    """Oracle (CPU port of the reference path) timed on the host: a bounded sample of the same
+    workload -- `cpu_sample` of the corpus images hashed on one core, plus the reference-shaped
+    banded scan over the full hash table -- scaled to images/s for the whole corpus."""
+    from oracle import oracle as O
+
+    m = min(args.cpu_sample, args.images)
+    px = ctx.synth_rgb(SEED, 0, m, args.side, args.side)          # same pixels the GPU hashed
+    t0 = time.perf_counter()
+    ph, _ = O.hash_batch(px, want_dhash=args.dhash)
+    t_hash = time.perf_counter() - t0
+    assert np.array_equal(ph, table_host[:m]), "GPU pHash differs from the oracle on the baseline sample"
+    t0 = time.perf_counter()
+    edges, _ = O.scan_banded(table_host, threshold=args.threshold)
+    t_scan = time.perf_counter() - t0
+    total = t_hash / m * args.images + t_scan
+    return {
+        "value": args.images / total, "unit": "images/s", "cores": 1, "kind": "port",
+        "sample": f"{m} of the {args.images} corpus images hashed by oracle/keyes_oracle.c on 1 core ({t_hash:.2f} s, "
+                  f"{m / t_hash:.0f} img/s) + reference-shaped banded scan over all {args.images} hashes ({t_scan:.2f} s, "
+                  f"{len(edges)} edges); hash time scaled to the corpus",
+        "hash_images_per_s": m / t_hash, "scan_seconds": t_scan,
+    }
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+
+    from kobato_eyes_amd import _native
+    from kobato_eyes_amd.distributed import allgather_hashes
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)   # nccl == RCCL on ROCm
+
+    ctx = _native.Context(local_rank)
+    stream = torch.cuda.current_stream()
+    ctx.set_stream(stream.cuda_stream)
+
+    n_total, side = args.images, args.side
+    img_bytes = side * side * 3
+    # hash-partition of the corpus: image i lives on rank i mod world
+    mine = np.arange(rank, n_total, world, dtype=np.int64)
+    n_local = len(mine)
+    per = (n_total + world - 1) // world
+
+    # ---- setup (untimed): materialise this rank's images in HBM with the on-device generator
+    pixels = torch.empty(n_local * img_bytes, dtype=torch.uint8, device=dev)
+    if world == 1:
+        ctx.synth_rgb(SEED, 0, n_local, side, side, out=pixels.data_ptr())
+    else:
+        for k, i in enumerate(mine.tolist()):   # strided indices: one small launch per image
+            ctx.synth_rgb(SEED, i, 1, side, side, out=pixels.data_ptr() + k * img_bytes)
+    local_hash = torch.zeros(per, dtype=torch.int64, device=dev)
+    local_dhash = torch.zeros(per, dtype=torch.int64, device=dev) if args.dhash else None
+    cap = max(1 << 16, n_total)
+    edges_dev = torch.empty(cap * 24, dtype=torch.uint8, device=dev)
+    counts_dev = torch.zeros(world, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+
+    state = {}
+
+    def step():
+        nonlocal edges_dev, cap
+        # 1. hash this rank's shard (device -> device)
+        ctx.hash_uniform(pixels.data_ptr(), n_local, side, side, 3, phash_out=local_hash.data_ptr(),
+                         dhash_out=local_dhash.data_ptr() if args.dhash else None, want_dhash=args.dhash)
+        # 2. the one exchange on the data path
+        table = allgather_hashes(local_hash, n_total) if world > 1 else local_hash[:n_total]
+        # 3. sharded scan; edges stay on the device, the count comes back with the counters
+        while True:
+            edges, counters = _scan(ctx, table, n_total, args.threshold, rank, world, edges_dev, cap)
+            if edges <= cap:
+                break
+            cap = int(edges)
+            edges_dev = torch.empty(cap * 24, dtype=torch.uint8, device=dev)
+        # 4. merge edge lists
+        if world > 1:
+            counts_dev.zero_()
+            mine_cnt = torch.tensor([edges], dtype=torch.int64, device=dev)
+            dist.all_gather_into_tensor(counts_dev, mine_cnt)
+            counts = counts_dev.cpu().tolist()
+            width = max(max(counts), 1) * 24
+            gathered = torch.empty(world * width, dtype=torch.uint8, device=dev)
+            dist.all_gather_into_tensor(gathered, edges_dev[:width].contiguous())
+            host = gathered.cpu().numpy().reshape(world, width)
+            all_edges = np.concatenate([host[r, : counts[r] * 24].view(_native.EDGE_DTYPE) for r in range(world)])
+        else:
+            all_edges = edges_dev[: edges * 24].cpu().numpy().view(_native.EDGE_DTYPE)
+        # 5. cluster membership on the host
+        labels = _native.cluster_labels(all_edges, n_total)
+        state.update(table=table, edges=all_edges, labels=labels, pairs=int(counters[0]))
+
+    def _scan(ctx, table, n, thr, part, parts, edges_dev, cap):
+        import ctypes as C
+
+        lib = ctx._lib
+        n_edges = C.c_int64(0)
+        counters = np.zeros(4, np.uint64)
+        rc = lib.ke_hamming_scan(ctx._h, table.data_ptr(), None, None, n, part, parts, thr, 16, 4, 0.0, 0,
+                                 edges_dev.data_ptr(), cap, C.byref(n_edges), counters.ctypes.data)
+        ctx._check(rc, "ke_hamming_scan")
+        return n_edges.value, counters
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    hash_ms, scan_ms = [], []
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        hash_ms.append(ctx.last_kernel_ms(0))   # hipEvents around the hash kernel on its stream
+        scan_ms.append(ctx.last_kernel_ms(1))
+    fence()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = n_total * args.steps / elapsed
+        hash_avg = float(np.mean(hash_ms))
+        scan_avg = float(np.mean(scan_ms))
+        alg_bytes = n_local * (img_bytes + 8 + (8 if args.dhash else 0))      # 3*W*H read + hash(es) written, per launch
+        achieved = alg_bytes / (hash_avg * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hash_kernel_traffic.json")
+        if os.path.exists(tpath):
+            with open(tpath) as fh:
+                tj = json.load(fh)
+            if tj.get("images_per_launch") == n_local and tj.get("side") == side:
+                traffic = tj.get("hbm_bytes_per_launch")
+        pairs_rank = state["pairs"]
+        pairs_s = pairs_rank / (scan_avg * 1e-3) if scan_avg > 0 else 0.0
+        n_clusters = int(len(np.unique(state["labels"][np.unique(np.concatenate([state["edges"]["a"], state["edges"]["b"]]))]))) \
+            if len(state["edges"]) else 0
+        out = {
+            "metric": "images/s (pHash + all-pairs Hamming scan + cluster membership)",
+            "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "u8/int32 resample, f64 DCT, u64 popcount", "data": "synthetic",
+            "config": {
+                "workload": f"{n_total} synthetic {side}x{side} RGB images resident in HBM, hamming_threshold={args.threshold}, "
+                            f"band 16x4 (BASELINE configs[{1 if world == 1 else 2}])",
+                "images": n_total, "side": side, "hamming_threshold": args.threshold, "dhash": bool(args.dhash),
+                "partition": f"image i on rank i mod {world}; scan tiles dealt round-robin",
+                "step": "hash kernel -> (all-gather) -> scan kernel -> edges to host -> union-find labels",
+            },
+            "gpairs_per_s": pairs_s * world / 1e9,
+            "hash_images_per_s": n_local * world / (hash_avg * 1e-3),
+            "edges": int(len(state["edges"])), "clusters": n_clusters,
+            "kernel_ms": {"hash": hash_avg, "scan": scan_avg},
+            "roofline": {"bound": "hbm", "kernel": "ke_phash_fused", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic},
+            "roofline_scan": {"bound": "hbm (16 B/pair convention, SURVEY 8d; operands are reused from LDS/registers so "
+                                       "this can exceed 1; the real limiter is VALU)",
+                              "kernel": "ke_scan_tiles", "achieved": pairs_s * 16 / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": pairs_s * 16 / 1e9 / HBM_PEAK_GBS,
+                              "valu_frac": pairs_s * 4.5 / VALU_LANE_OPS},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(ctx, args, state["table"].cpu().numpy().view(np.uint64))
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

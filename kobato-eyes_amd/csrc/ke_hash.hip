@@ -209,7 +209,8 @@ struct KeFusedArgs {
     const int32_t *h_packed, *h_start, *h_bias;          // 32 outputs, NDWH dwords
     const int32_t *v_packed, *v_start, *v_bias;          // 32 outputs, ndwv dwords
     int ndwv;
-    int lt_bytes;   // LDS bytes of the luma tile region (>= 3584)
+    int lt_half;    // LDS bytes of ONE luma tile buffer (two are allocated; >= 1792 so 2 halves hold the DCT scratch)
+    int lt_bytes;   // = 2 * lt_half
     int hp;         // pitch of one HT column (bytes, multiple of 8)
     uint64_t *phash;
     uint8_t *tile32_out;  // nullable debug output
@@ -244,36 +245,45 @@ __global__ __launch_bounds__(256, 3) void ke_phash_fused(const KeFusedArgs a) {
     const int hst = a.h_start[o];
     const int hbias = a.h_bias[o];
 
+    // Software pipeline with the luma tile double-buffered in LDS: while the dot products of tile t
+    // run out of Lt[t&1], the 12-byte loads of tile t+1 are in flight; they are converted and
+    // written to Lt[(t+1)&1] at the end of the iteration.  One barrier per tile; the raw registers
+    // live inside one iteration only (a loop-carried register set makes hipcc wait for the loads
+    // right after issuing them).
     uint32_t raw[QPT][3];
     auto load_tile = [&](int t) {
 #pragma unroll
         for (int q = 0; q < QPT; ++q) {
-            const int gq = t * QUADS_PER_TILE + q * 256 + tid;
-            if (gq < total_quads) {
-                const uint32_t *p = reinterpret_cast<const uint32_t *>(src + (size_t)gq * 12);
-                raw[q][0] = p[0];
-                raw[q][1] = p[1];
-                raw[q][2] = p[2];
-            } else {
-                raw[q][0] = raw[q][1] = raw[q][2] = 0;
-            }
+            // Unconditional loads (a guarded load makes hipcc wait vmcnt(0) after each one): quads past
+            // the image end re-read the last quad; those rows only ever meet zero tap weights.
+            int gq = t * QUADS_PER_TILE + q * 256 + tid;
+            gq = gq < total_quads ? gq : total_quads - 1;
+            const uint32_t *p = reinterpret_cast<const uint32_t *>(src + (size_t)gq * 12);
+            raw[q][0] = p[0];
+            raw[q][1] = p[1];
+            raw[q][2] = p[2];
         }
+    };
+    auto store_luma = [&](uint8_t *dst) {
+#pragma unroll
+        for (int q = 0; q < QPT; ++q)
+            reinterpret_cast<uint32_t *>(dst)[q * 256 + tid] = luma4_biased(raw[q][0], raw[q][1], raw[q][2]);
     };
 
     const int ntiles = (h + kRT - 1) / kRT;
     load_tile(0);
+    store_luma(Lt);
+    __syncthreads();
     for (int t = 0; t < ntiles; ++t) {
-        // ---- K1a: luma of the tile already in registers -> signed bytes in LDS
-#pragma unroll
-        for (int q = 0; q < QPT; ++q)
-            reinterpret_cast<uint32_t *>(Lt)[q * 256 + tid] = luma4_biased(raw[q][0], raw[q][1], raw[q][2]);
-        if (t + 1 < ntiles) load_tile(t + 1);  // next tile's HBM reads fly during the dot products
-        __syncthreads();
+        const uint8_t *cur = Lt + (t & 1) * a.lt_half;
+        const int tn = t + 1 < ntiles ? t + 1 : t;   // last iteration re-reads its own tile (L2 hit, result unused)
+        load_tile(tn);
+        __builtin_amdgcn_sched_barrier(0);   // keep the loads at the top: hipcc otherwise sinks them next to their use
         // ---- K1b: horizontal taps: thread = (output column o, rows 2rg, 2rg+1)
         uint32_t packed2 = 0;
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr) {
-            const uint8_t *lrow = Lt + (2 * rg + rr) * W + hst;
+            const uint8_t *lrow = cur + (2 * rg + rr) * W + hst;
             int d0 = 0, d1 = 0, d2 = 0;
 #pragma unroll
             for (int p = 0; p < NDWH / 2; ++p) {
@@ -290,6 +300,9 @@ __global__ __launch_bounds__(256, 3) void ke_phash_fused(const KeFusedArgs a) {
             packed2 |= (uint32_t)(r ^ 0x80) << (8 * rr);  // signed byte again for the vertical dot products
         }
         *reinterpret_cast<uint16_t *>(HT + (size_t)o * a.hp + t * kRT + 2 * rg) = (uint16_t)packed2;
+        // ---- K1a for the next tile: luma of the loads issued above -> the other LDS buffer
+        __builtin_amdgcn_sched_barrier(0);   // ...and keep their first use down here, behind the dot products
+        store_luma(Lt + ((t + 1) & 1) * a.lt_half);
         __syncthreads();
     }
 
@@ -355,8 +368,9 @@ int launch_fused(ke_ctx *ctx, const KeHashGroup &g, const KeAxisCoeffs *ch, cons
     a.v_packed = cv->d_packed; a.v_start = cv->d_start; a.v_bias = cv->d_bias;
     a.ndwv = cv->ndw;
     int lt = kRT * W + std::max(0, ch->span - W) + 16;
-    if (lt < 3584) lt = 3584;
-    a.lt_bytes = (lt + 15) & ~15;
+    if (lt < 1792) lt = 1792;
+    a.lt_half = (lt + 15) & ~15;
+    a.lt_bytes = 2 * a.lt_half;
     const int rows_padded = ((g.h + kRT - 1) / kRT) * kRT;
     a.hp = ((std::max(cv->span, rows_padded) + 7) & ~7) + 8;
     a.phash = d_phash; a.tile32_out = d_tile32;

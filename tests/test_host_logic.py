@@ -1,0 +1,214 @@
+"""CPU tests of the host side: the C-ABI library loads and exports every declared symbol, the
+drop-in dataclasses / row parsing / cluster assembly reproduce the reference's goldens, the
+product refuses to run without a GPU, and the N>1 sharding logic works under gloo."""
+from __future__ import annotations
+
+import os
+import re
+import sqlite3
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import _golden as G
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def K():
+    if not os.path.exists(os.path.join(ROOT, "kobato-eyes_amd", "libkeyes_hip.so")):
+        subprocess.check_call(["bash", os.path.join(ROOT, "kobato-eyes_amd", "build.sh")])
+    import kobato_eyes_amd
+
+    return kobato_eyes_amd
+
+
+def test_library_exports_every_declared_symbol(K):
+    header = open(os.path.join(ROOT, "include", "keyes.h")).read()
+    declared = set(re.findall(r"\b(ke_[a-z0-9_]+)\s*\(", header)) - {"ke_ctx"}
+    lib = K._native.load_library()
+    assert declared == set(K._native.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.ke_abi_version() == 1
+
+
+def test_no_cpu_fallback_without_gpu(K):
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    with pytest.raises(RuntimeError):
+        K._native.Context(0)
+    from PIL import Image
+
+    with pytest.raises(RuntimeError):      # same contract as the reference when cv2 is missing (src/sig/phash.py:35-36)
+        K.phash(Image.new("RGB", (64, 64)))
+
+
+def test_product_never_imports_the_oracle():
+    """Nothing under the product package imports, links or opens anything under oracle/."""
+    pkg = os.path.join(ROOT, "kobato-eyes_amd")
+    pattern = re.compile(r"(from|import)\s+oracle|libkeyes_oracle|keyes_oracle|[\"'/]oracle[/\"']")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h", ".sh")) and f != "dct_table.h":   # generated constants
+                text = open(os.path.join(dirpath, f), encoding="utf-8").read()
+                assert not pattern.search(text), os.path.join(dirpath, f)
+
+
+def test_from_row_matches_reference(K):
+    rows, expected, bad = G.rows_golden()
+    for row, exp in zip(rows, expected):
+        f = K.DuplicateFile.from_row(row)
+        got = {"file_id": f.file_id, "path": f.path.as_posix(), "size": f.size, "width": f.width, "height": f.height,
+               "phash": str(f.phash), "resolution": f.resolution, "extension_priority": f.extension_priority}
+        assert got == exp
+    for row in bad:
+        with pytest.raises(ValueError, match="missing perceptual hash"):
+            K.DuplicateFile.from_row(row)
+
+
+def test_from_row_accepts_sqlite_rows(K):
+    conn = sqlite3.connect(":memory:")
+    conn.row_factory = sqlite3.Row
+    conn.execute("CREATE TABLE t (file_id INTEGER, path TEXT, size INTEGER, width INTEGER, height INTEGER, phash_u64 INTEGER)")
+    conn.execute("INSERT INTO t VALUES (7, 'a/b.PNG', 10, 3, 4, -2)")
+    f = K.DuplicateFile.from_row(conn.execute("SELECT * FROM t").fetchone())
+    assert (f.file_id, f.phash, f.extension_priority, f.resolution) == (7, (1 << 64) - 2, 4, 12)
+
+
+def test_config_validation(K):
+    for kw in ({"band_bits": 0}, {"band_count": 0}, {"hamming_threshold": -1}, {"hamming_threshold": 65},
+               {"cosine_threshold": 1.5}):
+        with pytest.raises(ValueError):
+            K.DuplicateScanConfig(**kw)
+    with pytest.raises(AssertionError):
+        K.DuplicateScanner(K.DuplicateScanConfig(band_bits=32, band_count=3))
+    s = K.DedupSettings.coerce("12", "0.5")
+    assert (s.hamming_threshold, s.ssim_threshold) == (12, 0.5)
+    s = K.DedupSettings.coerce("x", None)
+    assert (s.hamming_threshold, s.ssim_threshold) == (10, 0.92)     # src/core/config/schema.py:186-201
+    assert K.DedupSettings.coerce(-4, 1).hamming_threshold == 0
+
+
+@pytest.mark.parametrize("name", sorted(G.scan_scenarios()))
+def test_cluster_assembly_matches_reference(K, name):
+    """Edges (from the golden file) -> clusters through the product's host code: union-find in
+    libkeyes_hip.so + the reference's keeper / ordering rules."""
+    sc = G.scan_scenarios()[name]
+    files = [K.DuplicateFile(file_id=f["file_id"], path=Path(f["path"]), size=f["size"], width=f["width"],
+                             height=f["height"], phash=f["phash"] & ((1 << 64) - 1)) for f in sc["files"]]
+    from kobato_eyes_amd.scanner import DuplicateEdge
+
+    edges = [DuplicateEdge(a, b, h) for a, b, h in sc["edges"]]
+    clusters = K.assemble_clusters(files, edges) if edges else []
+    got = [{"keeper_id": c.keeper_id, "entries": [[e.file.file_id, e.best_hamming] for e in c.files]} for c in clusters]
+    assert got == sc["clusters"]
+
+
+def test_first_writer_rule_with_duplicate_ids(K):
+    """_edges_from_raw resolves duplicate file ids exactly as the reference's dict insertion order does."""
+    sc = G.scan_scenarios()["dup_ids_signed"]
+    from oracle import oracle as O
+
+    files = [K.DuplicateFile(file_id=f["file_id"], path=Path(f["path"]), size=f["size"], width=f["width"],
+                             height=f["height"], phash=f["phash"] & ((1 << 64) - 1)) for f in sc["files"]]
+    hashes, ids, _ = G.files_to_arrays(sc["files"])
+    raw = O.scan_bruteforce(hashes, threshold=10)          # every (i,j,h,bands) the GPU kernel would emit...
+    raw = raw[ids[raw["a"]] != ids[raw["b"]]]              # ...after its same-id test
+    scanner = K.DuplicateScanner(K.DuplicateScanConfig(**sc["config"]))
+    edges = scanner._edges_from_raw(files, hashes, ids, raw, np.array([0, int(sum(bin(b).count("1") for b in raw["bands"])), len(raw), 0], np.uint64))
+    assert sorted([a, b, e.hamming] for (a, b), e in edges.items()) == sc["edges"]
+
+
+def test_cluster_builder(K):
+    M = K.RefinedMatch
+    out = K.ClusterBuilder().build([M(1, 2, 0.95, 0.2, True, "ssim"), M(2, 3, 0.93, 0.15, True, "ssim"),
+                                    M(4, 5, 0.91, 0.16, True, "ssim"), M(3, 5, 0.5, 0.05, False, "below")])
+    assert [c.members for c in out] == [[1, 2, 3], [4, 5]] and [c.representative for c in out] == [1, 4]
+    assert [len(c.matches) for c in out] == [2, 1]
+    assert K.ClusterBuilder().build([]) == []
+
+
+def test_signed_wrap_and_upsert(K, tmp_path):
+    from kobato_eyes_amd.fastsig import _to_signed64
+
+    assert [_to_signed64(v) for v in (0, (1 << 64) - 1, 1 << 63, (1 << 63) - 1, (1 << 64) + 7)] == [0, -1, -(1 << 63), (1 << 63) - 1, 7]
+    db = tmp_path / "s.db"
+    conn = sqlite3.connect(db)
+    conn.execute("CREATE TABLE signatures (file_id INTEGER PRIMARY KEY, phash_u64 INTEGER NOT NULL, dhash_u64 INTEGER NOT NULL)")
+    assert K.bulk_upsert_signatures(conn, [(1, (1 << 64) - 1, 5), (2, 2, 0)]) == 2
+    assert K.bulk_upsert_signatures(conn, [(2, 1 << 63, 9)]) == 1
+    assert conn.execute("SELECT * FROM signatures ORDER BY file_id").fetchall() == [(1, -1, 5), (2, -(1 << 63), 9)]
+    assert K.bulk_upsert_signatures(conn, []) == 0
+
+
+def test_fastsig_drops_missing_files_and_reports_progress(K, monkeypatch, tmp_path):
+    """Progress cadence / cancel semantics of src/core/fastsig.py:86-98 with the GPU hasher stubbed out
+    (this is host logic; the hashing itself is covered by the gpu tests)."""
+    import kobato_eyes_amd.fastsig as fs
+    from PIL import Image
+
+    paths = []
+    for k in range(5):
+        p = tmp_path / f"i{k}.png"
+        Image.new("RGB", (8, 8), (k, k, k)).save(p)
+        paths.append((k + 1, str(p)))
+    paths.insert(2, (99, str(tmp_path / "missing.png")))
+    monkeypatch.setattr(fs._phash, "hash_batch", lambda imgs, want_dhash=True, device=0: (
+        np.arange(len(imgs), dtype=np.uint64) + np.uint64(1 << 63), np.zeros(len(imgs), np.uint64), np.ones(len(imgs), bool)))
+    seen = []
+    out = fs.compute_signatures_mp(paths, max_workers=2, chunksize=4, progress=lambda d, t: seen.append((d, t)))
+    assert [r[0] for r in out] == [1, 2, 3, 4, 5] and seen == [(6, 6)]
+    assert all(r[1] < 0 for r in out)                      # stored signed
+    calls = {"n": 0}
+
+    def cancel():
+        calls["n"] += 1
+        return calls["n"] > 2
+
+    out = fs.compute_signatures_mp(paths, max_workers=2, chunksize=4, cancel_fn=cancel)
+    assert len(out) == 2                                   # partial result after cancel
+
+
+_GLOO_WORKER = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, torch.distributed as dist
+from kobato_eyes_amd.distributed import allgather_hashes, gather_edges, owned_indices, interleave_gathered
+from kobato_eyes_amd import _native
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % sys.argv[2], rank=int(sys.argv[3]), world_size=2)
+rank, world, n = dist.get_rank(), 2, 1001
+table = (np.arange(n, dtype=np.int64) * 7919) ^ 0x5555
+mine = owned_indices(n, rank, world)
+local = torch.from_numpy(table[mine].copy())
+full = allgather_hashes(local, n)
+assert np.array_equal(full.numpy(), table), "all-gather did not restore corpus order"
+edges = np.zeros(3 + rank, _native.EDGE_DTYPE); edges["a"] = rank; edges["b"] = np.arange(len(edges)) + 10
+merged = gather_edges(edges)
+assert len(merged) == 7 and sorted(merged["a"].tolist()) == [0, 0, 0, 1, 1, 1, 1]
+parts = [table[owned_indices(n, r, world)] for r in range(world)]
+assert np.array_equal(interleave_gathered(parts, n), table)
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_sharding_helpers_world_size_2_gloo(tmp_path):
+    script = tmp_path / "w.py"
+    script.write_text(_GLOO_WORKER)
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(port), str(r)], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o

@@ -79,7 +79,7 @@ def main():
     import torch.distributed as dist
 
     from kobato_eyes_amd import _native
-    from kobato_eyes_amd.distributed import allgather_hashes
+    from kobato_eyes_amd.distributed import allgather_edge_buffers, allgather_hashes
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -88,7 +88,10 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # under torch.distributed.run the process group is used even at WORLD_SIZE=1, so the RCCL code
+    # path can be rehearsed on a one-GPU box
+    distributed = "RANK" in os.environ and "MASTER_ADDR" in os.environ
+    if distributed:
         dist.init_process_group("nccl", device_id=dev)   # nccl == RCCL on ROCm
 
     ctx = _native.Context(local_rank)
@@ -113,7 +116,6 @@ def main():
     local_dhash = torch.zeros(per, dtype=torch.int64, device=dev) if args.dhash else None
     cap = max(1 << 16, n_total)
     edges_dev = torch.empty(cap * 24, dtype=torch.uint8, device=dev)
-    counts_dev = torch.zeros(world, dtype=torch.int64, device=dev)
     torch.cuda.synchronize()
 
     state = {}
@@ -124,7 +126,7 @@ def main():
         ctx.hash_uniform(pixels.data_ptr(), n_local, side, side, 3, phash_out=local_hash.data_ptr(),
                          dhash_out=local_dhash.data_ptr() if args.dhash else None, want_dhash=args.dhash)
         # 2. the one exchange on the data path
-        table = allgather_hashes(local_hash, n_total) if world > 1 else local_hash[:n_total]
+        table = allgather_hashes(local_hash, n_total) if distributed else local_hash[:n_total]
         # 3. sharded scan; edges stay on the device, the count comes back with the counters
         while True:
             edges, counters = _scan(ctx, table, n_total, args.threshold, rank, world, edges_dev, cap)
@@ -133,16 +135,9 @@ def main():
             cap = int(edges)
             edges_dev = torch.empty(cap * 24, dtype=torch.uint8, device=dev)
         # 4. merge edge lists
-        if world > 1:
-            counts_dev.zero_()
-            mine_cnt = torch.tensor([edges], dtype=torch.int64, device=dev)
-            dist.all_gather_into_tensor(counts_dev, mine_cnt)
-            counts = counts_dev.cpu().tolist()
-            width = max(max(counts), 1) * 24
-            gathered = torch.empty(world * width, dtype=torch.uint8, device=dev)
-            dist.all_gather_into_tensor(gathered, edges_dev[:width].contiguous())
-            host = gathered.cpu().numpy().reshape(world, width)
-            all_edges = np.concatenate([host[r, : counts[r] * 24].view(_native.EDGE_DTYPE) for r in range(world)])
+        if distributed:
+            merged, _ = allgather_edge_buffers(edges_dev, edges)
+            all_edges = merged.view(_native.EDGE_DTYPE)
         else:
             all_edges = edges_dev[: edges * 24].cpu().numpy().view(_native.EDGE_DTYPE)
         # 5. cluster membership on the host
@@ -161,7 +156,7 @@ def main():
         return n_edges.value, counters
 
     def fence():
-        if world > 1:
+        if distributed:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -177,7 +172,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
+    if distributed:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
@@ -226,7 +221,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(ctx, args, state["table"].cpu().numpy().view(np.uint64))
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if distributed:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -65,3 +65,28 @@ def gather_edges(edges: np.ndarray, *, group=None, dst: Optional[int] = None) ->
         if parts is None:
             return None
     return np.concatenate(parts) if parts else edges
+
+
+def allgather_edge_buffers(edges_u8, count: int, *, group=None):
+    """Device-side merge of the per-rank edge lists: all-gather of the counts, then of the edge
+    buffers cut to the largest count.  ``edges_u8``: this rank's uint8 tensor holding ``count``
+    24-byte ke_edge records at its start.  Returns (host ndarray of all edges as raw bytes viewed
+    per record by the caller, per-rank counts)."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    mine = torch.tensor([int(count)], dtype=torch.int64, device=edges_u8.device)
+    counts_t = torch.empty(world, dtype=torch.int64, device=edges_u8.device)
+    dist.all_gather_into_tensor(counts_t, mine, group=group)
+    counts = counts_t.cpu().tolist()
+    width = max(max(counts), 1) * 24
+    if edges_u8.numel() < width:           # a rank with a short buffer pads up to the common width
+        padded = torch.zeros(width, dtype=torch.uint8, device=edges_u8.device)
+        padded[: edges_u8.numel()] = edges_u8
+        edges_u8 = padded
+    gathered = torch.empty(world * width, dtype=torch.uint8, device=edges_u8.device)
+    dist.all_gather_into_tensor(gathered, edges_u8[:width].contiguous(), group=group)
+    host = gathered.cpu().numpy().reshape(world, width)
+    merged = np.concatenate([host[r, : counts[r] * 24] for r in range(world)])
+    return merged, counts

@@ -180,7 +180,7 @@ _GLOO_WORKER = r"""
 import os, sys
 sys.path.insert(0, sys.argv[1])
 import numpy as np, torch, torch.distributed as dist
-from kobato_eyes_amd.distributed import allgather_hashes, gather_edges, owned_indices, interleave_gathered
+from kobato_eyes_amd.distributed import allgather_hashes, allgather_edge_buffers, gather_edges, owned_indices, interleave_gathered
 from kobato_eyes_amd import _native
 dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % sys.argv[2], rank=int(sys.argv[3]), world_size=2)
 rank, world, n = dist.get_rank(), 2, 1001
@@ -192,6 +192,10 @@ assert np.array_equal(full.numpy(), table), "all-gather did not restore corpus o
 edges = np.zeros(3 + rank, _native.EDGE_DTYPE); edges["a"] = rank; edges["b"] = np.arange(len(edges)) + 10
 merged = gather_edges(edges)
 assert len(merged) == 7 and sorted(merged["a"].tolist()) == [0, 0, 0, 1, 1, 1, 1]
+buf = torch.zeros(24 * 8, dtype=torch.uint8); buf[: edges.nbytes] = torch.from_numpy(edges.view(np.uint8).copy())
+raw, counts = allgather_edge_buffers(buf, len(edges))
+m2 = raw.view(_native.EDGE_DTYPE)
+assert counts == [3, 4] and m2["a"].tolist() == [0, 0, 0, 1, 1, 1, 1] and m2["b"].tolist() == [10, 11, 12, 10, 11, 12, 13]
 parts = [table[owned_indices(n, r, world)] for r in range(world)]
 assert np.array_equal(interleave_gathered(parts, n), table)
 dist.barrier(); dist.destroy_process_group()

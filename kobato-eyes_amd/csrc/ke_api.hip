@@ -84,7 +84,9 @@ const KeAxisCoeffs *ke_get_coeffs(ke_ctx *ctx, int in_size, int out_size) {
     if (it != ctx->coeffs.end()) return it->second;
     auto *c = new KeAxisCoeffs();
     ke_build_axis_coeffs(in_size, out_size, *c);
-    if (upload_i32(ctx, c->bounds, &c->d_bounds) || upload_i32(ctx, c->kk, &c->d_kk) ||
+    if (out_size == 9 || out_size == 8) ke_build_chunked(*c, 3);   // the dHash axes: long windows, 3 chunks each
+    if (upload_i32(ctx, c->cstart, &c->d_cstart) || upload_i32(ctx, c->cpacked, &c->d_cpacked) ||
+        upload_i32(ctx, c->bounds, &c->d_bounds) || upload_i32(ctx, c->kk, &c->d_kk) ||
         upload_i32(ctx, c->start, &c->d_start) || upload_i32(ctx, c->bias, &c->d_bias) ||
         upload_i32(ctx, c->packed, &c->d_packed)) {
         delete c;
@@ -156,7 +158,7 @@ KE_API void ke_destroy(ke_ctx *ctx) {
         if (b.ptr) (void)hipFree(b.ptr);
     for (auto &kv : ctx->coeffs) {
         KeAxisCoeffs *c = kv.second;
-        for (int32_t *p : {c->d_bounds, c->d_kk, c->d_start, c->d_bias, c->d_packed})
+        for (int32_t *p : {c->d_bounds, c->d_kk, c->d_start, c->d_bias, c->d_packed, c->d_cstart, c->d_cpacked})
             if (p) (void)hipFree(p);
         delete c;
     }

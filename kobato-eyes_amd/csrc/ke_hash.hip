@@ -214,16 +214,25 @@ struct KeFusedArgs {
     int hp;         // pitch of one HT column (bytes, multiple of 8)
     uint64_t *phash;
     uint8_t *tile32_out;  // nullable debug output
+    // dHash side (only read by the NDWD > 0 instantiations): 9 output columns x 3 chunks horizontally,
+    // 8 output rows x 3 chunks vertically
+    const int32_t *hd_cpacked, *hd_cstart, *hd_bias;
+    const int32_t *vd_cpacked, *vd_cstart, *vd_bias;
+    int ndwcv;      // chunk dwords of the vertical dHash axis
+    int hpd;        // pitch of one dHash HT column (bytes, multiple of 8)
+    uint64_t *dhash;
+    uint8_t *tile98_out;
 };
 
-template <int W64, int NDWH>
-__global__ __launch_bounds__(256, 3) void ke_phash_fused(const KeFusedArgs a) {
+template <int W64, int NDWH, int NDWD>
+__global__ __launch_bounds__(256, (NDWD > 0 ? 2 : 3)) void ke_phash_fused(const KeFusedArgs a) {
     constexpr int W = 64 * W64;
     constexpr int QPT = W64;                 // 12-byte quads per thread per 16-row tile
     constexpr int QUADS_PER_TILE = kRT * W / 4;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *Lt = smem;
     uint8_t *HT = smem + a.lt_bytes;
+    uint8_t *HTd = HT + 32 * a.hp;          // 9 columns x hpd bytes (dHash instantiations only)
     const int tid = threadIdx.x;
     const int64_t img = blockIdx.x;
     const uint8_t *src = a.pixels + (a.offsets ? a.offsets[img] : (uint64_t)img * a.stride);
@@ -244,6 +253,20 @@ __global__ __launch_bounds__(256, 3) void ke_phash_fused(const KeFusedArgs a) {
     }
     const int hst = a.h_start[o];
     const int hbias = a.h_bias[o];
+    // dHash: lane o < 27 is virtual column (output o/3, chunk o%3) of the 9-wide axis
+    constexpr int ND = NDWD > 0 ? NDWD : 4;
+    int cd[ND][3];
+    int dst = 0, dbias = 0;
+    const bool d_lane = NDWD > 0 && o < 27;
+    if (NDWD > 0) {
+        const int vcol = o < 27 ? o : 26;
+#pragma unroll
+        for (int j = 0; j < ND; ++j)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) cd[j][c] = a.hd_cpacked[((size_t)vcol * ND + j) * 3 + c];
+        dst = a.hd_cstart[vcol];
+        dbias = a.hd_bias[vcol / 3];
+    }
 
     // Software pipeline with the luma tile double-buffered in LDS: while the dot products of tile t
     // run out of Lt[t&1], the 12-byte loads of tile t+1 are in flight; they are converted and
@@ -300,6 +323,31 @@ __global__ __launch_bounds__(256, 3) void ke_phash_fused(const KeFusedArgs a) {
             packed2 |= (uint32_t)(r ^ 0x80) << (8 * rr);  // signed byte again for the vertical dot products
         }
         *reinterpret_cast<uint16_t *>(HT + (size_t)o * a.hp + t * kRT + 2 * rg) = (uint16_t)packed2;
+        if (NDWD > 0) {
+            // ---- K1b for the 9-wide dHash axis: 27 lanes, chunk sums added across 3 adjacent lanes
+            uint32_t dp2 = 0;
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                const uint8_t *lrow = cur + (2 * rg + rr) * W + dst;
+                int d0 = 0, d1 = 0, d2 = 0;
+#pragma unroll
+                for (int p = 0; p < ND / 2; ++p) {
+                    const uint2 v = *reinterpret_cast<const uint2 *>(__builtin_assume_aligned(lrow + 8 * p, 8));
+                    d0 = __builtin_amdgcn_sdot4((int)v.x, cd[2 * p][0], d0, false);
+                    d1 = __builtin_amdgcn_sdot4((int)v.x, cd[2 * p][1], d1, false);
+                    d2 = __builtin_amdgcn_sdot4((int)v.x, cd[2 * p][2], d2, false);
+                    d0 = __builtin_amdgcn_sdot4((int)v.y, cd[2 * p + 1][0], d0, false);
+                    d1 = __builtin_amdgcn_sdot4((int)v.y, cd[2 * p + 1][1], d1, false);
+                    d2 = __builtin_amdgcn_sdot4((int)v.y, cd[2 * p + 1][2], d2, false);
+                }
+                int part = combine_planes(d0, d1, d2, 0);
+                part += __shfl_down(part, 1) + __shfl_down(part, 2);      // chunks sit in lanes 3k, 3k+1, 3k+2
+                const int r = clip8_fixed((int)((uint32_t)part + (uint32_t)dbias));
+                dp2 |= (uint32_t)(r ^ 0x80) << (8 * rr);
+            }
+            if (d_lane && o % 3 == 0)
+                *reinterpret_cast<uint16_t *>(HTd + (size_t)(o / 3) * a.hpd + t * kRT + 2 * rg) = (uint16_t)dp2;
+        }
         // ---- K1a for the next tile: luma of the loads issued above -> the other LDS buffer
         __builtin_amdgcn_sched_barrier(0);   // ...and keep their first use down here, behind the dot products
         store_luma(Lt + ((t + 1) & 1) * a.lt_half);
@@ -345,6 +393,44 @@ __global__ __launch_bounds__(256, 3) void ke_phash_fused(const KeFusedArgs a) {
     // ---- K2: DCT corner, mean, bits
     const uint64_t hv = tile32_to_phash(T32, Td, cf, tid);
     if (tid == 0 && a.phash) a.phash[a.out_idx ? a.out_idx[img] : img] = hv;
+    if (NDWD > 0) {
+        // ---- K1' + K3 for dHash: 8 rows x 9 columns, each output = 3 chunk sums (threads 0..215)
+        __syncthreads();
+        int *part = reinterpret_cast<int *>(Lt);                 // 216 ints
+        uint8_t *T98 = Lt + 1024;                                // 72 bytes
+        if (tid < 216) {
+            const int out = tid / 3, chunk = tid % 3;
+            const int yy = out / 9, oc = out % 9;
+            const int vc = yy * 3 + chunk;
+            const int vst = a.vd_cstart[vc];
+            const int nd = a.ndwcv;
+            int d0 = 0, d1 = 0, d2 = 0;
+            for (int j = 0; j < nd; j += 2) {
+                const int32_t *cp = a.vd_cpacked + ((size_t)vc * nd + j) * 3;
+                const uint2 v = *reinterpret_cast<const uint2 *>(__builtin_assume_aligned(HTd + (size_t)oc * a.hpd + vst + 4 * j, 8));
+                d0 = __builtin_amdgcn_sdot4((int)v.x, cp[0], d0, false);
+                d1 = __builtin_amdgcn_sdot4((int)v.x, cp[1], d1, false);
+                d2 = __builtin_amdgcn_sdot4((int)v.x, cp[2], d2, false);
+                d0 = __builtin_amdgcn_sdot4((int)v.y, cp[3], d0, false);
+                d1 = __builtin_amdgcn_sdot4((int)v.y, cp[4], d1, false);
+                d2 = __builtin_amdgcn_sdot4((int)v.y, cp[5], d2, false);
+            }
+            part[tid] = combine_planes(d0, d1, d2, 0);
+        }
+        __syncthreads();
+        if (tid < 72) {
+            const int yy = tid / 9;
+            const uint32_t sum = (uint32_t)part[3 * tid] + (uint32_t)part[3 * tid + 1] + (uint32_t)part[3 * tid + 2] + (uint32_t)a.vd_bias[yy];
+            T98[tid] = (uint8_t)clip8_fixed((int)sum);
+        }
+        __syncthreads();
+        if (a.tile98_out && tid < 72) a.tile98_out[(size_t)img * 72 + tid] = T98[tid];
+        if (tid < 64) {
+            const int r = tid >> 3, c = tid & 7;
+            const unsigned long long m = __ballot(T98[r * 9 + c + 1] > T98[r * 9 + c]);   // src/sig/phash.py:52
+            if (tid == 0 && a.dhash) a.dhash[a.out_idx ? a.out_idx[img] : img] = __brevll(m);
+        }
+    }
 }
 
 bool g_tables_ready = false;
@@ -358,25 +444,38 @@ int upload_dct_tables(ke_ctx *ctx) {
     return KE_OK;
 }
 
-template <int W64, int NDWH>
+template <int W64, int NDWH, int NDWD>
 int launch_fused(ke_ctx *ctx, const KeHashGroup &g, const KeAxisCoeffs *ch, const KeAxisCoeffs *cv, uint64_t *d_phash,
-                 uint8_t *d_tile32) {
+                 uint8_t *d_tile32, uint64_t *d_dhash, uint8_t *d_tile98) {
     constexpr int W = 64 * W64;
     KeFusedArgs a;
+    std::memset(&a, 0, sizeof a);
     a.pixels = g.pixels; a.offsets = g.offsets; a.stride = g.stride; a.out_idx = g.out_idx; a.h = g.h;
     a.h_packed = ch->d_packed; a.h_start = ch->d_start; a.h_bias = ch->d_bias;
     a.v_packed = cv->d_packed; a.v_start = cv->d_start; a.v_bias = cv->d_bias;
     a.ndwv = cv->ndw;
-    int lt = kRT * W + std::max(0, ch->span - W) + 16;
+    int hspan = ch->span;
+    const int rows_padded = ((g.h + kRT - 1) / kRT) * kRT;
+    a.hpd = 8;
+    if (NDWD > 0) {
+        const KeAxisCoeffs *chd = ke_get_coeffs(ctx, g.w, 9), *cvd = ke_get_coeffs(ctx, g.h, 8);
+        if (!chd || !cvd) return ke_fail(ctx, KE_EHIP, "coefficient upload failed");
+        if (chd->ndwc != NDWD || chd->cpo != 3 || cvd->cpo != 3) return KE_EUNSUPPORTED;
+        a.hd_cpacked = chd->d_cpacked; a.hd_cstart = chd->d_cstart; a.hd_bias = chd->d_bias;
+        a.vd_cpacked = cvd->d_cpacked; a.vd_cstart = cvd->d_cstart; a.vd_bias = cvd->d_bias;
+        a.ndwcv = cvd->ndwc;
+        hspan = std::max(hspan, chd->cspan);
+        a.hpd = ((std::max(cvd->cspan, rows_padded) + 7) & ~7) + 8;
+    }
+    int lt = kRT * W + std::max(0, hspan - W) + 16;
     if (lt < 1792) lt = 1792;
     a.lt_half = (lt + 15) & ~15;
     a.lt_bytes = 2 * a.lt_half;
-    const int rows_padded = ((g.h + kRT - 1) / kRT) * kRT;
     a.hp = ((std::max(cv->span, rows_padded) + 7) & ~7) + 8;
-    a.phash = d_phash; a.tile32_out = d_tile32;
-    const size_t lds = (size_t)a.lt_bytes + (size_t)32 * a.hp;
+    a.phash = d_phash; a.tile32_out = d_tile32; a.dhash = d_dhash; a.tile98_out = d_tile98;
+    const size_t lds = (size_t)a.lt_bytes + (size_t)32 * a.hp + (NDWD > 0 ? (size_t)9 * a.hpd : 0);
     if (lds > 64 * 1024) return KE_EUNSUPPORTED;
-    hipLaunchKernelGGL((ke_phash_fused<W64, NDWH>), dim3((unsigned)g.n), dim3(256), lds, ctx->stream, a);
+    hipLaunchKernelGGL((ke_phash_fused<W64, NDWH, NDWD>), dim3((unsigned)g.n), dim3(256), lds, ctx->stream, a);
     KE_HIP(ctx, hipGetLastError());
     return KE_OK;
 }
@@ -417,7 +516,7 @@ int ke_launch_hash_group(ke_ctx *ctx, const KeHashGroup &g, uint64_t *d_phash, u
                          uint8_t *d_tile98_out) {
     KE_TRY(upload_dct_tables(ctx));
     const bool want_p = d_phash || d_tile32_out, want_d = d_dhash || d_tile98_out;
-    bool p_done = false;
+    bool p_done = false, d_done = false;
     // ---- fused fast path: packed RGB, 4-byte aligned rows, width 256/384/512, both axes resampled
     if (want_p && g.channels == 3 && g.w % 64 == 0 && g.h != 32 && g.h >= 16 && g.h <= 1536 &&
         !((int64_t)g.h > (int64_t)g.w * 100) && ((uintptr_t)g.pixels % 4 == 0) && (g.offsets || g.stride % 4 == 0)) {
@@ -426,14 +525,23 @@ int ke_launch_hash_group(ke_ctx *ctx, const KeHashGroup &g, uint64_t *d_phash, u
         if (!ch || !cv) return ke_fail(ctx, KE_EHIP, "coefficient upload failed");
         int rc = KE_EUNSUPPORTED;
         // offsets (ragged groups) are only 4-byte aligned when every image size is; w % 64 == 0 makes it so
-        if (g.w == 256 && ch->ndw == 16) rc = launch_fused<4, 16>(ctx, g, ch, cv, d_phash, d_tile32_out);
-        else if (g.w == 384 && ch->ndw == 20) rc = launch_fused<6, 20>(ctx, g, ch, cv, d_phash, d_tile32_out);
-        else if (g.w == 512 && ch->ndw == 24) rc = launch_fused<8, 24>(ctx, g, ch, cv, d_phash, d_tile32_out);
-        if (rc == KE_OK) p_done = true;
-        else if (rc != KE_EUNSUPPORTED) return rc;
+        if (want_d && g.h != 8) {   // pHash + dHash in one pass over the pixels
+            if (g.w == 256 && ch->ndw == 16) rc = launch_fused<4, 16, 16>(ctx, g, ch, cv, d_phash, d_tile32_out, d_dhash, d_tile98_out);
+            else if (g.w == 384 && ch->ndw == 20) rc = launch_fused<6, 20, 24>(ctx, g, ch, cv, d_phash, d_tile32_out, d_dhash, d_tile98_out);
+            else if (g.w == 512 && ch->ndw == 24) rc = launch_fused<8, 24, 32>(ctx, g, ch, cv, d_phash, d_tile32_out, d_dhash, d_tile98_out);
+            if (rc == KE_OK) p_done = d_done = true;
+            else if (rc != KE_EUNSUPPORTED) return rc;
+        }
+        if (!p_done) {
+            if (g.w == 256 && ch->ndw == 16) rc = launch_fused<4, 16, 0>(ctx, g, ch, cv, d_phash, d_tile32_out, nullptr, nullptr);
+            else if (g.w == 384 && ch->ndw == 20) rc = launch_fused<6, 20, 0>(ctx, g, ch, cv, d_phash, d_tile32_out, nullptr, nullptr);
+            else if (g.w == 512 && ch->ndw == 24) rc = launch_fused<8, 24, 0>(ctx, g, ch, cv, d_phash, d_tile32_out, nullptr, nullptr);
+            if (rc == KE_OK) p_done = true;
+            else if (rc != KE_EUNSUPPORTED) return rc;
+        }
     }
     // ---- generic path, chunked so the first-pass scratch stays bounded
-    if ((want_p && !p_done) || want_d) {
+    if ((want_p && !p_done) || (want_d && !d_done)) {
         const size_t per_img = (size_t)std::max(g.w, 32) * std::max(g.h, 32);
         const int64_t chunk = std::max<int64_t>(1, (int64_t)(((size_t)512 << 20) / per_img));
         for (int64_t f = 0; f < g.n; f += chunk) {
@@ -452,13 +560,13 @@ int ke_launch_hash_group(ke_ctx *ctx, const KeHashGroup &g, uint64_t *d_phash, u
                 else KE_TRY(ke_reserve(ctx, KE_BUF_TILE32, (size_t)s.n * 1024, &t32));
                 KE_TRY(resample_generic(ctx, s, 32, 32, (uint8_t *)t32));
             }
-            if (want_d) {
+            if (want_d && !d_done) {
                 if (d_tile98_out) t98 = d_tile98_out + (size_t)f * 72;
                 else KE_TRY(ke_reserve(ctx, KE_BUF_TILE98, (size_t)s.n * 72, &t98));
                 KE_TRY(resample_generic(ctx, s, 9, 8, (uint8_t *)t98));
             }
             uint64_t *ph = (d_phash && !p_done) ? d_phash + slot0 : nullptr;
-            uint64_t *dh = d_dhash ? d_dhash + slot0 : nullptr;
+            uint64_t *dh = (d_dhash && !d_done) ? d_dhash + slot0 : nullptr;
             if (ph || dh) {
                 hipLaunchKernelGGL(ke_tiles_to_hashes, dim3((unsigned)s.n), dim3(256), 0, ctx->stream, (const uint8_t *)t32,
                                    (const uint8_t *)t98, s.out_idx, ph, dh);

@@ -35,9 +35,16 @@ struct KeAxisCoeffs {
     std::vector<int32_t> packed;  // out*ndw*3
     // device copies
     int32_t *d_bounds = nullptr, *d_kk = nullptr, *d_start = nullptr, *d_bias = nullptr, *d_packed = nullptr;
+    // chunked byte-plane layout (long windows, e.g. the 9-wide dHash axis): every output's window is cut
+    // into `cpo` chunks of `ndwc` dwords; virtual column v = o*cpo + c starts at cstart[v] and owns
+    // cpacked[v][ndwc][3]; the chunks' plane sums are added before bias[o] and the clip.
+    int cpo = 0, ndwc = 0, cspan = 0;
+    std::vector<int32_t> cstart, cpacked;
+    int32_t *d_cstart = nullptr, *d_cpacked = nullptr;
 };
 
 void ke_build_axis_coeffs(int in_size, int out_size, KeAxisCoeffs &out);
+void ke_build_chunked(KeAxisCoeffs &c, int cpo);
 
 struct KeDevBuf {
     void *ptr = nullptr;

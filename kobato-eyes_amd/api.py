@@ -12,7 +12,11 @@ from dataclasses import dataclass
 from pathlib import Path
 from typing import Callable, Iterable, Mapping, Optional, Sequence
 
-from . import fastsig, phash as _phash, refine as _refine
+import importlib
+
+from . import fastsig, refine as _refine
+
+_phash = importlib.import_module(".phash", __package__)   # the package also exports a function named phash
 from .cluster import ClusterBuilder
 from .scanner import DuplicateCluster, DuplicateFile, DuplicateScanConfig, DuplicateScanner
 

@@ -16,7 +16,9 @@ from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
 from typing import Callable, Iterable, List, Optional, Tuple
 
-from . import phash as _phash
+import importlib
+
+_phash = importlib.import_module(".phash", __package__)   # the package also exports a function named phash
 
 U64MASK = (1 << 64) - 1
 _PROGRESS_EVERY = 200

@@ -6,7 +6,9 @@ import logging
 from pathlib import Path
 from typing import Optional
 
-from . import phash as _phash
+import importlib
+
+_phash = importlib.import_module(".phash", __package__)   # the package also exports a function named phash
 from .fastsig import _to_signed64
 from .image_io import load_rgb
 

@@ -1,0 +1,137 @@
+"""GPU tests of the reference-shaped seams with real files and a real SQLite table:
+fast_fill_missing_signatures (src/core/fastsig.py:102-126), ensure_signatures
+(src/core/signature.py:31-62), refine_pair / ClusterBuilder (src/dup/refine.py:71-117,
+src/dup/cluster.py:22-70), find_duplicates / run_duplicate_scan (call sequence of
+src/ui/dup_workers.py:148-239).  They read like the reference's own tests
+(tests/core/test_fastsig.py, tests/core/test_image_signature.py, tests/dup/test_refine.py)."""
+from __future__ import annotations
+
+import sqlite3
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+Image = pytest.importorskip("PIL.Image")
+
+
+@pytest.fixture(scope="module")
+def K():
+    import kobato_eyes_amd
+
+    kobato_eyes_amd._native.get_context(0)
+    return kobato_eyes_amd
+
+
+def _make_conn(path=":memory:"):
+    conn = sqlite3.connect(path)
+    conn.row_factory = sqlite3.Row
+    conn.execute("CREATE TABLE IF NOT EXISTS signatures (file_id INTEGER PRIMARY KEY, phash_u64 INTEGER NOT NULL, dhash_u64 INTEGER NOT NULL)")
+    return conn
+
+
+def _corpus(tmp_path: Path, n=12, side=96):
+    """PNG files (lossless, so the decoded pixels are known): synthetic corpus images 10..10+n."""
+    items, arrays = [], {}
+    for k in range(n):
+        arr = O.synth_rgb(10 + k, side + 8 * (k % 3), side)
+        p = tmp_path / f"img_{k:03d}.png"
+        Image.fromarray(arr).save(p)
+        items.append((k + 1, str(p)))
+        arrays[k + 1] = arr
+    return items, arrays
+
+
+def test_fast_fill_missing_signatures_end_to_end(K, tmp_path):
+    items, arrays = _corpus(tmp_path)
+    items.insert(3, (77, str(tmp_path / "does_not_exist.png")))
+    (tmp_path / "broken.png").write_bytes(b"not an image")
+    items.insert(5, (78, str(tmp_path / "broken.png")))
+    db = tmp_path / "sig.db"
+    _make_conn(db).close()
+    seen = []
+    out = K.fast_fill_missing_signatures(str(db), items, max_workers=4, chunksize=5, progress=lambda d, t: seen.append((d, t)))
+    assert [fid for fid, _, _ in out] == [fid for fid, _ in items if fid < 70]      # input order, failures dropped
+    assert seen[-1] == (len(items), len(items))
+    for fid, ph, dh in out:
+        ep, ed = O.hash_image(arrays[fid])
+        assert (ph, dh) == (O.to_signed64(ep), O.to_signed64(ed))
+        assert -(1 << 63) <= ph < (1 << 63)
+    rows = _make_conn(db).execute("SELECT file_id, phash_u64, dhash_u64 FROM signatures ORDER BY file_id").fetchall()
+    assert [tuple(r) for r in rows] == sorted(out)
+    # signed store -> unsigned round trip through the scanner's row parser (tests/core/test_image_signature.py:48-55)
+    f = K.DuplicateFile.from_row({"file_id": rows[0]["file_id"], "path": "x.png", "phash_u64": rows[0]["phash_u64"]})
+    assert f.phash == rows[0]["phash_u64"] & ((1 << 64) - 1)
+
+
+def test_ensure_signatures(K):
+    conn = _make_conn()
+    for file_id in range(1, 21):
+        rng = np.random.default_rng(file_id)
+        img = Image.fromarray((rng.random((64, 64, 3)) * 255).astype("uint8"))   # tests/core/test_image_signature.py:24-27
+        assert K.ensure_signatures(conn, file_id, image=img) is True
+        p, d = K.compute_signatures_from_image(img)
+        row = conn.execute("SELECT phash_u64, dhash_u64 FROM signatures WHERE file_id=?", (file_id,)).fetchone()
+        assert (row["phash_u64"], row["dhash_u64"]) == (p, d)
+        ep, ed = O.hash_image(np.asarray(img))
+        assert (p, d) == (O.to_signed64(ep), O.to_signed64(ed))
+    assert conn.execute("SELECT COUNT(*) FROM signatures").fetchone()[0] == 20
+    assert K.ensure_signatures(conn, 1) is True                      # row exists -> kept
+    assert K.ensure_signatures(conn, 99) is False                    # nothing to compute from
+    assert K.ensure_signatures(conn, 99, path="/nonexistent/file.png") is False
+
+
+def test_refine_pair_like_the_reference_tests(K, tmp_path):
+    from PIL import ImageEnhance
+
+    a, b = tmp_path / "a.png", tmp_path / "b.png"
+    Image.new("RGB", (64, 64), color=(200, 10, 10)).save(a)
+    ImageEnhance.Brightness(Image.open(a).convert("RGB")).enhance(1.02).save(b)
+    r = K.refine_pair(1, 2, a, b)                                   # tests/dup/test_refine.py:24-34
+    assert isinstance(r, K.RefinedMatch) and r.is_duplicate and r.ssim > 0.95 and r.reason == "ssim>=0.9"
+    assert abs(r.ssim - O.ssim_luma(np.asarray(Image.open(a).convert("L")), np.asarray(Image.open(b).convert("L")))) <= 1e-6
+    g, bl = tmp_path / "g.png", tmp_path / "bl.png"
+    Image.new("RGB", (64, 64), (0, 255, 0)).save(g)
+    Image.new("RGB", (64, 64), (0, 0, 255)).save(bl)
+    r = K.refine_pair(1, 3, g, bl, thresholds=K.RefinementThresholds(ssim=0.95, orb=0.5))   # :37-46
+    assert not r.is_duplicate and r.reason == "below thresholds" and r.orb_ratio is None
+    (tmp_path / "broken.png").write_bytes(b"not an image")
+    assert K.refine_pair(1, 2, a, tmp_path / "broken.png") is None   # :49-55
+    tiny = tmp_path / "tiny.png"
+    Image.new("RGB", (5, 5)).save(tiny)
+    r = K.refine_pair(1, 2, tiny, tiny)                              # SSIM raises for < 7 px -> "ssim unavailable"
+    assert r.ssim is None and not r.is_duplicate and r.reason == "ssim unavailable"
+
+
+def test_find_duplicates_and_headless_scan(K, tmp_path):
+    # corpus with planted variants: images 19, 29, 39 are variants of earlier bases
+    idx = sorted({19, 29, 39, O.synth_info(19)[0], O.synth_info(29)[0], O.synth_info(39)[0], 0, 1, 2, 3})
+    rows, arrays = [], {}
+    for i in idx:
+        arr = O.synth_rgb(i, 256, 256)
+        p = tmp_path / f"c_{i:03d}.png"
+        Image.fromarray(arr).save(p)
+        rows.append({"file_id": i + 1, "path": str(p), "size": p.stat().st_size, "width": 256, "height": 256, "phash_u64": None})
+        arrays[i + 1] = arr
+    stages = []
+    clusters = K.run_duplicate_scan(rows, config=K.DuplicateScanConfig(hamming_threshold=8),
+                                    progress=lambda s, d, t: stages.append(s))
+    assert [s for s in dict.fromkeys(stages)] == ["Loading files", "Computing signatures", "Building groups", "Clustering duplicates"]
+    # expected clusters from the oracle end to end
+    hashes = np.array([O.hash_image(arrays[r["file_id"]])[0] for r in rows], np.uint64)
+    ids = np.array([r["file_id"] for r in rows], np.int64)
+    e, _ = O.scan_banded(hashes, ids, threshold=8)
+    exp = O.assemble_clusters([dict(r) for r in rows], [(int(ids[x["a"]]), int(ids[x["b"]]), int(x["h"])) for x in e])
+    got = [(c.keeper_id, [(en.file.file_id, en.best_hamming) for en in c.files]) for c in clusters]
+    assert got == exp and len(got) >= 2
+    # find_duplicates alias on rows that already carry hashes, with and without the SSIM re-check
+    for r, hv in zip(rows, hashes.tolist()):
+        r["phash_u64"] = O.to_signed64(hv)
+    plain = K.find_duplicates(rows + [{"file_id": 999, "path": "bad.png"}], hamming_threshold=8)
+    assert [(c.keeper_id, [(en.file.file_id, en.best_hamming) for en in c.files]) for c in plain] == exp
+    strict = K.find_duplicates(rows, hamming_threshold=8, ssim_threshold=0.999)
+    loose = K.find_duplicates(rows, hamming_threshold=8, ssim_threshold=0.5)
+    assert strict == [] and len(loose) == len(plain)

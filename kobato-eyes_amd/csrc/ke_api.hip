@@ -84,9 +84,7 @@ const KeAxisCoeffs *ke_get_coeffs(ke_ctx *ctx, int in_size, int out_size) {
     if (it != ctx->coeffs.end()) return it->second;
     auto *c = new KeAxisCoeffs();
     ke_build_axis_coeffs(in_size, out_size, *c);
-    if (out_size == 9 || out_size == 8) ke_build_chunked(*c, 3);   // the dHash axes: long windows, 3 chunks each
-    if (upload_i32(ctx, c->cstart, &c->d_cstart) || upload_i32(ctx, c->cpacked, &c->d_cpacked) ||
-        upload_i32(ctx, c->bounds, &c->d_bounds) || upload_i32(ctx, c->kk, &c->d_kk) ||
+    if (upload_i32(ctx, c->bounds, &c->d_bounds) || upload_i32(ctx, c->kk, &c->d_kk) ||
         upload_i32(ctx, c->start, &c->d_start) || upload_i32(ctx, c->bias, &c->d_bias) ||
         upload_i32(ctx, c->packed, &c->d_packed)) {
         delete c;
@@ -94,6 +92,20 @@ const KeAxisCoeffs *ke_get_coeffs(ke_ctx *ctx, int in_size, int out_size) {
     }
     ctx->coeffs[key] = c;
     return c;
+}
+
+const KeChunkTable *ke_get_chunks(ke_ctx *ctx, const KeAxisCoeffs *cc, int cpo) {
+    auto *c = const_cast<KeAxisCoeffs *>(cc);
+    auto it = c->chunked.find(cpo);
+    if (it != c->chunked.end()) return it->second;
+    auto *t = new KeChunkTable();
+    ke_build_chunked(*c, cpo, *t);
+    if (upload_i32(ctx, t->cstart, &t->d_cstart) || upload_i32(ctx, t->cpacked, &t->d_cpacked)) {
+        delete t;
+        return nullptr;
+    }
+    c->chunked[cpo] = t;
+    return t;
 }
 
 void ke_time_begin(ke_ctx *ctx, int kind) {
@@ -158,8 +170,13 @@ KE_API void ke_destroy(ke_ctx *ctx) {
         if (b.ptr) (void)hipFree(b.ptr);
     for (auto &kv : ctx->coeffs) {
         KeAxisCoeffs *c = kv.second;
-        for (int32_t *p : {c->d_bounds, c->d_kk, c->d_start, c->d_bias, c->d_packed, c->d_cstart, c->d_cpacked})
+        for (int32_t *p : {c->d_bounds, c->d_kk, c->d_start, c->d_bias, c->d_packed})
             if (p) (void)hipFree(p);
+        for (auto &ck : c->chunked) {
+            if (ck.second->d_cstart) (void)hipFree(ck.second->d_cstart);
+            if (ck.second->d_cpacked) (void)hipFree(ck.second->d_cpacked);
+            delete ck.second;
+        }
         delete c;
     }
     for (int k = 0; k < KE_T_COUNT; ++k) {

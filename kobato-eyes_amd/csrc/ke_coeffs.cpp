@@ -108,24 +108,24 @@ void ke_build_axis_coeffs(int in_size, int out_size, KeAxisCoeffs &c) {
     }
 }
 
-// Cut every output's packed window into `cpo` equal chunks (see KeAxisCoeffs).
-void ke_build_chunked(KeAxisCoeffs &c, int cpo) {
-    c.cpo = cpo;
-    c.ndwc = (((c.ndw + cpo - 1) / cpo) + 3) & ~3;
+// Cut every output's packed window into `cpo` equal chunks (see KeChunkTable).
+void ke_build_chunked(const KeAxisCoeffs &c, int cpo, KeChunkTable &t) {
+    t.cpo = cpo;
+    t.ndwc = (((c.ndw + cpo - 1) / cpo) + 3) & ~3;
     const int nv = c.out_size * cpo;
-    c.cstart.assign((size_t)nv, 0);
-    c.cpacked.assign((size_t)nv * c.ndwc * 3, 0);
-    c.cspan = 0;
+    t.cstart.assign((size_t)nv, 0);
+    t.cpacked.assign((size_t)nv * t.ndwc * 3, 0);
+    t.cspan = 0;
     for (int o = 0; o < c.out_size; ++o)
         for (int k = 0; k < cpo; ++k) {
             const int v = o * cpo + k;
-            c.cstart[v] = c.start[o] + 4 * c.ndwc * k;
-            if (c.cstart[v] + 4 * c.ndwc > c.cspan) c.cspan = c.cstart[v] + 4 * c.ndwc;
-            for (int j = 0; j < c.ndwc; ++j) {
-                const int src = k * c.ndwc + j;
+            t.cstart[v] = c.start[o] + 4 * t.ndwc * k;
+            if (t.cstart[v] + 4 * t.ndwc > t.cspan) t.cspan = t.cstart[v] + 4 * t.ndwc;
+            for (int j = 0; j < t.ndwc; ++j) {
+                const int src = k * t.ndwc + j;
                 if (src >= c.ndw) continue;
                 for (int p = 0; p < 3; ++p)
-                    c.cpacked[((size_t)v * c.ndwc + j) * 3 + p] = c.packed[((size_t)o * c.ndw + src) * 3 + p];
+                    t.cpacked[((size_t)v * t.ndwc + j) * 3 + p] = c.packed[((size_t)o * c.ndw + src) * 3 + p];
             }
         }
 }

@@ -460,12 +460,14 @@ int launch_fused(ke_ctx *ctx, const KeHashGroup &g, const KeAxisCoeffs *ch, cons
     if (NDWD > 0) {
         const KeAxisCoeffs *chd = ke_get_coeffs(ctx, g.w, 9), *cvd = ke_get_coeffs(ctx, g.h, 8);
         if (!chd || !cvd) return ke_fail(ctx, KE_EHIP, "coefficient upload failed");
-        if (chd->ndwc != NDWD || chd->cpo != 3 || cvd->cpo != 3) return KE_EUNSUPPORTED;
-        a.hd_cpacked = chd->d_cpacked; a.hd_cstart = chd->d_cstart; a.hd_bias = chd->d_bias;
-        a.vd_cpacked = cvd->d_cpacked; a.vd_cstart = cvd->d_cstart; a.vd_bias = cvd->d_bias;
-        a.ndwcv = cvd->ndwc;
-        hspan = std::max(hspan, chd->cspan);
-        a.hpd = ((std::max(cvd->cspan, rows_padded) + 7) & ~7) + 8;
+        const KeChunkTable *th = ke_get_chunks(ctx, chd, 3), *tv = ke_get_chunks(ctx, cvd, 3);
+        if (!th || !tv) return ke_fail(ctx, KE_EHIP, "coefficient upload failed");
+        if (th->ndwc != NDWD) return KE_EUNSUPPORTED;
+        a.hd_cpacked = th->d_cpacked; a.hd_cstart = th->d_cstart; a.hd_bias = chd->d_bias;
+        a.vd_cpacked = tv->d_cpacked; a.vd_cstart = tv->d_cstart; a.vd_bias = cvd->d_bias;
+        a.ndwcv = tv->ndwc;
+        hspan = std::max(hspan, th->cspan);
+        a.hpd = ((std::max(tv->cspan, rows_padded) + 7) & ~7) + 8;
     }
     int lt = kRT * W + std::max(0, hspan - W) + 16;
     if (lt < 1792) lt = 1792;
@@ -476,6 +478,286 @@ int launch_fused(ke_ctx *ctx, const KeHashGroup &g, const KeAxisCoeffs *ch, cons
     const size_t lds = (size_t)a.lt_bytes + (size_t)32 * a.hp + (NDWD > 0 ? (size_t)9 * a.hpd : 0);
     if (lds > 64 * 1024) return KE_EUNSUPPORTED;
     hipLaunchKernelGGL((ke_phash_fused<W64, NDWH, NDWD>), dim3((unsigned)g.n), dim3(256), lds, ctx->stream, a);
+    KE_HIP(ctx, hipGetLastError());
+    return KE_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// Banded path: any width/height.  ke_hband streams a band of rows of one image (luma + the
+// horizontal taps of `nout` output columns, windows cut into cpo = 2^k chunks that sit in
+// adjacent lanes and are summed with xor shuffles) and writes the clipped bytes, transposed and
+// re-biased to signed, into a small global scratch hs[img][column][row]; ke_vtile then runs the
+// vertical taps out of LDS and writes the (oh x ow) tile.  Scratch traffic is nout*H bytes per
+// image each way (4 % of the pixel bytes at 512 px, 0.3 % at 4096 px).
+// ---------------------------------------------------------------------------------------
+struct KeBandArgs {
+    const uint8_t *pixels;
+    const uint64_t *offsets;
+    uint64_t stride;
+    int w, h;
+    int qr;            // 4-pixel quads per row = ceil(w / 4)
+    int lp;            // LDS pitch of one luma row (bytes, multiple of 8)
+    int rt;            // rows per tile (rt * qr <= 2048)
+    int band_rows;     // rows per workgroup (multiple of rt)
+    int bands;         // workgroups per image
+    int nout;          // output columns (32 or 9)
+    int cpo_log2;      // log2(chunks per output)
+    int vcp_log2;      // log2(lanes per row group) >= log2(nout << cpo_log2)
+    const int32_t *cpacked, *cstart, *bias;
+    int lt_half;       // bytes of one LDS luma tile buffer
+    uint8_t *hs;       // [img][nout][hp]
+    int hp;
+};
+
+// Four consecutive pixels of one row -> four signed luma bytes.  d: the 4*C source bytes.
+template <int C>
+__device__ __forceinline__ uint32_t luma4_generic(const uint32_t *d) {
+    if (C == 3) return luma4_biased(d[0], d[1], d[2]);
+    if (C == 1) return d[0] ^ 0x80808080u;
+    constexpr uint32_t CHI = 0x001D964Cu, CLO = 0x002F468Bu, START = 0x8000u - 0x800000u;
+    uint32_t s[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)   // RGBX: byte 3 meets a zero weight, as Pillow's rgb2l ignores it
+        s[k] = (__builtin_amdgcn_udot4(d[k], CHI, 0u, false) << 8) + __builtin_amdgcn_udot4(d[k], CLO, START, false);
+    return ((s[0] >> 16) & 0xFFu) | ((s[1] >> 8) & 0xFF00u) | (s[2] & 0xFF0000u) | ((s[3] << 8) & 0xFF000000u);
+}
+
+template <int NDWC, int C, bool ALIGNED>
+__global__ __launch_bounds__(256, 3) void ke_hband(const KeBandArgs a) {
+    constexpr int QPT = 8;
+    constexpr int DW = C;   // dwords per quad: 4 pixels * C bytes
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x;
+    const int64_t img = blockIdx.x / a.bands;
+    const int band = blockIdx.x % a.bands;
+    const uint8_t *src = a.pixels + (a.offsets ? a.offsets[img] : (uint64_t)img * a.stride);
+    const int y_begin = band * a.band_rows;
+    const int y_end = min(a.h, y_begin + a.band_rows);
+    const int64_t total_pix = (int64_t)a.w * a.h;
+    const uintptr_t last_dword = ((uintptr_t)src + (uintptr_t)total_pix * C - 1) & ~(uintptr_t)3;
+
+    // lane -> (virtual column, row group)
+    const int vcl = tid & ((1 << a.vcp_log2) - 1);
+    const int rg = tid >> a.vcp_log2, RG = 256 >> a.vcp_log2;
+    const int nvc = a.nout << a.cpo_log2;
+    const int vc = vcl < nvc ? vcl : nvc - 1;
+    const int o = vc >> a.cpo_log2;
+    const bool writer = vcl < nvc && (vc & ((1 << a.cpo_log2) - 1)) == 0;
+    int ck[NDWC][3];
+#pragma unroll
+    for (int j = 0; j < NDWC; ++j)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) ck[j][c] = a.cpacked[((size_t)vc * NDWC + j) * 3 + c];
+    const int cst = a.cstart[vc];
+    const int obias = a.bias[o];
+
+    // quad items of a tile: item = q*256 + tid -> (row r, quad j); advanced incrementally
+    const int r0 = tid / a.qr, j0 = tid % a.qr;
+    const int dr = 256 / a.qr, dj = 256 % a.qr;
+    const int items = a.rt * a.qr;
+
+    uint32_t raw[QPT][DW];
+    auto load_tile = [&](int ty0) {
+        int r = r0, j = j0;
+#pragma unroll
+        for (int q = 0; q < QPT; ++q) {
+            int row = ty0 + r;
+            row = row < a.h ? row : a.h - 1;
+            int64_t pix = (int64_t)row * a.w + 4 * j;
+            if (ALIGNED) {
+                pix = pix < total_pix - 4 ? pix : total_pix - 4;   // w % 4 == 0: the last quad ends with the image
+                const uint32_t *p = reinterpret_cast<const uint32_t *>(src + pix * C);
+#pragma unroll
+                for (int k = 0; k < DW; ++k) raw[q][k] = p[k];
+            } else {
+                pix = pix < total_pix - 1 ? pix : total_pix - 1;
+                const uintptr_t ad = (uintptr_t)src + (uintptr_t)pix * C;
+                const uintptr_t al = ad & ~(uintptr_t)3;
+                const int sb = (int)(ad & 3);
+                uint32_t wv[DW + 1];
+#pragma unroll
+                for (int k = 0; k <= DW; ++k) {   // every dword load is clamped to the last dword of the image
+                    const uintptr_t x = al + 4 * k;
+                    wv[k] = *reinterpret_cast<const uint32_t *>(x < last_dword ? x : last_dword);
+                }
+#pragma unroll
+                for (int k = 0; k < DW; ++k) raw[q][k] = __builtin_amdgcn_alignbyte(wv[k + 1], wv[k], sb);
+            }
+            r += dr; j += dj;
+            if (j >= a.qr) { j -= a.qr; ++r; }
+        }
+    };
+    auto store_luma = [&](uint8_t *dst) {
+        int r = r0, j = j0;
+#pragma unroll
+        for (int q = 0; q < QPT; ++q) {
+            if (q * 256 + tid < items) *reinterpret_cast<uint32_t *>(dst + r * a.lp + 4 * j) = luma4_generic<C>(raw[q]);
+            r += dr; j += dj;
+            if (j >= a.qr) { j -= a.qr; ++r; }
+        }
+    };
+
+    const int ntiles = (y_end - y_begin + a.rt - 1) / a.rt;
+    uint8_t *hs_col = a.hs + ((size_t)img * a.nout + o) * a.hp;
+    load_tile(y_begin);
+    store_luma(smem);
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        const uint8_t *cur = smem + (t & 1) * a.lt_half;
+        const int ty0 = y_begin + t * a.rt;
+        load_tile(t + 1 < ntiles ? ty0 + a.rt : ty0);
+        __builtin_amdgcn_sched_barrier(0);
+        for (int r = rg; r < a.rt; r += RG) {
+            const uint8_t *lrow = cur + r * a.lp + cst;
+            int d0 = 0, d1 = 0, d2 = 0;
+#pragma unroll
+            for (int p = 0; p < NDWC / 2; ++p) {
+                const uint2 v = *reinterpret_cast<const uint2 *>(__builtin_assume_aligned(lrow + 8 * p, 8));
+                d0 = __builtin_amdgcn_sdot4((int)v.x, ck[2 * p][0], d0, false);
+                d1 = __builtin_amdgcn_sdot4((int)v.x, ck[2 * p][1], d1, false);
+                d2 = __builtin_amdgcn_sdot4((int)v.x, ck[2 * p][2], d2, false);
+                d0 = __builtin_amdgcn_sdot4((int)v.y, ck[2 * p + 1][0], d0, false);
+                d1 = __builtin_amdgcn_sdot4((int)v.y, ck[2 * p + 1][1], d1, false);
+                d2 = __builtin_amdgcn_sdot4((int)v.y, ck[2 * p + 1][2], d2, false);
+            }
+            int part = combine_planes(d0, d1, d2, 0);
+            for (int m = 1; m < (1 << a.cpo_log2); m <<= 1) part += __shfl_xor(part, m);   // chunks in adjacent lanes
+            const int y = ty0 + r;
+            if (writer && y < y_end) hs_col[y] = (uint8_t)(clip8_fixed((int)((uint32_t)part + (uint32_t)obias)) ^ 0x80);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        store_luma(smem + ((t + 1) & 1) * a.lt_half);
+        __syncthreads();
+    }
+}
+
+struct KeVtileArgs {
+    const uint8_t *hs;     // [img][ow][hp] signed bytes
+    int hp, ow, oh;
+    const int32_t *packed, *start, *bias;   // vertical axis, oh outputs, ndw dwords
+    int ndw;
+    int cg;                // columns staged in LDS per round
+    uint8_t *tiles;        // [img][oh][ow]
+};
+
+__global__ __launch_bounds__(256) void ke_vtile(const KeVtileArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x;
+    const int64_t img = blockIdx.x;
+    const uint8_t *hs = a.hs + (size_t)img * a.ow * a.hp;
+    for (int c0 = 0; c0 < a.ow; c0 += a.cg) {
+        const int nc = min(a.cg, a.ow - c0);
+        const int words = nc * a.hp / 4;
+        for (int e = tid; e < words; e += 256)
+            reinterpret_cast<uint32_t *>(smem)[e] = reinterpret_cast<const uint32_t *>(hs + (size_t)c0 * a.hp)[e];
+        __syncthreads();
+        for (int e = tid; e < a.oh * nc; e += 256) {
+            const int yy = e % a.oh, c = e / a.oh;
+            const uint8_t *col = smem + (size_t)c * a.hp + a.start[yy];
+            const int32_t *cp = a.packed + (size_t)yy * a.ndw * 3;
+            int d0 = 0, d1 = 0, d2 = 0;
+            for (int j = 0; j < a.ndw; j += 2) {
+                const uint2 v = *reinterpret_cast<const uint2 *>(__builtin_assume_aligned(col + 4 * j, 8));
+                d0 = __builtin_amdgcn_sdot4((int)v.x, cp[3 * j + 0], d0, false);
+                d1 = __builtin_amdgcn_sdot4((int)v.x, cp[3 * j + 1], d1, false);
+                d2 = __builtin_amdgcn_sdot4((int)v.x, cp[3 * j + 2], d2, false);
+                d0 = __builtin_amdgcn_sdot4((int)v.y, cp[3 * j + 3], d0, false);
+                d1 = __builtin_amdgcn_sdot4((int)v.y, cp[3 * j + 4], d1, false);
+                d2 = __builtin_amdgcn_sdot4((int)v.y, cp[3 * j + 5], d2, false);
+            }
+            a.tiles[(size_t)img * a.oh * a.ow + (size_t)yy * a.ow + c0 + c] =
+                (uint8_t)clip8_fixed(combine_planes(d0, d1, d2, a.bias[yy]));
+        }
+        __syncthreads();
+    }
+}
+
+template <int NDWC, int C, bool ALIGNED>
+int launch_hband_one(ke_ctx *ctx, const KeBandArgs &a, int64_t n, size_t lds) {
+    hipLaunchKernelGGL((ke_hband<NDWC, C, ALIGNED>), dim3((unsigned)(n * a.bands)), dim3(256), lds, ctx->stream, a);
+    KE_HIP(ctx, hipGetLastError());
+    return KE_OK;
+}
+
+template <int C, bool ALIGNED>
+int launch_hband_ndwc(ke_ctx *ctx, const KeBandArgs &a, int64_t n, size_t lds, int ndwc) {
+    switch (ndwc) {
+        case 4: return launch_hband_one<4, C, ALIGNED>(ctx, a, n, lds);
+        case 8: return launch_hband_one<8, C, ALIGNED>(ctx, a, n, lds);
+        case 12: return launch_hband_one<12, C, ALIGNED>(ctx, a, n, lds);
+        case 16: return launch_hband_one<16, C, ALIGNED>(ctx, a, n, lds);
+        case 20: return launch_hband_one<20, C, ALIGNED>(ctx, a, n, lds);
+        case 24: return launch_hband_one<24, C, ALIGNED>(ctx, a, n, lds);
+        case 28: return launch_hband_one<28, C, ALIGNED>(ctx, a, n, lds);
+        case 32: return launch_hband_one<32, C, ALIGNED>(ctx, a, n, lds);
+        default: return KE_EUNSUPPORTED;
+    }
+}
+
+// Banded target: src images -> (oh x ow) u8 tiles.  Returns KE_EUNSUPPORTED for shapes it does not take
+// (Pillow's vertical-first rule, images under 4 pixels, windows beyond 8 chunks of 32 dwords).
+int resample_banded(ke_ctx *ctx, const KeHashGroup &g, int ow, int oh, uint8_t *d_tiles) {
+    if ((int64_t)g.h > (int64_t)g.w * 100 && oh < g.h) return KE_EUNSUPPORTED;
+    if ((int64_t)g.w * g.h < 4 || g.w > 16384 || g.h > 65536) return KE_EUNSUPPORTED;
+    const KeAxisCoeffs *chz = ke_get_coeffs(ctx, g.w, ow);
+    const KeAxisCoeffs *cvt = ke_get_coeffs(ctx, g.h, oh);
+    if (!chz || !cvt) return ke_fail(ctx, KE_EHIP, "coefficient upload failed");
+    // chunks per output: the power of two that wastes the fewest padded dwords, chunk <= 32 dwords
+    int best_log2 = -1, best_waste = 1 << 30;
+    for (int l = 0; l <= 3; ++l) {
+        const int cpo = 1 << l, ndwc = (((chz->ndw + cpo - 1) / cpo) + 3) & ~3;
+        if (ndwc > 32) continue;
+        int vcp = 1;
+        while (vcp < ow * cpo) vcp <<= 1;
+        if (vcp > 256) continue;
+        const int waste = cpo * ndwc - chz->ndw + (ndwc > 24 ? 8 : 0);   // mild preference for <= 24 (3 waves/SIMD)
+        if (waste < best_waste) { best_waste = waste; best_log2 = l; }
+    }
+    if (best_log2 < 0) return KE_EUNSUPPORTED;
+    const KeChunkTable *tc = ke_get_chunks(ctx, chz, 1 << best_log2);
+    if (!tc) return ke_fail(ctx, KE_EHIP, "coefficient upload failed");
+    KeBandArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.pixels = g.pixels; a.offsets = g.offsets; a.stride = g.stride; a.w = g.w; a.h = g.h;
+    a.qr = (g.w + 3) / 4;
+    if (a.qr > 2048) return KE_EUNSUPPORTED;
+    a.lp = (4 * a.qr + 7) & ~7;
+    a.rt = std::max(1, std::min(2048 / a.qr, g.h));
+    // rows per workgroup: about 512 KB of pixels, a whole number of tiles, at most 64 bands per image
+    int64_t rows = std::max<int64_t>(a.rt, ((int64_t)(512 << 10) / ((int64_t)g.w * g.channels)) / a.rt * a.rt);
+    if ((g.h + rows - 1) / rows > 64) rows = (((g.h + 63) / 64 + a.rt - 1) / a.rt) * a.rt;
+    a.band_rows = (int)rows;
+    a.bands = (g.h + a.band_rows - 1) / a.band_rows;
+    a.nout = ow; a.cpo_log2 = best_log2;
+    int vcp = 1, vl = 0;
+    while (vcp < (ow << best_log2)) { vcp <<= 1; ++vl; }
+    a.vcp_log2 = vl;
+    a.cpacked = tc->d_cpacked; a.cstart = tc->d_cstart; a.bias = chz->d_bias;
+    const int tile_bytes = a.rt * a.lp + std::max(0, tc->cspan - a.lp) + 16;
+    a.lt_half = (tile_bytes + 15) & ~15;
+    const size_t lds = 2 * (size_t)a.lt_half;
+    if (lds > 64 * 1024) return KE_EUNSUPPORTED;
+    a.hp = ((std::max(cvt->span, g.h) + 7) & ~7) + 8;
+    void *hs;
+    KE_TRY(ke_reserve(ctx, KE_BUF_TMP, (size_t)g.n * ow * a.hp, &hs));
+    a.hs = (uint8_t *)hs;
+    if ((int64_t)g.n * a.bands > 0x7fffffffLL) return ke_fail(ctx, KE_EUNSUPPORTED, "group too large for one launch");
+    // "aligned" = every row starts on a quad boundary of the packed stream (w % 4 == 0), so a
+    // quad is DW whole dwords and the last quad of the image ends with the image.  gfx950 global loads tolerate a base
+    // that is not 4-byte aligned, so ragged batches keep this path; other widths take the funnel-shift loader.
+    const bool aligned = g.w % 4 == 0;
+    int rc;
+    if (g.channels == 3) rc = aligned ? launch_hband_ndwc<3, true>(ctx, a, g.n, lds, tc->ndwc) : launch_hband_ndwc<3, false>(ctx, a, g.n, lds, tc->ndwc);
+    else if (g.channels == 1) rc = aligned ? launch_hband_ndwc<1, true>(ctx, a, g.n, lds, tc->ndwc) : launch_hband_ndwc<1, false>(ctx, a, g.n, lds, tc->ndwc);
+    else rc = aligned ? launch_hband_ndwc<4, true>(ctx, a, g.n, lds, tc->ndwc) : launch_hband_ndwc<4, false>(ctx, a, g.n, lds, tc->ndwc);
+    if (rc != KE_OK) return rc;
+    KeVtileArgs v;
+    v.hs = a.hs; v.hp = a.hp; v.ow = ow; v.oh = oh;
+    v.packed = cvt->d_packed; v.start = cvt->d_start; v.bias = cvt->d_bias; v.ndw = cvt->ndw;
+    v.cg = std::max(1, std::min(ow, (48 * 1024) / a.hp));
+    v.tiles = d_tiles;
+    if ((size_t)v.cg * a.hp > 64 * 1024) return KE_EUNSUPPORTED;
+    hipLaunchKernelGGL(ke_vtile, dim3((unsigned)g.n), dim3(256), (size_t)v.cg * a.hp, ctx->stream, v);
     KE_HIP(ctx, hipGetLastError());
     return KE_OK;
 }
@@ -558,12 +840,16 @@ int ke_launch_hash_group(ke_ctx *ctx, const KeHashGroup &g, uint64_t *d_phash, u
             if (want_p && !p_done) {
                 if (d_tile32_out) t32 = d_tile32_out + (size_t)f * 1024;
                 else KE_TRY(ke_reserve(ctx, KE_BUF_TILE32, (size_t)s.n * 1024, &t32));
-                KE_TRY(resample_generic(ctx, s, 32, 32, (uint8_t *)t32));
+                int rb = resample_banded(ctx, s, 32, 32, (uint8_t *)t32);
+                if (rb == KE_EUNSUPPORTED) rb = resample_generic(ctx, s, 32, 32, (uint8_t *)t32);
+                KE_TRY(rb);
             }
             if (want_d && !d_done) {
                 if (d_tile98_out) t98 = d_tile98_out + (size_t)f * 72;
                 else KE_TRY(ke_reserve(ctx, KE_BUF_TILE98, (size_t)s.n * 72, &t98));
-                KE_TRY(resample_generic(ctx, s, 9, 8, (uint8_t *)t98));
+                int rb = resample_banded(ctx, s, 9, 8, (uint8_t *)t98);
+                if (rb == KE_EUNSUPPORTED) rb = resample_generic(ctx, s, 9, 8, (uint8_t *)t98);
+                KE_TRY(rb);
             }
             uint64_t *ph = (d_phash && !p_done) ? d_phash + slot0 : nullptr;
             uint64_t *dh = (d_dhash && !d_done) ? d_dhash + slot0 : nullptr;

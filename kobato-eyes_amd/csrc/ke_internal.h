@@ -35,16 +35,22 @@ struct KeAxisCoeffs {
     std::vector<int32_t> packed;  // out*ndw*3
     // device copies
     int32_t *d_bounds = nullptr, *d_kk = nullptr, *d_start = nullptr, *d_bias = nullptr, *d_packed = nullptr;
-    // chunked byte-plane layout (long windows, e.g. the 9-wide dHash axis): every output's window is cut
-    // into `cpo` chunks of `ndwc` dwords; virtual column v = o*cpo + c starts at cstart[v] and owns
-    // cpacked[v][ndwc][3]; the chunks' plane sums are added before bias[o] and the clip.
+    // chunked byte-plane layouts, by chunks-per-output (see KeChunkTable)
+    std::map<int, struct KeChunkTable *> chunked;
+};
+
+// Chunked byte-plane layout for long windows: every output's packed window is cut into `cpo` chunks of
+// `ndwc` dwords; virtual column v = o*cpo + c starts at cstart[v] and owns cpacked[v][ndwc][3]; the
+// chunks' plane sums are added before bias[o] and the clip.
+struct KeChunkTable {
     int cpo = 0, ndwc = 0, cspan = 0;
     std::vector<int32_t> cstart, cpacked;
     int32_t *d_cstart = nullptr, *d_cpacked = nullptr;
 };
 
+
 void ke_build_axis_coeffs(int in_size, int out_size, KeAxisCoeffs &out);
-void ke_build_chunked(KeAxisCoeffs &c, int cpo);
+void ke_build_chunked(const KeAxisCoeffs &c, int cpo, KeChunkTable &out);
 
 struct KeDevBuf {
     void *ptr = nullptr;
@@ -104,6 +110,7 @@ int ke_reserve(ke_ctx *ctx, int which, size_t bytes, void **out);
 // else a staged copy in buffer `which`).
 int ke_to_device(ke_ctx *ctx, const void *p, size_t bytes, int which, const void **dev);
 const KeAxisCoeffs *ke_get_coeffs(ke_ctx *ctx, int in_size, int out_size);
+const KeChunkTable *ke_get_chunks(ke_ctx *ctx, const KeAxisCoeffs *c, int cpo);
 void ke_time_begin(ke_ctx *ctx, int kind);
 void ke_time_end(ke_ctx *ctx, int kind);
 

@@ -219,3 +219,37 @@ def test_error_behaviour(ctx):
         ctx.hamming_scan(np.zeros(4, np.uint64), 4, threshold=65)
     with pytest.raises(ValueError):
         ctx.hamming_scan(np.zeros(4, np.uint64), 4, band_bits=32, band_count=3)
+
+
+@pytest.mark.parametrize("w,h,ch,n", [(1024, 768, 3, 6), (640, 480, 3, 8), (1000, 667, 3, 5), (333, 517, 3, 5), (2048, 1536, 3, 2),
+                                       (4096, 4096, 3, 1), (768, 3072, 3, 2), (100, 60, 3, 9), (37, 1000, 3, 4), (16, 16, 3, 7),
+                                       (5, 4, 3, 3), (513, 512, 3, 4), (800, 600, 1, 4), (801, 603, 1, 3), (640, 360, 4, 4),
+                                       (1920, 1080, 3, 2), (3072, 256, 3, 2), (256, 4096, 3, 2), (8, 2048, 3, 2)])
+def test_banded_path_matches_oracle(ctx, w, h, ch, n):
+    """Every shape the fused kernel does not take goes through ke_hband + ke_vtile (or, for the shapes that
+    refuses, the generic passes): luma tiles, pHash and dHash must still be bit-exact."""
+    rng = np.random.default_rng(w * 7919 + h)
+    if ch == 3:
+        px = O.synth_rgb_batch(3, n, w, h)
+        px[0] = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)        # one full-range noise image
+    else:
+        px = rng.integers(0, 256, (n, h, w) if ch == 1 else (n, h, w, ch), dtype=np.uint8)
+    got_p, got_d = ctx.hash_uniform(px, n, w, h, ch)
+    t32, t98 = ctx.luma_tiles_uniform(px, n, w, h, ch)
+    for k in range(n):
+        ep, ed, e32, e98, _ = O.hash_image(px[k], want_tiles=True)
+        assert np.array_equal(t32[k], e32), (k, "tile32")
+        assert np.array_equal(t98[k], e98), (k, "tile98")
+        assert (int(got_p[k]), int(got_d[k])) == (ep, ed), k
+
+
+def test_mixed_resolution_batch_like_config5(ctx):
+    """BASELINE configs[4] in miniature: independent widths/heights from the config's side list."""
+    sides = [256, 384, 512, 768, 1024, 1536, 2048]
+    rng = np.random.default_rng(5)
+    shapes = [(int(rng.choice(sides)), int(rng.choice(sides))) for _ in range(14)]
+    imgs = [O.synth_rgb(40 + k, w, h) for k, (w, h) in enumerate(shapes)]
+    ph, dh, status = ctx.hash_images(imgs)
+    assert status.tolist() == [0] * len(imgs)
+    for k, im in enumerate(imgs):
+        assert (int(ph[k]), int(dh[k])) == O.hash_image(im), shapes[k]

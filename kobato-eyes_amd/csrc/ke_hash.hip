@@ -533,8 +533,7 @@ __global__ __launch_bounds__(256, 3) void ke_hband(const KeBandArgs a) {
     const uint8_t *src = a.pixels + (a.offsets ? a.offsets[img] : (uint64_t)img * a.stride);
     const int y_begin = band * a.band_rows;
     const int y_end = min(a.h, y_begin + a.band_rows);
-    const int64_t total_pix = (int64_t)a.w * a.h;
-    const uintptr_t last_dword = ((uintptr_t)src + (uintptr_t)total_pix * C - 1) & ~(uintptr_t)3;
+    const uintptr_t last_dword = ((uintptr_t)src + (uintptr_t)a.w * a.h * C - 1) & ~(uintptr_t)3;
 
     // lane -> (virtual column, row group)
     const int vcl = tid & ((1 << a.vcp_log2) - 1);
@@ -551,22 +550,32 @@ __global__ __launch_bounds__(256, 3) void ke_hband(const KeBandArgs a) {
     const int cst = a.cstart[vc];
     const int obias = a.bias[o];
 
-    // quad items of a tile: item = q*256 + tid -> (row r, quad j); advanced incrementally
-    const int r0 = tid / a.qr, j0 = tid % a.qr;
-    const int dr = 256 / a.qr, dj = 256 % a.qr;
+    // quad items of a tile: item = q*256 + tid -> (row r, quad j).  The mapping is the same for every tile,
+    // so the pixel offset inside the tile and the LDS byte offset are computed once per thread.
     const int items = a.rt * a.qr;
+    const int total_pix = a.w * a.h;                  // < 2^31 (checked on the host)
+    int rel_pix[QPT], lds_off[QPT];
+    {
+        int r = tid / a.qr, j = tid % a.qr;
+        const int dr = 256 / a.qr, dj = 256 % a.qr;
+#pragma unroll
+        for (int q = 0; q < QPT; ++q) {
+            rel_pix[q] = r * a.w + 4 * j;
+            lds_off[q] = (q * 256 + tid < items) ? r * a.lp + 4 * j : -1;
+            r += dr; j += dj;
+            if (j >= a.qr) { j -= a.qr; ++r; }
+        }
+    }
 
     uint32_t raw[QPT][DW];
     auto load_tile = [&](int ty0) {
-        int r = r0, j = j0;
+        const int pix0 = ty0 * a.w;
 #pragma unroll
         for (int q = 0; q < QPT; ++q) {
-            int row = ty0 + r;
-            row = row < a.h ? row : a.h - 1;
-            int64_t pix = (int64_t)row * a.w + 4 * j;
+            int pix = pix0 + rel_pix[q];
             if (ALIGNED) {
                 pix = pix < total_pix - 4 ? pix : total_pix - 4;   // w % 4 == 0: the last quad ends with the image
-                const uint32_t *p = reinterpret_cast<const uint32_t *>(src + pix * C);
+                const uint32_t *p = reinterpret_cast<const uint32_t *>(src + (size_t)pix * C);
 #pragma unroll
                 for (int k = 0; k < DW; ++k) raw[q][k] = p[k];
             } else {
@@ -583,18 +592,12 @@ __global__ __launch_bounds__(256, 3) void ke_hband(const KeBandArgs a) {
 #pragma unroll
                 for (int k = 0; k < DW; ++k) raw[q][k] = __builtin_amdgcn_alignbyte(wv[k + 1], wv[k], sb);
             }
-            r += dr; j += dj;
-            if (j >= a.qr) { j -= a.qr; ++r; }
         }
     };
     auto store_luma = [&](uint8_t *dst) {
-        int r = r0, j = j0;
 #pragma unroll
-        for (int q = 0; q < QPT; ++q) {
-            if (q * 256 + tid < items) *reinterpret_cast<uint32_t *>(dst + r * a.lp + 4 * j) = luma4_generic<C>(raw[q]);
-            r += dr; j += dj;
-            if (j >= a.qr) { j -= a.qr; ++r; }
-        }
+        for (int q = 0; q < QPT; ++q)
+            if (lds_off[q] >= 0) *reinterpret_cast<uint32_t *>(dst + lds_off[q]) = luma4_generic<C>(raw[q]);
     };
 
     const int ntiles = (y_end - y_begin + a.rt - 1) / a.rt;
@@ -698,7 +701,7 @@ int launch_hband_ndwc(ke_ctx *ctx, const KeBandArgs &a, int64_t n, size_t lds, i
 // (Pillow's vertical-first rule, images under 4 pixels, windows beyond 8 chunks of 32 dwords).
 int resample_banded(ke_ctx *ctx, const KeHashGroup &g, int ow, int oh, uint8_t *d_tiles) {
     if ((int64_t)g.h > (int64_t)g.w * 100 && oh < g.h) return KE_EUNSUPPORTED;
-    if ((int64_t)g.w * g.h < 4 || g.w > 16384 || g.h > 65536) return KE_EUNSUPPORTED;
+    if ((int64_t)g.w * g.h < 4 || g.w > 16384 || g.h > 65536 || (int64_t)g.w * g.h >= (1LL << 30)) return KE_EUNSUPPORTED;
     const KeAxisCoeffs *chz = ke_get_coeffs(ctx, g.w, ow);
     const KeAxisCoeffs *cvt = ke_get_coeffs(ctx, g.h, oh);
     if (!chz || !cvt) return ke_fail(ctx, KE_EHIP, "coefficient upload failed");
@@ -771,6 +774,16 @@ int resample_generic(ke_ctx *ctx, const KeHashGroup &g, int ow, int oh, uint8_t 
     const bool vertical_first = (int64_t)g.h > (int64_t)g.w * 100 && oh < g.h;
     const int mid_w = vertical_first ? g.w : ow, mid_h = vertical_first ? oh : g.h;
     const size_t mid_bytes = (size_t)mid_w * mid_h;
+    const int64_t max_n = std::max<int64_t>(1, (int64_t)(((size_t)512 << 20) / mid_bytes));
+    if (g.n > max_n) {   // bound the first-pass scratch: split the group
+        for (int64_t f = 0; f < g.n; f += max_n) {
+            KeHashGroup s = g;
+            s.n = std::min(max_n, g.n - f);
+            if (g.offsets) s.offsets = g.offsets + f; else s.pixels = g.pixels + (size_t)f * g.stride;
+            KE_TRY(resample_generic(ctx, s, ow, oh, d_tiles + (size_t)f * ow * oh));
+        }
+        return KE_OK;
+    }
     void *tmp;
     KE_TRY(ke_reserve(ctx, KE_BUF_TMP, (size_t)g.n * mid_bytes, &tmp));
     const int b0 = (int)((mid_bytes + 255) / 256), b1 = (ow * oh + 255) / 256;
@@ -824,7 +837,9 @@ int ke_launch_hash_group(ke_ctx *ctx, const KeHashGroup &g, uint64_t *d_phash, u
     }
     // ---- generic path, chunked so the first-pass scratch stays bounded
     if ((want_p && !p_done) || (want_d && !d_done)) {
-        const size_t per_img = (size_t)std::max(g.w, 32) * std::max(g.h, 32);
+        // the banded path needs 32*H bytes of scratch per image, the generic passes up to W*H: size chunks for
+        // the former (the generic fallback re-chunks itself below)
+        const size_t per_img = (size_t)40 * (std::max(g.h, 32) + 1024);
         const int64_t chunk = std::max<int64_t>(1, (int64_t)(((size_t)512 << 20) / per_img));
         for (int64_t f = 0; f < g.n; f += chunk) {
             KeHashGroup s = g;

@@ -9,109 +9,194 @@
 // -ffp-contract=off) so the map matches NumPy's; window sums of seven float32 values are
 // exact in fp64, so their order does not matter.
 //
-// Layout: one workgroup per (pair, 16x64 tile of interior pixels).  The tile plus a 3 px halo
-// of both images is converted once to float32 in LDS; the vertical pass writes five window
-// means per halo column to LDS; the horizontal pass finishes the means, evaluates S and the
-// workgroup writes one fp64 partial sum.  A second tiny kernel adds the partials of a pair in
-// a fixed order (bitwise reproducible) and divides.
+// Layout: see ke_ssim_waves below.  A second tiny kernel adds the partial sums of a pair in a fixed order
+// (bitwise reproducible) and divides.
 #include "ke_internal.h"
 
 namespace {
 
-constexpr int kTH = 16, kTW = 64;
-constexpr int kHH = kTH + 6, kHW = kTW + 6;   // halo tile
-constexpr int kPitch = kHW + 1;
+// ---------------------------------------------------------------------------------------
+// v2 layout: one WAVE per (pair, 250-column block, band of rows), no LDS traffic on the data path and no
+// barriers.  Lane l owns halo columns x0 + 4l .. x0 + 4l + 3 and slides down the rows: seven rows of both
+// images live in registers, the five vertical window sums are updated incrementally (+ new row, - oldest
+// row; sums of seven float32 values are exact in fp64, so the order cannot matter), rounded to float32
+// (scipy's axis-0 pass), then the horizontal windows are gathered from the two neighbouring lanes with
+// wave shuffles (axis-1 pass), again summed exactly in fp64.  division by 7: one Newton step on q = s*(1/7),
+// which is the correctly rounded quotient.  x = L/255 is formed arithmetically (exact).
+// ---------------------------------------------------------------------------------------
+constexpr int kBandRows = 64;     // interior rows per wave
 
 struct SsimArgs {
     const uint8_t *images;
     const int64_t *pa, *pb;
-    int w, h, ch;
-    int tiles_x, tiles_y;
-    double *partial;   // [pair][tiles_y*tiles_x]
+    int w, h;
+    int col_blocks, bands, items_per_pair;
+    int64_t n_items;
+    double *partial;   // [pair][items_per_pair]
 };
 
-__device__ __forceinline__ float unit_luma(const uint8_t *p, int ch) {
-    const int l = ch == 1 ? p[0] : (int)((19595u * p[0] + 38470u * p[1] + 7471u * p[2] + 0x8000u) >> 16);
-    return (float)l / 255.0f;
+__device__ __forceinline__ double div7(double s) {
+    const double r = 0x1.2492492492492p-3;           // RN(1/7)
+    const double q = s * r;
+    return fma(fma(-7.0, q, s), r, q);
 }
 
-__global__ __launch_bounds__(256) void ke_ssim_tiles(const SsimArgs a) {
-    __shared__ float s_x[kHH][kPitch], s_y[kHH][kPitch];
-    __shared__ float s_m[5][kTH][kPitch];
-    __shared__ double s_red[256];
-    const int tid = threadIdx.x;
-    const int tiles = a.tiles_x * a.tiles_y;
-    const int64_t pair = blockIdx.x / tiles;
-    const int tile = blockIdx.x % tiles;
-    const int ty = tile / a.tiles_x, tx = tile % a.tiles_x;
-    const int y0 = ty * kTH, x0 = tx * kTW;   // halo origin == first interior pixel - 3
-    const size_t img_bytes = (size_t)a.w * a.h * a.ch;
+// Four consecutive pixels of one row starting at byte address `ad` (any alignment) -> four luma bytes.
+template <int C>
+__device__ __forceinline__ uint32_t load_luma4(uintptr_t ad, uintptr_t last_dword) {
+    const uintptr_t al = ad & ~(uintptr_t)3;
+    const int sb = (int)(ad & 3);
+    uint32_t wv[C + 1], d[C];
+#pragma unroll
+    for (int k = 0; k <= C; ++k) {
+        const uintptr_t x = al + 4 * k;
+        wv[k] = *reinterpret_cast<const uint32_t *>(x < last_dword ? x : last_dword);
+    }
+#pragma unroll
+    for (int k = 0; k < C; ++k) d[k] = __builtin_amdgcn_alignbyte(wv[k + 1], wv[k], sb);
+    if (C == 1) return d[0];
+    constexpr uint32_t CHI = 0x001D964Cu, CLO = 0x002F468Bu;     // 19595 = 76*256+139, 38470 = 150*256+70, 7471 = 29*256+47
+    uint32_t p[4];
+    if (C == 3) {
+        p[0] = d[0];
+        p[1] = __builtin_amdgcn_alignbyte(d[1], d[0], 3);
+        p[2] = __builtin_amdgcn_alignbyte(d[2 % C], d[1], 2);
+        p[3] = d[2 % C] >> 8;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) p[k] = d[k % C];
+    }
+    uint32_t out = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t sum = (__builtin_amdgcn_udot4(p[k], CHI, 0u, false) << 8) + __builtin_amdgcn_udot4(p[k], CLO, 0x8000u, false);
+        out |= ((sum >> 16) & 0xFFu) << (8 * k);
+    }
+    return out;
+}
+
+// x = L/255 in float32, correctly rounded for every L in 0..255 (checked exhaustively against a true
+// division): q0 = L*r, one fma residual, one fma correction.
+__device__ __forceinline__ float unit_of(uint32_t L) {
+    const float r = 0x1.010102p-8f;                         // RN(1/255)
+    const float l = (float)L;
+    const float q0 = l * r;
+    return fmaf(fmaf(-255.0f, q0, l), r, q0);
+}
+
+// PX pixels per lane (4 or 8): a wave covers 64*PX halo columns, 64*PX - 6 interior ones.
+template <int C, int PX>
+__global__ __launch_bounds__(256, 2) void ke_ssim_waves(const SsimArgs a) {
+    constexpr int NW = PX / 4;                              // luma dwords per row per image per lane
+    const int lane = threadIdx.x & 63;
+    const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= a.n_items) return;
+    const int64_t pair = item / a.items_per_pair;
+    const int sub = (int)(item % a.items_per_pair);
+    const int band = sub / a.col_blocks, cb = sub % a.col_blocks;
+    const int block_cols = 64 * PX - 6;
+    const int x0 = cb * block_cols;
+    const int y0 = band * kBandRows;                       // first halo row; interior rows y0+3 ..
+    const int y_int_end = min(a.h - 3, y0 + 3 + kBandRows);  // one past the last interior row of this band
+    const size_t img_bytes = (size_t)a.w * a.h * C;
     const uint8_t *A = a.images + (size_t)a.pa[pair] * img_bytes;
     const uint8_t *B = a.images + (size_t)a.pb[pair] * img_bytes;
-    for (int e = tid; e < kHH * kHW; e += 256) {
-        const int r = e / kHW, c = e % kHW;
-        const int y = y0 + r, x = x0 + c;
-        float fx = 0.f, fy = 0.f;
-        if (y < a.h && x < a.w) {
-            const size_t off = ((size_t)y * a.w + x) * a.ch;
-            fx = unit_luma(A + off, a.ch);
-            fy = unit_luma(B + off, a.ch);
-        }
-        s_x[r][c] = fx;
-        s_y[r][c] = fy;
-    }
-    __syncthreads();
-    // vertical pass (scipy axis 0): rows r..r+6 of the halo -> interior row r
-    for (int e = tid; e < kTH * kHW; e += 256) {
-        const int r = e / kHW, c = e % kHW;
-        double sx = 0, sy = 0, sxx = 0, syy = 0, sxy = 0;
+    const uintptr_t lastA = ((uintptr_t)A + img_bytes - 1) & ~(uintptr_t)3;
+    const uintptr_t lastB = ((uintptr_t)B + img_bytes - 1) & ~(uintptr_t)3;
+    int xc = x0 + PX * lane;                                // this lane's first column
+    xc = xc < a.w ? xc : a.w - 1;                           // lanes past the right edge load something valid; never used
+
+    uint32_t ra[7][NW], rb[7][NW];                          // luma bytes of the seven most recent rows
+    double sx[PX], sy[PX], sxx[PX], syy[PX], sxy[PX];
 #pragma unroll
-        for (int d = 0; d < 7; ++d) {
-            const float vx = s_x[r + d][c], vy = s_y[r + d][c];
-            sx += (double)vx;
-            sy += (double)vy;
-            sxx += (double)(vx * vx);
-            syy += (double)(vy * vy);
-            sxy += (double)(vx * vy);
-        }
-        s_m[0][r][c] = (float)(sx / 7.0);
-        s_m[1][r][c] = (float)(sy / 7.0);
-        s_m[2][r][c] = (float)(sxx / 7.0);
-        s_m[3][r][c] = (float)(syy / 7.0);
-        s_m[4][r][c] = (float)(sxy / 7.0);
-    }
-    __syncthreads();
+    for (int k = 0; k < PX; ++k) sx[k] = sy[k] = sxx[k] = syy[k] = sxy[k] = 0.0;
+#pragma unroll
+    for (int d = 0; d < 7; ++d)
+#pragma unroll
+        for (int n = 0; n < NW; ++n) ra[d][n] = rb[d][n] = 0;
+
     const float cov_norm = (float)(49.0 / 48.0);
     const float C1 = (float)(0.01 * 0.01), C2 = (float)(0.03 * 0.03);
     double local = 0.0;
-    for (int e = tid; e < kTH * kTW; e += 256) {
-        const int r = e / kTW, c = e % kTW;
-        if (y0 + r + 3 >= a.h - 3 || x0 + c + 3 >= a.w - 3) continue;   // outside the cropped interior
-        double s[5];
+    const int y_last = y_int_end + 3;                       // one past the last halo row
+    for (int y = y0; y < y_last; ++y) {
+        const size_t off = ((size_t)y * a.w + xc) * C;
+        uint32_t na[NW], nb[NW];
+#pragma unroll
+        for (int n = 0; n < NW; ++n) {
+            na[n] = load_luma4<C>((uintptr_t)A + off + (size_t)n * 4 * C, lastA);
+            nb[n] = load_luma4<C>((uintptr_t)B + off + (size_t)n * 4 * C, lastB);
+        }
+        // slide: drop the oldest row, add the new one.  The first six rows of a band subtract the zeros the
+        // ring starts with (L = 0 -> x = 0), so no special case.
+#pragma unroll
+        for (int k = 0; k < PX; ++k) {
+            const int n = k >> 2, sh = 8 * (k & 3);
+            const float ox = unit_of((ra[0][n] >> sh) & 0xFF), oy = unit_of((rb[0][n] >> sh) & 0xFF);
+            const float nx = unit_of((na[n] >> sh) & 0xFF), ny = unit_of((nb[n] >> sh) & 0xFF);
+            sx[k] += (double)nx - (double)ox;
+            sy[k] += (double)ny - (double)oy;
+            sxx[k] += (double)(nx * nx) - (double)(ox * ox);
+            syy[k] += (double)(ny * ny) - (double)(oy * oy);
+            sxy[k] += (double)(nx * ny) - (double)(ox * oy);
+        }
+#pragma unroll
+        for (int n = 0; n < NW; ++n) {
+#pragma unroll
+            for (int d = 0; d < 6; ++d) { ra[d][n] = ra[d + 1][n]; rb[d][n] = rb[d + 1][n]; }
+            ra[6][n] = na[n]; rb[6][n] = nb[n];
+        }
+        if (y < y0 + 6) continue;                           // window not full yet (wave-uniform)
+        // axis-0 means of this lane's columns, rounded to float32 as scipy stores them
+        float m[5][PX + 6];                                 // [quantity][left 3 | own PX | right 3]
+#pragma unroll
+        for (int k = 0; k < PX; ++k) {
+            m[0][3 + k] = (float)div7(sx[k]);
+            m[1][3 + k] = (float)div7(sy[k]);
+            m[2][3 + k] = (float)div7(sxx[k]);
+            m[3][3 + k] = (float)div7(syy[k]);
+            m[4][3 + k] = (float)div7(sxy[k]);
+        }
 #pragma unroll
         for (int q = 0; q < 5; ++q) {
-            double acc = 0;
 #pragma unroll
-            for (int d = 0; d < 7; ++d) acc += (double)s_m[q][r][c + d];
-            s[q] = acc / 7.0;
+            for (int e = 0; e < 3; ++e) {
+                m[q][e] = __shfl_up(m[q][PX + e], 1);            // left lane's last three columns
+                m[q][PX + 3 + e] = __shfl_down(m[q][3 + e], 1);  // right lane's first three columns
+            }
         }
-        const float ux = (float)s[0], uy = (float)s[1], uxx = (float)s[2], uyy = (float)s[3], uxy = (float)s[4];
-        const float mxx = ux * ux, myy = uy * uy, mxy = ux * uy;
-        const float vx = cov_norm * (uxx - mxx);
-        const float vy = cov_norm * (uyy - myy);
-        const float vxy = cov_norm * (uxy - mxy);
-        const float A1 = 2.0f * mxy + C1, A2 = 2.0f * vxy + C2;
-        const float B1 = (mxx + myy) + C1, B2 = (vx + vy) + C2;
-        const float S = (A1 * A2) / (B1 * B2);
-        local += (double)S;
+        // axis-1 means + SSIM; the window of own column k covers m[.][k .. k+6]
+        double hs[5];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            hs[q] = 0.0;
+#pragma unroll
+            for (int d = 0; d < 7; ++d) hs[q] += (double)m[q][d];
+        }
+#pragma unroll
+        for (int k = 0; k < PX; ++k) {
+            if (k > 0) {
+#pragma unroll
+                for (int q = 0; q < 5; ++q) hs[q] += (double)m[q][k + 6] - (double)m[q][k - 1];
+            }
+            const int bc = PX * lane + k;                  // column inside the block
+            const bool inside = (bc >= 3) && (bc < 3 + block_cols) && (x0 + bc < a.w - 3);
+            const float ux = (float)div7(hs[0]), uy = (float)div7(hs[1]);
+            const float uxx = (float)div7(hs[2]), uyy = (float)div7(hs[3]), uxy = (float)div7(hs[4]);
+            const float mxx = ux * ux, myy = uy * uy, mxy = ux * uy;
+            const float vx = cov_norm * (uxx - mxx);
+            const float vy = cov_norm * (uyy - myy);
+            const float vxy = cov_norm * (uxy - mxy);
+            const float A1 = 2.0f * mxy + C1, A2 = 2.0f * vxy + C2;
+            const float B1 = (mxx + myy) + C1, B2 = (vx + vy) + C2;
+            const float S = (A1 * A2) / (B1 * B2);
+            if (inside) local += (double)S;
+        }
     }
-    s_red[tid] = local;
-    __syncthreads();
-    for (int k = 128; k > 0; k >>= 1) {
-        if (tid < k) s_red[tid] += s_red[tid + k];
-        __syncthreads();
-    }
-    if (tid == 0) a.partial[(size_t)pair * tiles + tile] = s_red[0];
+    // wave reduction in a fixed order
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) local += __shfl_down(local, s);
+    if (lane == 0) a.partial[item] = local;
 }
 
 __global__ void ke_ssim_finish(const double *__restrict__ partial, int tiles, int64_t n_pairs, double denom,
@@ -139,18 +224,28 @@ int ke_launch_ssim(ke_ctx *ctx, const uint8_t *d_images, int w, int h, int chann
     }
     SsimArgs a;
     a.images = d_images; a.pa = d_pa; a.pb = d_pb;
-    a.w = w; a.h = h; a.ch = channels;
-    a.tiles_x = (w - 6 + kTW - 1) / kTW;
-    a.tiles_y = (h - 6 + kTH - 1) / kTH;
-    const int tiles = a.tiles_x * a.tiles_y;
-    if ((int64_t)tiles * n_pairs > 0x7fffffffLL) return ke_fail(ctx, KE_EUNSUPPORTED, "too many SSIM tiles for one launch");
+    a.w = w; a.h = h;
+    // pixels per lane: the choice that leaves the fewest idle lanes (ties -> 4, which holds 2 waves/SIMD more easily)
+    const int cb4 = (w - 6 + 249) / 250, cb8 = (w - 6 + 505) / 506;
+    const int px = (cb8 * 506 < cb4 * 250) ? 8 : 4;
+    a.col_blocks = px == 8 ? cb8 : cb4;
+    a.bands = (h - 6 + kBandRows - 1) / kBandRows;
+    a.items_per_pair = a.col_blocks * a.bands;
+    a.n_items = n_pairs * a.items_per_pair;
+    const int64_t blocks = (a.n_items + 3) / 4;
+    if (blocks > 0x7fffffffLL) return ke_fail(ctx, KE_EUNSUPPORTED, "too many SSIM work items for one launch");
     void *part;
-    KE_TRY(ke_reserve(ctx, KE_BUF_SCAN_AUX, (size_t)n_pairs * tiles * sizeof(double), &part));
+    KE_TRY(ke_reserve(ctx, KE_BUF_SCAN_AUX, (size_t)a.n_items * sizeof(double), &part));
     a.partial = (double *)part;
-    hipLaunchKernelGGL(ke_ssim_tiles, dim3((unsigned)(n_pairs * tiles)), dim3(256), 0, ctx->stream, a);
+    const dim3 grid((unsigned)blocks), blk(256);
+#define KE_SSIM_LAUNCH(CH, PXV) hipLaunchKernelGGL((ke_ssim_waves<CH, PXV>), grid, blk, 0, ctx->stream, a)
+    if (channels == 3) { if (px == 8) KE_SSIM_LAUNCH(3, 8); else KE_SSIM_LAUNCH(3, 4); }
+    else if (channels == 1) { if (px == 8) KE_SSIM_LAUNCH(1, 8); else KE_SSIM_LAUNCH(1, 4); }
+    else { if (px == 8) KE_SSIM_LAUNCH(4, 8); else KE_SSIM_LAUNCH(4, 4); }
+#undef KE_SSIM_LAUNCH
     KE_HIP(ctx, hipGetLastError());
     hipLaunchKernelGGL(ke_ssim_finish, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, ctx->stream,
-                       (const double *)part, tiles, n_pairs, (double)(w - 6) * (double)(h - 6), d_out);
+                       (const double *)part, a.items_per_pair, n_pairs, (double)(w - 6) * (double)(h - 6), d_out);
     KE_HIP(ctx, hipGetLastError());
     return KE_OK;
 }

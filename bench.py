@@ -44,6 +44,7 @@ def parse_args():
     ap.add_argument("--threshold", type=int, default=8)
     ap.add_argument("--dhash", action="store_true", help="also compute dHash in the hash step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--phase-timing", action="store_true", help="after the timed run, time each phase of a step with syncs in between (stderr)")
     ap.add_argument("--cpu-sample", type=int, default=4000, help="images hashed by the CPU oracle for the baseline")
     return ap.parse_args()
 
@@ -175,6 +176,36 @@ def main():
     if distributed:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+
+    if args.phase_timing:
+        acc = {}
+
+        def lap(name, t0):
+            torch.cuda.synchronize()
+            acc[name] = acc.get(name, 0.0) + (time.perf_counter() - t0) * 1e3
+
+        for _ in range(args.steps):
+            t0 = time.perf_counter()
+            ctx.hash_uniform(pixels.data_ptr(), n_local, side, side, 3, phash_out=local_hash.data_ptr(), want_dhash=False)
+            lap("hash", t0)
+            t0 = time.perf_counter()
+            table = allgather_hashes(local_hash, n_total) if distributed else local_hash[:n_total]
+            lap("allgather_hashes", t0)
+            t0 = time.perf_counter()
+            edges, counters = _scan(ctx, table, n_total, args.threshold, rank, world, edges_dev, cap)
+            lap("scan+count", t0)
+            t0 = time.perf_counter()
+            if distributed:
+                merged, _ = allgather_edge_buffers(edges_dev, edges)
+                all_edges = merged.view(_native.EDGE_DTYPE)
+            else:
+                all_edges = edges_dev[: edges * 24].cpu().numpy().view(_native.EDGE_DTYPE)
+            lap("edge_merge", t0)
+            t0 = time.perf_counter()
+            _native.cluster_labels(all_edges, n_total)
+            lap("labels", t0)
+        if rank == 0:
+            print("phase ms/step:", {k: round(v / args.steps, 3) for k, v in acc.items()}, file=sys.stderr, flush=True)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3

@@ -16,7 +16,9 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int kRI = 4;                      // row hashes per thread
-constexpr int kTile = kThreads * kRI;       // 1024 rows x 1024 columns per workgroup
+constexpr int kTile = kThreads * kRI;       // 1024 rows per workgroup ...
+constexpr int kCols = 256;                  // ... against 256 columns: fine-grained tiles keep the tail short at N = 100k
+constexpr int kCPR = kTile / kCols;         // column chunks per row block
 constexpr int kGroup = 8;                   // columns between threshold checks
 
 struct ScanArgs {
@@ -24,7 +26,8 @@ struct ScanArgs {
     const int64_t *ids;
     const int64_t *sizes;
     int64_t n;
-    int nb;                 // tiles per axis
+    int nb;                 // row blocks
+    int ncc;                // column chunks
     int64_t first_tile;     // ordinal of this launch's first tile in the triangle enumeration
     int64_t tile_step;
     int64_t n_tiles;        // total tiles in the triangle
@@ -74,19 +77,20 @@ __device__ void consider_pair(const ScanArgs &a, int64_t gi, int64_t gj, uint64_
 }
 
 __global__ __launch_bounds__(kThreads) void ke_scan_tiles(const ScanArgs a) {
-    __shared__ __attribute__((aligned(16))) uint64_t s_cols[kTile];
+    __shared__ __attribute__((aligned(16))) uint64_t s_cols[kCols];
     const int tid = threadIdx.x;
     const int64_t t = a.first_tile + (int64_t)blockIdx.x * a.tile_step;
     if (t >= a.n_tiles) return;
-    // invert the row-major enumeration of the upper triangle: offset(rb) = rb*nb - rb*(rb-1)/2
-    const double nbd = (double)a.nb;
-    int64_t rb = (int64_t)floor(((2.0 * nbd + 1.0) - sqrt((2.0 * nbd + 1.0) * (2.0 * nbd + 1.0) - 8.0 * (double)t)) * 0.5);
+    // Tiles of the upper triangle, row-major: row block rb owns column chunks kCPR*rb .. ncc-1, so
+    // offset(rb) = rb*ncc - kCPR*rb*(rb-1)/2.  Invert with a float estimate and an exact fix-up.
+    const double hc = 0.5 * kCPR, bq = (double)a.ncc + hc;
+    int64_t rb = (int64_t)floor((bq - sqrt(fmax(bq * bq - 4.0 * hc * (double)t, 0.0))) / (2.0 * hc));
     if (rb < 0) rb = 0;
     if (rb >= a.nb) rb = a.nb - 1;
-    while (rb > 0 && rb * a.nb - rb * (rb - 1) / 2 > t) --rb;
-    while (rb + 1 < a.nb && (rb + 1) * a.nb - (rb + 1) * rb / 2 <= t) ++rb;
-    const int64_t cb = rb + (t - (rb * a.nb - rb * (rb - 1) / 2));
-    const int64_t row0 = rb * kTile, col0 = cb * kTile;
+    while (rb > 0 && rb * a.ncc - kCPR * rb * (rb - 1) / 2 > t) --rb;
+    while (rb + 1 < a.nb && (rb + 1) * a.ncc - kCPR * (rb + 1) * rb / 2 <= t) ++rb;
+    const int64_t cc = kCPR * rb + (t - (rb * a.ncc - kCPR * rb * (rb - 1) / 2));
+    const int64_t row0 = rb * kTile, col0 = cc * kCols;
 
     uint32_t xlo[kRI], xhi[kRI];
 #pragma unroll
@@ -96,15 +100,14 @@ __global__ __launch_bounds__(kThreads) void ke_scan_tiles(const ScanArgs a) {
         xlo[r] = (uint32_t)x;
         xhi[r] = (uint32_t)(x >> 32);
     }
-#pragma unroll
-    for (int k = 0; k < kRI; ++k) {
-        const int64_t gj = col0 + k * kThreads + tid;
-        s_cols[k * kThreads + tid] = gj < a.n ? a.hashes[gj] : ~0ull;
+    {
+        const int64_t gj = col0 + tid;
+        s_cols[tid] = gj < a.n ? a.hashes[gj] : ~0ull;
     }
     __syncthreads();
 
     const int thr = a.threshold;
-    const int ncols = (int)((a.n - col0) < kTile ? (a.n - col0) : kTile);
+    const int ncols = (int)((a.n - col0) < kCols ? (a.n - col0) : kCols);
     for (int c0 = 0; c0 < ncols; c0 += kGroup) {
         int best = 64;
 #pragma unroll
@@ -150,7 +153,8 @@ int ke_launch_scan(ke_ctx *ctx, const uint64_t *d_hashes, const int64_t *d_ids, 
     a.hashes = d_hashes; a.ids = d_ids; a.sizes = (size_ratio > 0.0) ? d_sizes : nullptr;
     a.n = n;
     a.nb = (int)((n + kTile - 1) / kTile);
-    a.n_tiles = (int64_t)a.nb * (a.nb + 1) / 2;
+    a.ncc = (int)((n + kCols - 1) / kCols);
+    a.n_tiles = (int64_t)a.nb * a.ncc - (int64_t)kCPR * a.nb * (a.nb - 1) / 2;
     a.first_tile = part_index;
     a.tile_step = part_count;
     a.threshold = threshold; a.band_bits = band_bits; a.band_count = band_count;
@@ -176,18 +180,35 @@ int ke_launch_scan(ke_ctx *ctx, const uint64_t *d_hashes, const int64_t *d_ids, 
         KE_HIP(ctx, hipGetLastError());
     }
     ke_time_end(ctx, KE_T_SCAN);
-    // pairs evaluated by this shard, closed form (host): every tile counts its i<j pairs inside [0,n)
+    // pairs evaluated by this shard (host, O(row blocks)): per row block, the chunks right of the diagonal are
+    // full rectangles, the kCPR chunks on the diagonal hold a partial triangle.
     unsigned long long pairs = 0;
-    for (int64_t t = part_index; t < a.n_tiles; t += part_count) {
-        // recover (rb, cb) the same way the kernel does
-        int64_t rb = 0, lo = 0, hi = a.nb - 1;
-        while (lo <= hi) {
-            const int64_t mid = (lo + hi) / 2;
-            if (mid * a.nb - mid * (mid - 1) / 2 <= t) { rb = mid; lo = mid + 1; } else hi = mid - 1;
+    for (int64_t rb = 0; rb < a.nb; ++rb) {
+        const int64_t off = rb * a.ncc - (int64_t)kCPR * rb * (rb - 1) / 2;
+        const int64_t row0 = rb * kTile, rows = std::min<int64_t>(kTile, n - row0);
+        for (int64_t cc = kCPR * rb; cc < a.ncc; ++cc) {
+            const int64_t t = off + (cc - kCPR * rb);
+            const bool diagonal = cc < kCPR * (rb + 1);
+            if (!diagonal) {
+                // every remaining chunk is a full rectangle except possibly the last one: count them arithmetically
+                const int64_t last = a.ncc - 1;
+                const int64_t t_last = off + (last - kCPR * rb);
+                // chunks cc .. last-1 (full width)
+                const int64_t first_full_t = t, end_full_t = t_last;   // [first_full_t, end_full_t)
+                if (end_full_t > first_full_t) {
+                    // count t in [first_full_t, end_full_t) with t % part_count == part_index
+                    auto upto = [&](int64_t x) { return x <= part_index ? 0 : (x - part_index + part_count - 1) / part_count; };
+                    pairs += (unsigned long long)(upto(end_full_t) - upto(first_full_t)) * (unsigned long long)(rows * kCols);
+                }
+                if (t_last % part_count == part_index && last >= cc)
+                    pairs += (unsigned long long)(rows * std::min<int64_t>(kCols, n - last * kCols));
+                break;
+            }
+            if (t % part_count != part_index) continue;
+            const int64_t col0 = cc * kCols, cols = std::min<int64_t>(kCols, n - col0);
+            for (int64_t j = col0; j < col0 + cols; ++j)
+                pairs += (unsigned long long)std::max<int64_t>(0, std::min<int64_t>(rows, j - row0));
         }
-        const int64_t cb = rb + (t - (rb * a.nb - rb * (rb - 1) / 2));
-        const int64_t rows = std::min<int64_t>(kTile, n - rb * kTile), cols = std::min<int64_t>(kTile, n - cb * kTile);
-        pairs += (rb == cb) ? (unsigned long long)(rows * (rows - 1) / 2) : (unsigned long long)(rows * cols);
     }
     *pairs_evaluated = pairs;
     return KE_OK;

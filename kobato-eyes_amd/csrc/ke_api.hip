@@ -94,17 +94,19 @@ const KeAxisCoeffs *ke_get_coeffs(ke_ctx *ctx, int in_size, int out_size) {
     return c;
 }
 
-const KeChunkTable *ke_get_chunks(ke_ctx *ctx, const KeAxisCoeffs *cc, int cpo) {
+const KeChunkTable *ke_get_chunks(ke_ctx *ctx, const KeAxisCoeffs *cc, int cpo, int ndwc_multiple) {
     auto *c = const_cast<KeAxisCoeffs *>(cc);
-    auto it = c->chunked.find(cpo);
+    const int key = cpo * 64 + ndwc_multiple;
+    auto it = c->chunked.find(key);
     if (it != c->chunked.end()) return it->second;
     auto *t = new KeChunkTable();
-    ke_build_chunked(*c, cpo, *t);
-    if (upload_i32(ctx, t->cstart, &t->d_cstart) || upload_i32(ctx, t->cpacked, &t->d_cpacked)) {
+    ke_build_chunked(*c, cpo, *t, ndwc_multiple);
+    if (upload_i32(ctx, t->cstart, &t->d_cstart) || upload_i32(ctx, t->cpacked, &t->d_cpacked) ||
+        upload_i32(ctx, t->cxor, &t->d_cxor)) {
         delete t;
         return nullptr;
     }
-    c->chunked[cpo] = t;
+    c->chunked[key] = t;
     return t;
 }
 
@@ -175,6 +177,7 @@ KE_API void ke_destroy(ke_ctx *ctx) {
         for (auto &ck : c->chunked) {
             if (ck.second->d_cstart) (void)hipFree(ck.second->d_cstart);
             if (ck.second->d_cpacked) (void)hipFree(ck.second->d_cpacked);
+            if (ck.second->d_cxor) (void)hipFree(ck.second->d_cxor);
             delete ck.second;
         }
         delete c;

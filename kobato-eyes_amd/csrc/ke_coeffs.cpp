@@ -6,6 +6,7 @@
 // sinc(t)*sinc(t/3) evaluated at tap centres, normalised to sum 1 in double precision and
 // quantised to 22-bit fixed point with round-half-away-from-zero.  An unchanged axis gets
 // identity taps (one tap of weight 2^22), which reproduces Pillow's "skip this pass" exactly.
+#include <algorithm>
 #include <cmath>
 
 #include "ke_internal.h"
@@ -109,9 +110,9 @@ void ke_build_axis_coeffs(int in_size, int out_size, KeAxisCoeffs &c) {
 }
 
 // Cut every output's packed window into `cpo` equal chunks (see KeChunkTable).
-void ke_build_chunked(const KeAxisCoeffs &c, int cpo, KeChunkTable &t) {
+void ke_build_chunked(const KeAxisCoeffs &c, int cpo, KeChunkTable &t, int ndwc_multiple) {
     t.cpo = cpo;
-    t.ndwc = (((c.ndw + cpo - 1) / cpo) + 3) & ~3;
+    t.ndwc = (((c.ndw + cpo - 1) / cpo) + ndwc_multiple - 1) / ndwc_multiple * ndwc_multiple;
     const int nv = c.out_size * cpo;
     t.cstart.assign((size_t)nv, 0);
     t.cpacked.assign((size_t)nv * t.ndwc * 3, 0);
@@ -128,4 +129,25 @@ void ke_build_chunked(const KeAxisCoeffs &c, int cpo, KeChunkTable &t) {
                     t.cpacked[((size_t)v * t.ndwc + j) * 3 + p] = c.packed[((size_t)o * c.ndw + src) * 3 + p];
             }
         }
+    // Bank-conflict swizzle: lanes are virtual columns; 32 consecutive ones form a ds_read_b64 lane group and
+    // step p reads 8 bytes at cstart + 8*(p ^ x).  Greedy choice of x per lane against the lanes already placed.
+    t.cxor.assign((size_t)nv, 0);
+    if (t.ndwc % 8 == 0) {
+        const int np = t.ndwc / 2;
+        for (int g0 = 0; g0 < nv; g0 += 32) {
+            for (int v = g0; v < std::min(nv, g0 + 32); ++v) {
+                int best_x = 0, best_hits = 1 << 30;
+                for (int x = 0; x < 4; ++x) {
+                    int hits = 0;
+                    for (int p = 0; p < np; ++p) {
+                        const int slot = ((t.cstart[v] / 8) + (p ^ x)) & 31;
+                        for (int u = g0; u < v; ++u)
+                            if ((((t.cstart[u] / 8) + (p ^ t.cxor[u])) & 31) == slot) ++hits;
+                    }
+                    if (hits < best_hits) { best_hits = hits; best_x = x; }
+                }
+                t.cxor[v] = best_x;
+            }
+        }
+    }
 }

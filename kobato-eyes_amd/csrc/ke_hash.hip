@@ -503,8 +503,9 @@ struct KeBandArgs {
     int nout;          // output columns (32 or 9)
     int cpo_log2;      // log2(chunks per output)
     int vcp_log2;      // log2(lanes per row group) >= log2(nout << cpo_log2)
-    const int32_t *cpacked, *cstart, *bias;
+    const int32_t *cpacked, *cstart, *cxor, *bias;
     int lt_half;       // bytes of one LDS luma tile buffer
+    int bp;            // pitch of one output column of the band staging area in LDS (bytes, multiple of 4)
     uint8_t *hs;       // [img][nout][hp]
     int hp;
 };
@@ -542,12 +543,18 @@ __global__ __launch_bounds__(256, 3) void ke_hband(const KeBandArgs a) {
     const int vc = vcl < nvc ? vcl : nvc - 1;
     const int o = vc >> a.cpo_log2;
     const bool writer = vcl < nvc && (vc & ((1 << a.cpo_log2) - 1)) == 0;
+    // step p reads the window dword pair p ^ xs (xs in 0..3, host-chosen so a half-wave's lanes spread over the
+    // LDS banks); the tap planes are loaded in the same permuted order
+    const int xs = a.cxor[vc];
     int ck[NDWC][3];
 #pragma unroll
-    for (int j = 0; j < NDWC; ++j)
+    for (int p = 0; p < NDWC / 2; ++p)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) ck[j][c] = a.cpacked[((size_t)vc * NDWC + j) * 3 + c];
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) ck[2 * p + e][c] = a.cpacked[((size_t)vc * NDWC + 2 * (p ^ xs) + e) * 3 + c];
     const int cst = a.cstart[vc];
+    const int sw[4] = {cst + 8 * (0 ^ xs), cst + 8 * (1 ^ xs), cst + 8 * (2 ^ xs), cst + 8 * (3 ^ xs)};
     const int obias = a.bias[o];
 
     // quad items of a tile: item = q*256 + tid -> (row r, quad j).  The mapping is the same for every tile,
@@ -601,7 +608,11 @@ __global__ __launch_bounds__(256, 3) void ke_hband(const KeBandArgs a) {
     };
 
     const int ntiles = (y_end - y_begin + a.rt - 1) / a.rt;
-    uint8_t *hs_col = a.hs + ((size_t)img * a.nout + o) * a.hp;
+    // The band's output bytes are staged in LDS and written out once at the end: a global store inside the
+    // row loop makes hipcc drain vmcnt(0) at the loop entry, which would wait for the prefetch just issued.
+    uint8_t *HB = smem + 2 * a.lt_half;
+    uint8_t *hb_col = HB + o * a.bp;
+    const int cpo = 1 << a.cpo_log2;
     load_tile(y_begin);
     store_luma(smem);
     __syncthreads();
@@ -611,11 +622,12 @@ __global__ __launch_bounds__(256, 3) void ke_hband(const KeBandArgs a) {
         load_tile(t + 1 < ntiles ? ty0 + a.rt : ty0);
         __builtin_amdgcn_sched_barrier(0);
         for (int r = rg; r < a.rt; r += RG) {
-            const uint8_t *lrow = cur + r * a.lp + cst;
+            const uint8_t *lrow = cur + r * a.lp;
+            const uint8_t *lr4[4] = {lrow + sw[0], lrow + sw[1], lrow + sw[2], lrow + sw[3]};
             int d0 = 0, d1 = 0, d2 = 0;
 #pragma unroll
             for (int p = 0; p < NDWC / 2; ++p) {
-                const uint2 v = *reinterpret_cast<const uint2 *>(__builtin_assume_aligned(lrow + 8 * p, 8));
+                const uint2 v = *reinterpret_cast<const uint2 *>(__builtin_assume_aligned(lr4[p & 3] + 8 * (p & ~3), 8));
                 d0 = __builtin_amdgcn_sdot4((int)v.x, ck[2 * p][0], d0, false);
                 d1 = __builtin_amdgcn_sdot4((int)v.x, ck[2 * p][1], d1, false);
                 d2 = __builtin_amdgcn_sdot4((int)v.x, ck[2 * p][2], d2, false);
@@ -624,13 +636,25 @@ __global__ __launch_bounds__(256, 3) void ke_hband(const KeBandArgs a) {
                 d2 = __builtin_amdgcn_sdot4((int)v.y, ck[2 * p + 1][2], d2, false);
             }
             int part = combine_planes(d0, d1, d2, 0);
-            for (int m = 1; m < (1 << a.cpo_log2); m <<= 1) part += __shfl_xor(part, m);   // chunks in adjacent lanes
-            const int y = ty0 + r;
-            if (writer && y < y_end) hs_col[y] = (uint8_t)(clip8_fixed((int)((uint32_t)part + (uint32_t)obias)) ^ 0x80);
+#pragma unroll
+            for (int m = 1; m < 8; m <<= 1) {                      // chunks sit in adjacent lanes (cpo <= 8)
+                const int other = __shfl_xor(part, m);
+                part += m < cpo ? other : 0;
+            }
+            if (writer) hb_col[t * a.rt + r] = (uint8_t)(clip8_fixed((int)((uint32_t)part + (uint32_t)obias)) ^ 0x80);
         }
         __builtin_amdgcn_sched_barrier(0);
         store_luma(smem + ((t + 1) & 1) * a.lt_half);
         __syncthreads();
+    }
+    // write the band out: whole dwords along y (y_begin and bp are multiples of 4; hs rows are padded)
+    {
+        const int wpc = (y_end - y_begin + 3) / 4;   // dwords per output column
+        uint8_t *dst = a.hs + (size_t)img * a.nout * a.hp + y_begin;
+        for (int e = tid; e < a.nout * wpc; e += 256) {
+            const int col = e / wpc, k = e % wpc;
+            *reinterpret_cast<uint32_t *>(dst + (size_t)col * a.hp + 4 * k) = *reinterpret_cast<const uint32_t *>(HB + col * a.bp + 4 * k);
+        }
     }
 }
 
@@ -685,13 +709,9 @@ int launch_hband_one(ke_ctx *ctx, const KeBandArgs &a, int64_t n, size_t lds) {
 template <int C, bool ALIGNED>
 int launch_hband_ndwc(ke_ctx *ctx, const KeBandArgs &a, int64_t n, size_t lds, int ndwc) {
     switch (ndwc) {
-        case 4: return launch_hband_one<4, C, ALIGNED>(ctx, a, n, lds);
         case 8: return launch_hband_one<8, C, ALIGNED>(ctx, a, n, lds);
-        case 12: return launch_hband_one<12, C, ALIGNED>(ctx, a, n, lds);
         case 16: return launch_hband_one<16, C, ALIGNED>(ctx, a, n, lds);
-        case 20: return launch_hband_one<20, C, ALIGNED>(ctx, a, n, lds);
         case 24: return launch_hband_one<24, C, ALIGNED>(ctx, a, n, lds);
-        case 28: return launch_hband_one<28, C, ALIGNED>(ctx, a, n, lds);
         case 32: return launch_hband_one<32, C, ALIGNED>(ctx, a, n, lds);
         default: return KE_EUNSUPPORTED;
     }
@@ -708,7 +728,7 @@ int resample_banded(ke_ctx *ctx, const KeHashGroup &g, int ow, int oh, uint8_t *
     // chunks per output: the power of two that wastes the fewest padded dwords, chunk <= 32 dwords
     int best_log2 = -1, best_waste = 1 << 30;
     for (int l = 0; l <= 3; ++l) {
-        const int cpo = 1 << l, ndwc = (((chz->ndw + cpo - 1) / cpo) + 3) & ~3;
+        const int cpo = 1 << l, ndwc = (((chz->ndw + cpo - 1) / cpo) + 7) & ~7;
         if (ndwc > 32) continue;
         int vcp = 1;
         while (vcp < ow * cpo) vcp <<= 1;
@@ -717,7 +737,7 @@ int resample_banded(ke_ctx *ctx, const KeHashGroup &g, int ow, int oh, uint8_t *
         if (waste < best_waste) { best_waste = waste; best_log2 = l; }
     }
     if (best_log2 < 0) return KE_EUNSUPPORTED;
-    const KeChunkTable *tc = ke_get_chunks(ctx, chz, 1 << best_log2);
+    const KeChunkTable *tc = ke_get_chunks(ctx, chz, 1 << best_log2, 8);
     if (!tc) return ke_fail(ctx, KE_EHIP, "coefficient upload failed");
     KeBandArgs a;
     std::memset(&a, 0, sizeof a);
@@ -726,21 +746,25 @@ int resample_banded(ke_ctx *ctx, const KeHashGroup &g, int ow, int oh, uint8_t *
     if (a.qr > 2048) return KE_EUNSUPPORTED;
     a.lp = (4 * a.qr + 7) & ~7;
     a.rt = std::max(1, std::min(2048 / a.qr, g.h));
-    // rows per workgroup: about 512 KB of pixels, a whole number of tiles, at most 64 bands per image
-    int64_t rows = std::max<int64_t>(a.rt, ((int64_t)(512 << 10) / ((int64_t)g.w * g.channels)) / a.rt * a.rt);
-    if ((g.h + rows - 1) / rows > 64) rows = (((g.h + 63) / 64 + a.rt - 1) / a.rt) * a.rt;
+    // rows per workgroup: about 512 KB of pixels, a whole number of 4-tile groups (so bands start on a multiple
+    // of 4 rows), at most 64 bands per image, and at most 480 rows (the band's output bytes are staged in LDS)
+    const int unit = 4 * a.rt;
+    int64_t rows = std::max<int64_t>(unit, ((int64_t)(512 << 10) / ((int64_t)g.w * g.channels)) / unit * unit);
+    rows = std::min<int64_t>(rows, std::max(unit, 480 / unit * unit));
+    if ((g.h + rows - 1) / rows > 64 && rows < 480) rows = std::min<int64_t>(std::max(unit, 480 / unit * unit), (((g.h + 63) / 64 + unit - 1) / unit) * unit);
     a.band_rows = (int)rows;
     a.bands = (g.h + a.band_rows - 1) / a.band_rows;
+    a.bp = ((a.band_rows + 3) & ~3) + 4;
     a.nout = ow; a.cpo_log2 = best_log2;
     int vcp = 1, vl = 0;
     while (vcp < (ow << best_log2)) { vcp <<= 1; ++vl; }
     a.vcp_log2 = vl;
-    a.cpacked = tc->d_cpacked; a.cstart = tc->d_cstart; a.bias = chz->d_bias;
+    a.cpacked = tc->d_cpacked; a.cstart = tc->d_cstart; a.cxor = tc->d_cxor; a.bias = chz->d_bias;
     const int tile_bytes = a.rt * a.lp + std::max(0, tc->cspan - a.lp) + 16;
     a.lt_half = (tile_bytes + 15) & ~15;
-    const size_t lds = 2 * (size_t)a.lt_half;
+    const size_t lds = 2 * (size_t)a.lt_half + (size_t)ow * a.bp;
     if (lds > 64 * 1024) return KE_EUNSUPPORTED;
-    a.hp = ((std::max(cvt->span, g.h) + 7) & ~7) + 8;
+    a.hp = ((std::max(cvt->span, g.h + 4) + 7) & ~7) + 8;
     void *hs;
     KE_TRY(ke_reserve(ctx, KE_BUF_TMP, (size_t)g.n * ow * a.hp, &hs));
     a.hs = (uint8_t *)hs;

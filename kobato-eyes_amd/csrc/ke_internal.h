@@ -45,12 +45,15 @@ struct KeAxisCoeffs {
 struct KeChunkTable {
     int cpo = 0, ndwc = 0, cspan = 0;
     std::vector<int32_t> cstart, cpacked;
-    int32_t *d_cstart = nullptr, *d_cpacked = nullptr;
+    // cxor[v] in 0..3: lane v visits window dword pair p at physical pair p ^ cxor[v], chosen on the host so
+    // that the 32 lanes of a half-wave hit distinct LDS banks with ds_read_b64 (needs ndwc % 8 == 0)
+    std::vector<int32_t> cxor;
+    int32_t *d_cstart = nullptr, *d_cpacked = nullptr, *d_cxor = nullptr;
 };
 
 
 void ke_build_axis_coeffs(int in_size, int out_size, KeAxisCoeffs &out);
-void ke_build_chunked(const KeAxisCoeffs &c, int cpo, KeChunkTable &out);
+void ke_build_chunked(const KeAxisCoeffs &c, int cpo, KeChunkTable &out, int ndwc_multiple = 4);
 
 struct KeDevBuf {
     void *ptr = nullptr;
@@ -110,7 +113,7 @@ int ke_reserve(ke_ctx *ctx, int which, size_t bytes, void **out);
 // else a staged copy in buffer `which`).
 int ke_to_device(ke_ctx *ctx, const void *p, size_t bytes, int which, const void **dev);
 const KeAxisCoeffs *ke_get_coeffs(ke_ctx *ctx, int in_size, int out_size);
-const KeChunkTable *ke_get_chunks(ke_ctx *ctx, const KeAxisCoeffs *c, int cpo);
+const KeChunkTable *ke_get_chunks(ke_ctx *ctx, const KeAxisCoeffs *c, int cpo, int ndwc_multiple = 4);
 void ke_time_begin(ke_ctx *ctx, int kind);
 void ke_time_end(ke_ctx *ctx, int kind);
 

@@ -241,7 +241,9 @@ __global__ __launch_bounds__(256, (NDWD > 0 ? 2 : 3)) void ke_phash_fused(const 
 
     // horizontal tap planes of this thread's output column -> registers
     const int o = tid & 31, rg = tid >> 5;
-    const int rot = (o >> 4) & 1;  // lanes o and o+16 would hit the same LDS banks: swap dword pairs
+    // hipcc pairs the two rows' reads into ds_read2st64_b64 (16-lane groups, 32 banks): lanes o and o+8 would
+    // hit the same banks, so every other group of 8 visits the dword pairs in swapped order
+    const int rot = (o >> 3) & 1;
     int ck[NDWH][3];
 #pragma unroll
     for (int p = 0; p < NDWH / 2; ++p) {
@@ -282,9 +284,10 @@ __global__ __launch_bounds__(256, (NDWD > 0 ? 2 : 3)) void ke_phash_fused(const 
             int gq = t * QUADS_PER_TILE + q * 256 + tid;
             gq = gq < total_quads ? gq : total_quads - 1;
             const uint32_t *p = reinterpret_cast<const uint32_t *>(src + (size_t)gq * 12);
-            raw[q][0] = p[0];
-            raw[q][1] = p[1];
-            raw[q][2] = p[2];
+            // streamed once: non-temporal loads (+1.4 % measured, interleaved A/B on 100k x 512^2)
+            raw[q][0] = __builtin_nontemporal_load(p);
+            raw[q][1] = __builtin_nontemporal_load(p + 1);
+            raw[q][2] = __builtin_nontemporal_load(p + 2);
         }
     };
     auto store_luma = [&](uint8_t *dst) {
@@ -584,7 +587,7 @@ __global__ __launch_bounds__(256, 3) void ke_hband(const KeBandArgs a) {
                 pix = pix < total_pix - 4 ? pix : total_pix - 4;   // w % 4 == 0: the last quad ends with the image
                 const uint32_t *p = reinterpret_cast<const uint32_t *>(src + (size_t)pix * C);
 #pragma unroll
-                for (int k = 0; k < DW; ++k) raw[q][k] = p[k];
+                for (int k = 0; k < DW; ++k) raw[q][k] = __builtin_nontemporal_load(p + k);
             } else {
                 pix = pix < total_pix - 1 ? pix : total_pix - 1;
                 const uintptr_t ad = (uintptr_t)src + (uintptr_t)pix * C;

@@ -639,10 +639,16 @@ __global__ __launch_bounds__(256, 3) void ke_hband(const KeBandArgs a) {
                 d2 = __builtin_amdgcn_sdot4((int)v.y, ck[2 * p + 1][2], d2, false);
             }
             int part = combine_planes(d0, d1, d2, 0);
-#pragma unroll
-            for (int m = 1; m < 8; m <<= 1) {                      // chunks sit in adjacent lanes (cpo <= 8)
-                const int other = __shfl_xor(part, m);
-                part += m < cpo ? other : 0;
+            // chunks sit in adjacent lanes (cpo <= 8): DPP butterflies inside the quad, then the upper quad of
+            // an 8-lane group shifted down onto the lower one (only the group's first lane is read afterwards).
+            // DPP runs in the VALU; wave shuffles (ds_bpermute) would add three LDS round trips per row.
+            {
+                const int x1 = __builtin_amdgcn_update_dpp(0, part, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
+                part += cpo > 1 ? x1 : 0;
+                const int x2 = __builtin_amdgcn_update_dpp(0, part, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
+                part += cpo > 2 ? x2 : 0;
+                const int x4 = __builtin_amdgcn_update_dpp(0, part, 0x104, 0xF, 0xF, true);   // row_shl:4
+                part += cpo > 4 ? x4 : 0;
             }
             if (writer) hb_col[t * a.rt + r] = (uint8_t)(clip8_fixed((int)((uint32_t)part + (uint32_t)obias)) ^ 0x80);
         }

@@ -503,7 +503,9 @@ struct KeBandArgs {
     int rt;            // rows per tile (rt * qr <= 2048)
     int band_rows;     // rows per workgroup (multiple of rt)
     int bands;         // workgroups per image
-    int nout;          // output columns (32 or 9)
+    int nout;          // output columns handled by this launch
+    int nout_total;    // output columns of the axis (32 or 9): pitch of the scratch
+    int out_first;     // first output column of this launch
     int cpo_log2;      // log2(chunks per output)
     int vcp_log2;      // log2(lanes per row group) >= log2(nout << cpo_log2)
     const int32_t *cpacked, *cstart, *cxor, *bias;
@@ -543,9 +545,10 @@ __global__ __launch_bounds__(256, 3) void ke_hband(const KeBandArgs a) {
     const int vcl = tid & ((1 << a.vcp_log2) - 1);
     const int rg = tid >> a.vcp_log2, RG = 256 >> a.vcp_log2;
     const int nvc = a.nout << a.cpo_log2;
-    const int vc = vcl < nvc ? vcl : nvc - 1;
-    const int o = vc >> a.cpo_log2;
-    const bool writer = vcl < nvc && (vc & ((1 << a.cpo_log2) - 1)) == 0;
+    const int vloc = vcl < nvc ? vcl : nvc - 1;
+    const int o = vloc >> a.cpo_log2;                       // output column inside this launch
+    const int vc = vloc + (a.out_first << a.cpo_log2);      // virtual column in the axis' tables
+    const bool writer = vcl < nvc && (vloc & ((1 << a.cpo_log2) - 1)) == 0;
     // step p reads the window dword pair p ^ xs (xs in 0..3, host-chosen so a half-wave's lanes spread over the
     // LDS banks); the tap planes are loaded in the same permuted order
     const int xs = a.cxor[vc];
@@ -558,7 +561,7 @@ __global__ __launch_bounds__(256, 3) void ke_hband(const KeBandArgs a) {
             for (int c = 0; c < 3; ++c) ck[2 * p + e][c] = a.cpacked[((size_t)vc * NDWC + 2 * (p ^ xs) + e) * 3 + c];
     const int cst = a.cstart[vc];
     const int sw[4] = {cst + 8 * (0 ^ xs), cst + 8 * (1 ^ xs), cst + 8 * (2 ^ xs), cst + 8 * (3 ^ xs)};
-    const int obias = a.bias[o];
+    const int obias = a.bias[a.out_first + o];
 
     // quad items of a tile: item = q*256 + tid -> (row r, quad j).  The mapping is the same for every tile,
     // so the pixel offset inside the tile and the LDS byte offset are computed once per thread.
@@ -649,6 +652,9 @@ __global__ __launch_bounds__(256, 3) void ke_hband(const KeBandArgs a) {
                 part += cpo > 2 ? x2 : 0;
                 const int x4 = __builtin_amdgcn_update_dpp(0, part, 0x104, 0xF, 0xF, true);   // row_shl:4
                 part += cpo > 4 ? x4 : 0;
+                const int x8 = __builtin_amdgcn_update_dpp(0, part, 0x108, 0xF, 0xF, true);   // row_shl:8
+                part += cpo > 8 ? x8 : 0;
+                if (cpo > 16) part += __shfl_down(part, 16);                                   // across DPP rows (wave-uniform branch)
             }
             if (writer) hb_col[t * a.rt + r] = (uint8_t)(clip8_fixed((int)((uint32_t)part + (uint32_t)obias)) ^ 0x80);
         }
@@ -659,7 +665,7 @@ __global__ __launch_bounds__(256, 3) void ke_hband(const KeBandArgs a) {
     // write the band out: whole dwords along y (y_begin and bp are multiples of 4; hs rows are padded)
     {
         const int wpc = (y_end - y_begin + 3) / 4;   // dwords per output column
-        uint8_t *dst = a.hs + (size_t)img * a.nout * a.hp + y_begin;
+        uint8_t *dst = a.hs + ((size_t)img * a.nout_total + a.out_first) * a.hp + y_begin;
         for (int e = tid; e < a.nout * wpc; e += 256) {
             const int col = e / wpc, k = e % wpc;
             *reinterpret_cast<uint32_t *>(dst + (size_t)col * a.hp + 4 * k) = *reinterpret_cast<const uint32_t *>(HB + col * a.bp + 4 * k);
@@ -734,15 +740,14 @@ int resample_banded(ke_ctx *ctx, const KeHashGroup &g, int ow, int oh, uint8_t *
     const KeAxisCoeffs *chz = ke_get_coeffs(ctx, g.w, ow);
     const KeAxisCoeffs *cvt = ke_get_coeffs(ctx, g.h, oh);
     if (!chz || !cvt) return ke_fail(ctx, KE_EHIP, "coefficient upload failed");
-    // chunks per output: the power of two that wastes the fewest padded dwords, chunk <= 32 dwords
+    // chunks per output: the power of two that wastes the fewest padded dwords, chunk <= 32 dwords; when the
+    // virtual columns of all outputs do not fit the 256 lanes, the outputs are split over several launches
     int best_log2 = -1, best_waste = 1 << 30;
-    for (int l = 0; l <= 3; ++l) {
+    for (int l = 0; l <= 5; ++l) {
         const int cpo = 1 << l, ndwc = (((chz->ndw + cpo - 1) / cpo) + 7) & ~7;
         if (ndwc > 32) continue;
-        int vcp = 1;
-        while (vcp < ow * cpo) vcp <<= 1;
-        if (vcp > 256) continue;
-        const int waste = cpo * ndwc - chz->ndw + (ndwc > 24 ? 8 : 0);   // mild preference for <= 24 (3 waves/SIMD)
+        const int launches = (ow * cpo + 255) / 256;
+        const int waste = cpo * ndwc - chz->ndw + (ndwc > 24 ? 8 : 0) + 1000 * (launches - 1);   // mild preference for <= 24 (3 waves/SIMD)
         if (waste < best_waste) { best_waste = waste; best_log2 = l; }
     }
     if (best_log2 < 0) return KE_EUNSUPPORTED;
@@ -764,14 +769,12 @@ int resample_banded(ke_ctx *ctx, const KeHashGroup &g, int ow, int oh, uint8_t *
     a.band_rows = (int)rows;
     a.bands = (g.h + a.band_rows - 1) / a.band_rows;
     a.bp = ((a.band_rows + 3) & ~3) + 4;
-    a.nout = ow; a.cpo_log2 = best_log2;
-    int vcp = 1, vl = 0;
-    while (vcp < (ow << best_log2)) { vcp <<= 1; ++vl; }
-    a.vcp_log2 = vl;
+    a.nout_total = ow; a.cpo_log2 = best_log2;
+    const int per_launch = std::min(ow, 256 >> best_log2);   // outputs whose virtual columns fit 256 lanes
     a.cpacked = tc->d_cpacked; a.cstart = tc->d_cstart; a.cxor = tc->d_cxor; a.bias = chz->d_bias;
     const int tile_bytes = a.rt * a.lp + std::max(0, tc->cspan - a.lp) + 16;
     a.lt_half = (tile_bytes + 15) & ~15;
-    const size_t lds = 2 * (size_t)a.lt_half + (size_t)ow * a.bp;
+    const size_t lds = 2 * (size_t)a.lt_half + (size_t)per_launch * a.bp;
     if (lds > 64 * 1024) return KE_EUNSUPPORTED;
     a.hp = ((std::max(cvt->span, g.h + 4) + 7) & ~7) + 8;
     void *hs;
@@ -782,11 +785,18 @@ int resample_banded(ke_ctx *ctx, const KeHashGroup &g, int ow, int oh, uint8_t *
     // quad is DW whole dwords and the last quad of the image ends with the image.  gfx950 global loads tolerate a base
     // that is not 4-byte aligned, so ragged batches keep this path; other widths take the funnel-shift loader.
     const bool aligned = g.w % 4 == 0;
-    int rc;
-    if (g.channels == 3) rc = aligned ? launch_hband_ndwc<3, true>(ctx, a, g.n, lds, tc->ndwc) : launch_hband_ndwc<3, false>(ctx, a, g.n, lds, tc->ndwc);
-    else if (g.channels == 1) rc = aligned ? launch_hband_ndwc<1, true>(ctx, a, g.n, lds, tc->ndwc) : launch_hband_ndwc<1, false>(ctx, a, g.n, lds, tc->ndwc);
-    else rc = aligned ? launch_hband_ndwc<4, true>(ctx, a, g.n, lds, tc->ndwc) : launch_hband_ndwc<4, false>(ctx, a, g.n, lds, tc->ndwc);
-    if (rc != KE_OK) return rc;
+    for (int first = 0; first < ow; first += per_launch) {
+        a.out_first = first;
+        a.nout = std::min(per_launch, ow - first);
+        int vcp = 1, vl = 0;
+        while (vcp < (a.nout << best_log2)) { vcp <<= 1; ++vl; }
+        a.vcp_log2 = vl;
+        int rc;
+        if (g.channels == 3) rc = aligned ? launch_hband_ndwc<3, true>(ctx, a, g.n, lds, tc->ndwc) : launch_hband_ndwc<3, false>(ctx, a, g.n, lds, tc->ndwc);
+        else if (g.channels == 1) rc = aligned ? launch_hband_ndwc<1, true>(ctx, a, g.n, lds, tc->ndwc) : launch_hband_ndwc<1, false>(ctx, a, g.n, lds, tc->ndwc);
+        else rc = aligned ? launch_hband_ndwc<4, true>(ctx, a, g.n, lds, tc->ndwc) : launch_hband_ndwc<4, false>(ctx, a, g.n, lds, tc->ndwc);
+        if (rc != KE_OK) return rc;
+    }
     KeVtileArgs v;
     v.hs = a.hs; v.hp = a.hp; v.ow = ow; v.oh = oh;
     v.packed = cvt->d_packed; v.start = cvt->d_start; v.bias = cvt->d_bias; v.ndw = cvt->ndw;

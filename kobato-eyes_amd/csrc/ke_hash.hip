@@ -300,11 +300,7 @@ __global__ __launch_bounds__(256, (NDWD > 0 ? 2 : 3)) void ke_phash_fused(const 
     load_tile(0);
     store_luma(Lt);
     __syncthreads();
-    for (int t = 0; t < ntiles; ++t) {
-        const uint8_t *cur = Lt + (t & 1) * a.lt_half;
-        const int tn = t + 1 < ntiles ? t + 1 : t;   // last iteration re-reads its own tile (L2 hit, result unused)
-        load_tile(tn);
-        __builtin_amdgcn_sched_barrier(0);   // keep the loads at the top: hipcc otherwise sinks them next to their use
+    auto hpass = [&](int t, const uint8_t *cur) {
         // ---- K1b: horizontal taps: thread = (output column o, rows 2rg, 2rg+1)
         uint32_t packed2 = 0;
 #pragma unroll
@@ -351,11 +347,20 @@ __global__ __launch_bounds__(256, (NDWD > 0 ? 2 : 3)) void ke_phash_fused(const 
             if (d_lane && o % 3 == 0)
                 *reinterpret_cast<uint16_t *>(HTd + (size_t)(o / 3) * a.hpd + t * kRT + 2 * rg) = (uint16_t)dp2;
         }
+    };
+    // the last tile is peeled: it has nothing to prefetch (a guarded prefetch would make hipcc wait for the
+    // loads right after issuing them, an unguarded one would fetch 1/ntiles more bytes from HBM)
+    for (int t = 0; t + 1 < ntiles; ++t) {
+        load_tile(t + 1);
+        __builtin_amdgcn_sched_barrier(0);   // keep the loads at the top: hipcc otherwise sinks them next to their use
+        hpass(t, Lt + (t & 1) * a.lt_half);
         // ---- K1a for the next tile: luma of the loads issued above -> the other LDS buffer
         __builtin_amdgcn_sched_barrier(0);   // ...and keep their first use down here, behind the dot products
         store_luma(Lt + ((t + 1) & 1) * a.lt_half);
         __syncthreads();
     }
+    hpass(ntiles - 1, Lt + ((ntiles - 1) & 1) * a.lt_half);
+    __syncthreads();
 
     // ---- K1': vertical taps: thread = (output row yy, columns og + 8m)
     uint8_t *T32 = Lt;
@@ -622,11 +627,7 @@ __global__ __launch_bounds__(256, 3) void ke_hband(const KeBandArgs a) {
     load_tile(y_begin);
     store_luma(smem);
     __syncthreads();
-    for (int t = 0; t < ntiles; ++t) {
-        const uint8_t *cur = smem + (t & 1) * a.lt_half;
-        const int ty0 = y_begin + t * a.rt;
-        load_tile(t + 1 < ntiles ? ty0 + a.rt : ty0);
-        __builtin_amdgcn_sched_barrier(0);
+    auto hpass = [&](int t, const uint8_t *cur) {
         for (int r = rg; r < a.rt; r += RG) {
             const uint8_t *lrow = cur + r * a.lp;
             const uint8_t *lr4[4] = {lrow + sw[0], lrow + sw[1], lrow + sw[2], lrow + sw[3]};
@@ -658,10 +659,17 @@ __global__ __launch_bounds__(256, 3) void ke_hband(const KeBandArgs a) {
             }
             if (writer) hb_col[t * a.rt + r] = (uint8_t)(clip8_fixed((int)((uint32_t)part + (uint32_t)obias)) ^ 0x80);
         }
+    };
+    for (int t = 0; t + 1 < ntiles; ++t) {     // last tile peeled: nothing to prefetch (see ke_phash_fused)
+        load_tile(y_begin + (t + 1) * a.rt);
+        __builtin_amdgcn_sched_barrier(0);
+        hpass(t, smem + (t & 1) * a.lt_half);
         __builtin_amdgcn_sched_barrier(0);
         store_luma(smem + ((t + 1) & 1) * a.lt_half);
         __syncthreads();
     }
+    hpass(ntiles - 1, smem + ((ntiles - 1) & 1) * a.lt_half);
+    __syncthreads();
     // write the band out: whole dwords along y (y_begin and bp are multiples of 4; hs rows are padded)
     {
         const int wpc = (y_end - y_begin + 3) / 4;   // dwords per output column

@@ -131,6 +131,23 @@ int ke_ssim_pairs_uniform(ke_ctx *ctx, const uint8_t *images, int64_t n_images, 
                           int32_t height, int32_t channels, const int64_t *pair_a, const int64_t *pair_b,
                           int64_t n_pairs, double *ssim_out);
 
+/* ---- shipped refine stage ("next" row of SURVEY 8f): replaces the per-file work of
+ * ui.dup_refine_parallel -- tile_ahash_bits (src/ui/dup_refine_parallel.py:59-83), _load_small_gray
+ * (:203-207) and _mae01 (:208-210).
+ *
+ * ke_resize_luma_uniform: n equally sized images -> n luma thumbnails of out_h rows x out_w bytes, exactly
+ * image.convert("L").resize((out_w, out_h), filter) of Pillow; filter 0 = LANCZOS (src/sig/phash.py:24),
+ * 1 = BILINEAR (src/ui/dup_refine_parallel.py:70, :204).
+ * ke_tile_ahash: thumbnails of side grid*tile -> ceil((grid*tile)^2 / 64) little-endian u64 words per image;
+ * bit i (order gy, gx, ty, tx) = pixel > mean of its tile.
+ * ke_sad_pairs: sum |a - b| over two thumbnails of `pixels` bytes; MAE = sad / pixels / 255 on the host. */
+enum { KE_FILTER_LANCZOS = 0, KE_FILTER_BILINEAR = 1 };
+int ke_resize_luma_uniform(ke_ctx *ctx, const uint8_t *pixels, int64_t n, int32_t width, int32_t height,
+                           int32_t channels, int32_t out_w, int32_t out_h, int32_t filter, uint8_t *tiles_out);
+int ke_tile_ahash(ke_ctx *ctx, const uint8_t *tiles, int64_t n, int32_t grid, int32_t tile, uint64_t *bits_out);
+int ke_sad_pairs(ke_ctx *ctx, const uint8_t *thumbs, int64_t n_thumbs, int64_t pixels, const int64_t *pair_a,
+                 const int64_t *pair_b, int64_t n_pairs, uint64_t *sad_out);
+
 /* ---- synthetic corpus (BASELINE configs; DESIGN.md "Synthetic data") --------------------
  * Writes images [first_index, first_index+n) of the counter-based corpus as packed RGB into
  * device or host memory; ke_synth_hashes writes the scan-only hash table. */

@@ -10,6 +10,8 @@ from .api import DedupSettings, compute_signature, find_duplicates, run_duplicat
 from .cluster import Cluster, ClusterBuilder
 from .fastsig import bulk_upsert_signatures, compute_signatures_mp, fast_fill_missing_signatures
 from .phash import dhash, hamming64, hash_batch, phash, phash_dhash
+from .refine_parallel import (refine_by_pixels_parallel, refine_by_tilehash_parallel, tile_ahash_bits,
+                              tile_ahash_from_arrays, tile_hamming)
 from .refine import RefinedMatch, RefinementThresholds, compute_ssim, refine_pair, ssim_pairs
 from .scanner import (DuplicateCluster, DuplicateClusterEntry, DuplicateFile, DuplicateScanConfig, DuplicateScanner,
                       assemble_clusters)
@@ -20,5 +22,6 @@ __all__ = [
     "run_duplicate_scan", "DedupSettings", "DuplicateFile", "DuplicateCluster", "DuplicateClusterEntry",
     "DuplicateScanConfig", "DuplicateScanner", "assemble_clusters", "fast_fill_missing_signatures",
     "compute_signatures_mp", "bulk_upsert_signatures", "compute_signatures_from_image", "ensure_signatures",
+    "tile_ahash_bits", "tile_hamming", "tile_ahash_from_arrays", "refine_by_tilehash_parallel", "refine_by_pixels_parallel",
     "refine_pair", "compute_ssim", "ssim_pairs", "RefinementThresholds", "RefinedMatch", "Cluster", "ClusterBuilder",
 ]

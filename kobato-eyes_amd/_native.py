@@ -24,7 +24,8 @@ EXPORTS = (
     "ke_abi_version", "ke_create", "ke_create_error", "ke_destroy", "ke_last_error", "ke_set_stream",
     "ke_get_stream", "ke_synchronize", "ke_device_info", "ke_malloc", "ke_free", "ke_memcpy",
     "ke_hash_images", "ke_hash_uniform", "ke_luma_tiles_uniform", "ke_hamming_scan", "ke_cluster_labels",
-    "ke_ssim_pairs_uniform", "ke_synth_rgb", "ke_synth_hashes", "ke_last_kernel_ms",
+    "ke_ssim_pairs_uniform", "ke_resize_luma_uniform", "ke_tile_ahash", "ke_sad_pairs", "ke_synth_rgb",
+    "ke_synth_hashes", "ke_last_kernel_ms",
 )
 
 _lib: Optional[C.CDLL] = None
@@ -74,13 +75,17 @@ def load_library() -> C.CDLL:
                                         C.POINTER(i64), vp]
         lib.ke_cluster_labels.argtypes = [vp, i64, i64, vp]
         lib.ke_ssim_pairs_uniform.argtypes = [vp, vp, i64, i32, i32, i32, vp, vp, i64, vp]
+        lib.ke_resize_luma_uniform.argtypes = [vp, vp, i64, i32, i32, i32, i32, i32, i32, vp]
+        lib.ke_tile_ahash.argtypes = [vp, vp, i64, i32, i32, vp]
+        lib.ke_sad_pairs.argtypes = [vp, vp, i64, i64, vp, vp, i64, vp]
         lib.ke_synth_rgb.argtypes = [vp, u64, i64, i64, i32, i32, vp]
         lib.ke_synth_hashes.argtypes = [vp, u64, i64, vp]
         lib.ke_last_kernel_ms.argtypes = [vp, i32]
         lib.ke_last_kernel_ms.restype = dbl
         for name in ("ke_set_stream", "ke_synchronize", "ke_device_info", "ke_malloc", "ke_free", "ke_memcpy",
                      "ke_hash_images", "ke_hash_uniform", "ke_luma_tiles_uniform", "ke_hamming_scan",
-                     "ke_cluster_labels", "ke_ssim_pairs_uniform", "ke_synth_rgb", "ke_synth_hashes"):
+                     "ke_cluster_labels", "ke_ssim_pairs_uniform", "ke_resize_luma_uniform", "ke_tile_ahash",
+                     "ke_sad_pairs", "ke_synth_rgb", "ke_synth_hashes"):
             getattr(lib, name).restype = C.c_int
         _lib = lib
         return lib
@@ -249,6 +254,41 @@ class Context:
         with self._lock:
             self._check(self._lib.ke_ssim_pairs_uniform(self._h, _addr(images), n_images, width, height, channels, _addr(pa),
                                                         _addr(pb), len(pa), _addr(out)), "ke_ssim_pairs_uniform")
+        return out
+
+    # -- shipped refine stage -------------------------------------------------------------------
+    def resize_luma_uniform(self, pixels, n: int, width: int, height: int, channels: int, out_w: int, out_h: int,
+                            filter: int = 1, out=None):
+        """n images -> (n, out_h, out_w) u8 luma thumbnails; filter 0 = LANCZOS, 1 = BILINEAR."""
+        if isinstance(pixels, np.ndarray):
+            pixels = np.ascontiguousarray(pixels, dtype=np.uint8)
+        if out is None:
+            out = np.empty((n, out_h, out_w), np.uint8)
+        with self._lock:
+            self._check(self._lib.ke_resize_luma_uniform(self._h, _addr(pixels), n, width, height, channels, out_w, out_h,
+                                                         filter, _addr(out)), "ke_resize_luma_uniform")
+        return out
+
+    def tile_ahash(self, tiles, n: int, grid: int, tile: int):
+        """(n, side, side) thumbnails -> (n, words) u64, little-endian bit order of tile_ahash_bits."""
+        if isinstance(tiles, np.ndarray):
+            tiles = np.ascontiguousarray(tiles, dtype=np.uint8)
+        side = grid * tile
+        words = (side * side + 63) // 64
+        out = np.empty((n, words), np.uint64)
+        with self._lock:
+            self._check(self._lib.ke_tile_ahash(self._h, _addr(tiles), n, grid, tile, _addr(out)), "ke_tile_ahash")
+        return out
+
+    def sad_pairs(self, thumbs, n_thumbs: int, pixels: int, pair_a, pair_b):
+        if isinstance(thumbs, np.ndarray):
+            thumbs = np.ascontiguousarray(thumbs, dtype=np.uint8)
+        pa = np.ascontiguousarray(pair_a, dtype=np.int64)
+        pb = np.ascontiguousarray(pair_b, dtype=np.int64)
+        out = np.empty(len(pa), np.uint64)
+        with self._lock:
+            self._check(self._lib.ke_sad_pairs(self._h, _addr(thumbs), n_thumbs, pixels, _addr(pa), _addr(pb), len(pa),
+                                               _addr(out)), "ke_sad_pairs")
         return out
 
     # -- synthetic corpus ---------------------------------------------------------------------

@@ -78,12 +78,12 @@ static int upload_i32(ke_ctx *ctx, const std::vector<int32_t> &v, int32_t **out)
     return KE_OK;
 }
 
-const KeAxisCoeffs *ke_get_coeffs(ke_ctx *ctx, int in_size, int out_size) {
-    auto key = std::make_pair(in_size, out_size);
+const KeAxisCoeffs *ke_get_coeffs(ke_ctx *ctx, int in_size, int out_size, int filter) {
+    auto key = std::make_pair(in_size, out_size * 4 + filter);
     auto it = ctx->coeffs.find(key);
     if (it != ctx->coeffs.end()) return it->second;
     auto *c = new KeAxisCoeffs();
-    ke_build_axis_coeffs(in_size, out_size, *c);
+    ke_build_axis_coeffs(in_size, out_size, *c, filter);
     if (upload_i32(ctx, c->bounds, &c->d_bounds) || upload_i32(ctx, c->kk, &c->d_kk) ||
         upload_i32(ctx, c->start, &c->d_start) || upload_i32(ctx, c->bias, &c->d_bias) ||
         upload_i32(ctx, c->packed, &c->d_packed)) {
@@ -514,6 +514,92 @@ KE_API int ke_ssim_pairs_uniform(ke_ctx *ctx, const uint8_t *images, int64_t n_i
     ke_time_end(ctx, KE_T_SSIM);
     if (!out_dev) {
         KE_HIP(ctx, hipMemcpyAsync(ssim_out, d_out, (size_t)n_pairs * 8, hipMemcpyDeviceToHost, ctx->stream));
+        KE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return KE_OK;
+}
+
+// ---- shipped refine stage: thumbnails, tile aHash, pixel MAE --------------------------------------
+KE_API int ke_resize_luma_uniform(ke_ctx *ctx, const uint8_t *pixels, int64_t n, int32_t width, int32_t height,
+                                  int32_t channels, int32_t out_w, int32_t out_h, int32_t filter, uint8_t *tiles_out) {
+    if (!ctx) return KE_EINVAL;
+    if (n < 0 || (n > 0 && (!pixels || !tiles_out))) return ke_fail(ctx, KE_EINVAL, "NULL argument");
+    if (width <= 0 || height <= 0 || out_w <= 0 || out_h <= 0) return ke_fail(ctx, KE_EINVAL, "sizes must be positive");
+    if (channels != 1 && channels != 3 && channels != 4) return ke_fail(ctx, KE_EINVAL, "channels must be 1, 3 or 4");
+    if (filter != KE_FILTER_LANCZOS && filter != KE_FILTER_BILINEAR) return ke_fail(ctx, KE_EINVAL, "unknown filter %d", filter);
+    if (n == 0) return KE_OK;
+    KE_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t img_bytes = (size_t)width * height * channels, out_bytes = (size_t)out_w * out_h;
+    const bool in_dev = ke_is_device_ptr(pixels), out_dev = ke_is_device_ptr(tiles_out);
+    const int64_t chunk = in_dev ? n : std::max<int64_t>(1, (int64_t)(kStageBytes / img_bytes));
+    ke_time_begin(ctx, KE_T_HASH);
+    for (int64_t f = 0; f < n; f += chunk) {
+        const int64_t m = std::min(chunk, n - f);
+        const void *d_px;
+        KE_TRY(ke_to_device(ctx, pixels + (size_t)f * img_bytes, (size_t)m * img_bytes, KE_BUF_PIXELS, &d_px));
+        uint8_t *d_out = tiles_out + (size_t)f * out_bytes;
+        void *tmp;
+        if (!out_dev) { KE_TRY(ke_reserve(ctx, KE_BUF_SSIM_IN, (size_t)m * out_bytes, &tmp)); d_out = (uint8_t *)tmp; }
+        KeHashGroup g{(const uint8_t *)d_px, nullptr, img_bytes, nullptr, m, width, height, channels};
+        KE_TRY(ke_launch_resize_group(ctx, g, out_w, out_h, filter, d_out));
+        if (!out_dev)
+            KE_HIP(ctx, hipMemcpyAsync(tiles_out + (size_t)f * out_bytes, d_out, (size_t)m * out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+        if (!in_dev || !out_dev) KE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    ke_time_end(ctx, KE_T_HASH);
+    return KE_OK;
+}
+
+KE_API int ke_tile_ahash(ke_ctx *ctx, const uint8_t *tiles, int64_t n, int32_t grid, int32_t tile, uint64_t *bits_out) {
+    if (!ctx) return KE_EINVAL;
+    if (n < 0 || (n > 0 && (!tiles || !bits_out))) return ke_fail(ctx, KE_EINVAL, "NULL argument");
+    if (grid <= 0 || tile <= 0 || (int64_t)grid * tile > 1024 || grid > 64) return ke_fail(ctx, KE_EINVAL, "bad grid/tile %d/%d", grid, tile);
+    if (n == 0) return KE_OK;
+    KE_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t side = (size_t)grid * tile, words = (side * side + 63) / 64;
+    const void *d_t;
+    KE_TRY(ke_to_device(ctx, tiles, (size_t)n * side * side, KE_BUF_SSIM_IN, &d_t));
+    const bool out_dev = ke_is_device_ptr(bits_out);
+    uint64_t *d_bits = bits_out;
+    void *tmp;
+    if (!out_dev) { KE_TRY(ke_reserve(ctx, KE_BUF_OUT0, (size_t)n * words * 8, &tmp)); d_bits = (uint64_t *)tmp; }
+    KE_TRY(ke_launch_tile_ahash(ctx, (const uint8_t *)d_t, n, grid, tile, d_bits));
+    if (!out_dev) {
+        KE_HIP(ctx, hipMemcpyAsync(bits_out, d_bits, (size_t)n * words * 8, hipMemcpyDeviceToHost, ctx->stream));
+        KE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return KE_OK;
+}
+
+KE_API int ke_sad_pairs(ke_ctx *ctx, const uint8_t *thumbs, int64_t n_thumbs, int64_t pixels, const int64_t *pair_a,
+                        const int64_t *pair_b, int64_t n_pairs, uint64_t *sad_out) {
+    if (!ctx) return KE_EINVAL;
+    if (n_pairs < 0 || n_thumbs < 0 || pixels <= 0) return ke_fail(ctx, KE_EINVAL, "bad counts");
+    if (n_pairs == 0) return KE_OK;
+    if (!thumbs || !pair_a || !pair_b || !sad_out) return ke_fail(ctx, KE_EINVAL, "NULL argument");
+    KE_HIP(ctx, hipSetDevice(ctx->device));
+    if (!ke_is_device_ptr(pair_a) && !ke_is_device_ptr(pair_b))
+        for (int64_t k = 0; k < n_pairs; ++k)
+            if (pair_a[k] < 0 || pair_a[k] >= n_thumbs || pair_b[k] < 0 || pair_b[k] >= n_thumbs)
+                return ke_fail(ctx, KE_EINVAL, "pair %lld indexes outside [0,%lld)", (long long)k, (long long)n_thumbs);
+    const void *d_t, *d_pa, *d_pb;
+    KE_TRY(ke_to_device(ctx, thumbs, (size_t)n_thumbs * pixels, KE_BUF_SSIM_IN, &d_t));
+    void *aux;
+    KE_TRY(ke_reserve(ctx, KE_BUF_SSIM_AUX, (size_t)n_pairs * 24, &aux));
+    auto stage = [&](const int64_t *src, int slot, const void **dst) -> int {
+        if (ke_is_device_ptr(src)) { *dst = src; return KE_OK; }
+        void *d = (uint8_t *)aux + (size_t)slot * n_pairs * 8;
+        KE_HIP(ctx, hipMemcpyAsync(d, src, (size_t)n_pairs * 8, hipMemcpyHostToDevice, ctx->stream));
+        *dst = d;
+        return KE_OK;
+    };
+    KE_TRY(stage(pair_a, 0, &d_pa));
+    KE_TRY(stage(pair_b, 1, &d_pb));
+    const bool out_dev = ke_is_device_ptr(sad_out);
+    uint64_t *d_out = out_dev ? sad_out : (uint64_t *)((uint8_t *)aux + (size_t)2 * n_pairs * 8);
+    KE_TRY(ke_launch_sad_pairs(ctx, (const uint8_t *)d_t, pixels, (const int64_t *)d_pa, (const int64_t *)d_pb, n_pairs, d_out));
+    if (!out_dev) {
+        KE_HIP(ctx, hipMemcpyAsync(sad_out, d_out, (size_t)n_pairs * 8, hipMemcpyDeviceToHost, ctx->stream));
         KE_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     return KE_OK;

@@ -26,9 +26,16 @@ inline double lanczos3(double x) {
     return (x >= -3.0 && x < 3.0) ? sinc_pi(x) * sinc_pi(x / 3.0) : 0.0;
 }
 
+// Pillow's BILINEAR ("triangle") kernel, support 1: the resize of the shipped refine stage
+// (src/ui/dup_refine_parallel.py:70 and :204)
+inline double triangle(double x) {
+    if (x < 0.0) x = -x;
+    return x < 1.0 ? 1.0 - x : 0.0;
+}
+
 }  // namespace
 
-void ke_build_axis_coeffs(int in_size, int out_size, KeAxisCoeffs &c) {
+void ke_build_axis_coeffs(int in_size, int out_size, KeAxisCoeffs &c, int filter) {
     c.in_size = in_size;
     c.out_size = out_size;
     c.bounds.assign(2 * (size_t)out_size, 0);
@@ -42,7 +49,7 @@ void ke_build_axis_coeffs(int in_size, int out_size, KeAxisCoeffs &c) {
     } else {
         const double scale = (double)in_size / (double)out_size;
         const double fscale = scale < 1.0 ? 1.0 : scale;
-        const double support = 3.0 * fscale;
+        const double support = (filter == KE_FILTER_BILINEAR ? 1.0 : 3.0) * fscale;
         const double inv = 1.0 / fscale;
         c.ksize = (int)std::ceil(support) * 2 + 1;
         c.kk.assign((size_t)out_size * c.ksize, 0);
@@ -56,7 +63,8 @@ void ke_build_axis_coeffs(int in_size, int out_size, KeAxisCoeffs &c) {
             const int cnt = hi - lo;
             double total = 0.0;
             for (int t = 0; t < cnt; ++t) {
-                w[t] = lanczos3((t + lo - center + 0.5) * inv);
+                const double arg = (t + lo - center + 0.5) * inv;
+                w[t] = filter == KE_FILTER_BILINEAR ? triangle(arg) : lanczos3(arg);
                 total += w[t];
             }
             int32_t *k = &c.kk[(size_t)o * c.ksize];

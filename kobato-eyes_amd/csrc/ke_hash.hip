@@ -742,11 +742,11 @@ int launch_hband_ndwc(ke_ctx *ctx, const KeBandArgs &a, int64_t n, size_t lds, i
 
 // Banded target: src images -> (oh x ow) u8 tiles.  Returns KE_EUNSUPPORTED for shapes it does not take
 // (Pillow's vertical-first rule, images under 4 pixels, windows beyond 8 chunks of 32 dwords).
-int resample_banded(ke_ctx *ctx, const KeHashGroup &g, int ow, int oh, uint8_t *d_tiles) {
+int resample_banded(ke_ctx *ctx, const KeHashGroup &g, int ow, int oh, uint8_t *d_tiles, int filter = KE_FILTER_LANCZOS) {
     if ((int64_t)g.h > (int64_t)g.w * 100 && oh < g.h) return KE_EUNSUPPORTED;
     if ((int64_t)g.w * g.h < 4 || g.w > 16384 || g.h > 65536 || (int64_t)g.w * g.h >= (1LL << 30)) return KE_EUNSUPPORTED;
-    const KeAxisCoeffs *chz = ke_get_coeffs(ctx, g.w, ow);
-    const KeAxisCoeffs *cvt = ke_get_coeffs(ctx, g.h, oh);
+    const KeAxisCoeffs *chz = ke_get_coeffs(ctx, g.w, ow, filter);
+    const KeAxisCoeffs *cvt = ke_get_coeffs(ctx, g.h, oh, filter);
     if (!chz || !cvt) return ke_fail(ctx, KE_EHIP, "coefficient upload failed");
     // chunks per output: the power of two that wastes the fewest padded dwords, chunk <= 32 dwords; when the
     // virtual columns of all outputs do not fit the 256 lanes, the outputs are split over several launches
@@ -774,11 +774,13 @@ int resample_banded(ke_ctx *ctx, const KeHashGroup &g, int ow, int oh, uint8_t *
     int64_t rows = std::max<int64_t>(unit, ((int64_t)(512 << 10) / ((int64_t)g.w * g.channels)) / unit * unit);
     rows = std::min<int64_t>(rows, std::max(unit, 480 / unit * unit));
     if ((g.h + rows - 1) / rows > 64 && rows < 480) rows = std::min<int64_t>(std::max(unit, 480 / unit * unit), (((g.h + 63) / 64 + unit - 1) / unit) * unit);
+    const int per_launch = std::min(ow, 256 >> best_log2);   // outputs whose virtual columns fit 256 lanes
+    // the band's output bytes (per_launch columns) are staged in LDS: keep that area under 24 KB
+    rows = std::min<int64_t>(rows, std::max<int64_t>(unit, ((24 * 1024) / per_launch - 8) / unit * unit));
     a.band_rows = (int)rows;
     a.bands = (g.h + a.band_rows - 1) / a.band_rows;
     a.bp = ((a.band_rows + 3) & ~3) + 4;
     a.nout_total = ow; a.cpo_log2 = best_log2;
-    const int per_launch = std::min(ow, 256 >> best_log2);   // outputs whose virtual columns fit 256 lanes
     a.cpacked = tc->d_cpacked; a.cstart = tc->d_cstart; a.cxor = tc->d_cxor; a.bias = chz->d_bias;
     const int tile_bytes = a.rt * a.lp + std::max(0, tc->cspan - a.lp) + 16;
     a.lt_half = (tile_bytes + 15) & ~15;
@@ -817,9 +819,9 @@ int resample_banded(ke_ctx *ctx, const KeHashGroup &g, int ow, int oh, uint8_t *
 }
 
 // Generic target: src images -> (oh x ow) u8 tiles, two single-axis passes in Pillow's order.
-int resample_generic(ke_ctx *ctx, const KeHashGroup &g, int ow, int oh, uint8_t *d_tiles) {
-    const KeAxisCoeffs *chz = ke_get_coeffs(ctx, g.w, ow);
-    const KeAxisCoeffs *cvt = ke_get_coeffs(ctx, g.h, oh);
+int resample_generic(ke_ctx *ctx, const KeHashGroup &g, int ow, int oh, uint8_t *d_tiles, int filter = KE_FILTER_LANCZOS) {
+    const KeAxisCoeffs *chz = ke_get_coeffs(ctx, g.w, ow, filter);
+    const KeAxisCoeffs *cvt = ke_get_coeffs(ctx, g.h, oh, filter);
     if (!chz || !cvt) return ke_fail(ctx, KE_EHIP, "coefficient upload failed");
     // Pillow's Image.resize shrinks very tall, narrow images vertically first (PIL/Image.py).
     const bool vertical_first = (int64_t)g.h > (int64_t)g.w * 100 && oh < g.h;
@@ -831,7 +833,7 @@ int resample_generic(ke_ctx *ctx, const KeHashGroup &g, int ow, int oh, uint8_t 
             KeHashGroup s = g;
             s.n = std::min(max_n, g.n - f);
             if (g.offsets) s.offsets = g.offsets + f; else s.pixels = g.pixels + (size_t)f * g.stride;
-            KE_TRY(resample_generic(ctx, s, ow, oh, d_tiles + (size_t)f * ow * oh));
+            KE_TRY(resample_generic(ctx, s, ow, oh, d_tiles + (size_t)f * ow * oh, filter));
         }
         return KE_OK;
     }
@@ -926,5 +928,94 @@ int ke_launch_hash_group(ke_ctx *ctx, const KeHashGroup &g, uint64_t *d_phash, u
             }
         }
     }
+    return KE_OK;
+}
+
+// Luma + resize of a group to (oh x ow) tiles: what _to_grayscale does for the hashes (LANCZOS) and what
+// the shipped refine stage does for its 32x32 / 128x128 thumbnails (BILINEAR).
+int ke_launch_resize_group(ke_ctx *ctx, const KeHashGroup &g, int ow, int oh, int filter, uint8_t *d_tiles) {
+    if (ow <= 0 || oh <= 0 || ow > 4096 || oh > 4096) return ke_fail(ctx, KE_EINVAL, "bad output size %dx%d", ow, oh);
+    const size_t per_img = (size_t)(ow + 8) * (std::max(g.h, oh) + 1024);
+    const int64_t chunk = std::max<int64_t>(1, (int64_t)(((size_t)512 << 20) / per_img));
+    for (int64_t f = 0; f < g.n; f += chunk) {
+        KeHashGroup s = g;
+        s.n = std::min(chunk, g.n - f);
+        if (g.offsets) s.offsets = g.offsets + f; else s.pixels = g.pixels + (size_t)f * g.stride;
+        uint8_t *dst = d_tiles + (size_t)f * ow * oh;
+        int rc = resample_banded(ctx, s, ow, oh, dst, filter);
+        if (rc == KE_EUNSUPPORTED) rc = resample_generic(ctx, s, ow, oh, dst, filter);
+        KE_TRY(rc);
+    }
+    return KE_OK;
+}
+
+namespace {
+
+// Tile aHash (src/ui/dup_refine_parallel.py:59-83): side = grid*tile luma thumbnail, one bit per pixel =
+// pixel > mean of its tile, bits in (gy, gx, ty, tx) order, packed little-endian.  `a > sum/T^2` is decided
+// in integers (a*T^2 > sum): exact for every tile size.
+__global__ __launch_bounds__(256) void ke_tile_ahash_kernel(const uint8_t *__restrict__ tiles, int grid, int tile,
+                                                            uint64_t *__restrict__ bits, int words) {
+    extern __shared__ uint32_t s_sum[];   // grid*grid tile sums
+    const int side = grid * tile, t2 = tile * tile;
+    const uint8_t *img = tiles + (size_t)blockIdx.x * side * side;
+    for (int g = threadIdx.x; g < grid * grid; g += 256) {
+        const int gy = g / grid, gx = g % grid;
+        uint32_t sum = 0;
+        for (int ty = 0; ty < tile; ++ty)
+            for (int tx = 0; tx < tile; ++tx) sum += img[(gy * tile + ty) * side + gx * tile + tx];
+        s_sum[g] = sum;
+    }
+    __syncthreads();
+    const int nbits = side * side;
+    for (int wd = threadIdx.x; wd < words; wd += 256) {
+        uint64_t v = 0;
+        for (int b = 0; b < 64; ++b) {
+            const int i = wd * 64 + b;
+            if (i >= nbits) break;
+            const int g = i / t2, r = i % t2;
+            const int gy = g / grid, gx = g % grid, ty = r / tile, tx = r % tile;
+            const uint32_t px = img[(gy * tile + ty) * side + gx * tile + tx];
+            if (px * (uint32_t)t2 > s_sum[g]) v |= 1ull << b;
+        }
+        bits[(size_t)blockIdx.x * words + wd] = v;
+    }
+}
+
+// Sum of absolute differences of two equally sized u8 thumbnails (the integer numerator of
+// _mae01, src/ui/dup_refine_parallel.py:208-210).
+__global__ __launch_bounds__(256) void ke_sad_pairs_kernel(const uint8_t *__restrict__ thumbs, int64_t pixels,
+                                                           const int64_t *__restrict__ pa, const int64_t *__restrict__ pb,
+                                                           uint64_t *__restrict__ out) {
+    __shared__ unsigned long long s_red[256];
+    const uint8_t *A = thumbs + (size_t)pa[blockIdx.x] * pixels, *B = thumbs + (size_t)pb[blockIdx.x] * pixels;
+    unsigned long long local = 0;
+    for (int64_t e = threadIdx.x; e < pixels; e += 256) {
+        const int d = (int)A[e] - (int)B[e];
+        local += (unsigned)(d < 0 ? -d : d);
+    }
+    s_red[threadIdx.x] = local;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) s_red[threadIdx.x] += s_red[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = s_red[0];
+}
+
+}  // namespace
+
+int ke_launch_tile_ahash(ke_ctx *ctx, const uint8_t *d_tiles, int64_t n, int grid, int tile, uint64_t *d_bits) {
+    const int side = grid * tile, words = (side * side + 63) / 64;
+    hipLaunchKernelGGL(ke_tile_ahash_kernel, dim3((unsigned)n), dim3(256), (size_t)grid * grid * sizeof(uint32_t), ctx->stream,
+                       d_tiles, grid, tile, d_bits, words);
+    KE_HIP(ctx, hipGetLastError());
+    return KE_OK;
+}
+
+int ke_launch_sad_pairs(ke_ctx *ctx, const uint8_t *d_thumbs, int64_t pixels, const int64_t *d_pa, const int64_t *d_pb,
+                        int64_t n_pairs, uint64_t *d_out) {
+    hipLaunchKernelGGL(ke_sad_pairs_kernel, dim3((unsigned)n_pairs), dim3(256), 0, ctx->stream, d_thumbs, pixels, d_pa, d_pb, d_out);
+    KE_HIP(ctx, hipGetLastError());
     return KE_OK;
 }

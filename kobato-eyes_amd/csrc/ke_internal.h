@@ -52,7 +52,7 @@ struct KeChunkTable {
 };
 
 
-void ke_build_axis_coeffs(int in_size, int out_size, KeAxisCoeffs &out);
+void ke_build_axis_coeffs(int in_size, int out_size, KeAxisCoeffs &out, int filter = KE_FILTER_LANCZOS);
 void ke_build_chunked(const KeAxisCoeffs &c, int cpo, KeChunkTable &out, int ndwc_multiple = 4);
 
 struct KeDevBuf {
@@ -86,7 +86,7 @@ struct ke_ctx {
     hipStream_t stream = nullptr;
     std::string err;
     KeDevBuf buf[KE_BUF_COUNT];
-    std::map<std::pair<int, int>, KeAxisCoeffs *> coeffs;
+    std::map<std::pair<int, int>, KeAxisCoeffs *> coeffs;   // key: (in_size, out_size * 4 + filter)
     hipEvent_t ev0[KE_T_COUNT] = {}, ev1[KE_T_COUNT] = {};
     bool ev_valid[KE_T_COUNT] = {};
 };
@@ -112,7 +112,7 @@ int ke_reserve(ke_ctx *ctx, int which, size_t bytes, void **out);
 // Returns in *dev a device pointer holding `bytes` of `p` (p itself if it already is device memory,
 // else a staged copy in buffer `which`).
 int ke_to_device(ke_ctx *ctx, const void *p, size_t bytes, int which, const void **dev);
-const KeAxisCoeffs *ke_get_coeffs(ke_ctx *ctx, int in_size, int out_size);
+const KeAxisCoeffs *ke_get_coeffs(ke_ctx *ctx, int in_size, int out_size, int filter = KE_FILTER_LANCZOS);
 const KeChunkTable *ke_get_chunks(ke_ctx *ctx, const KeAxisCoeffs *c, int cpo, int ndwc_multiple = 4);
 void ke_time_begin(ke_ctx *ctx, int kind);
 void ke_time_end(ke_ctx *ctx, int kind);
@@ -128,6 +128,11 @@ struct KeHashGroup {
 };
 int ke_launch_hash_group(ke_ctx *ctx, const KeHashGroup &g, uint64_t *d_phash, uint64_t *d_dhash,
                          uint8_t *d_tile32_out, uint8_t *d_tile98_out);
+// luma + resize of a group to (oh x ow) u8 tiles with the given filter (banded path, generic fallback)
+int ke_launch_resize_group(ke_ctx *ctx, const KeHashGroup &g, int ow, int oh, int filter, uint8_t *d_tiles);
+int ke_launch_tile_ahash(ke_ctx *ctx, const uint8_t *d_tiles, int64_t n, int grid, int tile, uint64_t *d_bits);
+int ke_launch_sad_pairs(ke_ctx *ctx, const uint8_t *d_thumbs, int64_t pixels, const int64_t *d_pa, const int64_t *d_pb,
+                        int64_t n_pairs, uint64_t *d_out);
 int ke_launch_scan(ke_ctx *ctx, const uint64_t *d_hashes, const int64_t *d_ids, const int64_t *d_sizes, int64_t n,
                    int part_index, int part_count, int threshold, int band_bits, int band_count, double size_ratio,
                    int64_t bucket_pair_cap, ke_edge *d_edges, int64_t capacity, unsigned long long *d_counters,

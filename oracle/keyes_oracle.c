@@ -59,12 +59,26 @@ static double ko_lanczos3(double x) {
     return 0.0;
 }
 
+/* Pillow BILINEAR ("triangle", support 1): the resize used by the shipped refine stage,
+ * src/ui/dup_refine_parallel.py:70 (32x32 tile-aHash thumbnail) and :204 (128x128 MAE thumbnail). */
+static double ko_triangle(double x) {
+    if (x < 0.0) x = -x;
+    return x < 1.0 ? 1.0 - x : 0.0;
+}
+
 /* Fills bounds[2*out_size] = (first tap, tap count) and kk[out_size*ksize].
  * Returns ksize, or <0 on allocation failure.  Caller frees *bounds_p, *kk_p. */
+static int ko_axis_coeffs(int in_size, int out_size, int filter, int32_t **bounds_p, int32_t **kk_p);
+
 KO_API int ko_lanczos_coeffs(int in_size, int out_size, int32_t **bounds_p, int32_t **kk_p) {
+    return ko_axis_coeffs(in_size, out_size, 0, bounds_p, kk_p);
+}
+
+/* filter: 0 = LANCZOS, 1 = BILINEAR */
+static int ko_axis_coeffs(int in_size, int out_size, int filter, int32_t **bounds_p, int32_t **kk_p) {
     double scale = (double)in_size / (double)out_size;
     double filterscale = scale < 1.0 ? 1.0 : scale;
-    double support = 3.0 * filterscale;
+    double support = (filter == 1 ? 1.0 : 3.0) * filterscale;
     int ksize = (int)ceil(support) * 2 + 1;
     int32_t *bounds = (int32_t *)malloc(sizeof(int32_t) * 2 * (size_t)out_size);
     int32_t *kk = (int32_t *)calloc((size_t)out_size * (size_t)ksize, sizeof(int32_t));
@@ -83,7 +97,7 @@ KO_API int ko_lanczos_coeffs(int in_size, int out_size, int32_t **bounds_p, int3
         xmax -= xmin;
         double ww = 0.0;
         for (int x = 0; x < xmax; x++) {
-            w[x] = ko_lanczos3((x + xmin - center + 0.5) * ss);
+            w[x] = filter == 1 ? ko_triangle((x + xmin - center + 0.5) * ss) : ko_lanczos3((x + xmin - center + 0.5) * ss);
             ww += w[x];
         }
         int32_t *k = kk + (size_t)xx * ksize;
@@ -110,29 +124,34 @@ static inline uint8_t ko_clip8(int32_t v) {
 
 /* L (h x w) -> out (oh x ow).  Horizontal pass first (only the rows the vertical
  * pass reads), u8 clip after each pass; a pass whose size is unchanged is skipped. */
-static int ko_resample_2pass(const uint8_t *L, int w, int h, int ow, int oh, uint8_t *out);
+static int ko_resample_2pass(const uint8_t *L, int w, int h, int ow, int oh, uint8_t *out, int filter);
+KO_API int ko_resample(const uint8_t *L, int w, int h, int ow, int oh, int filter, uint8_t *out);
 
 KO_API int ko_resample_lanczos(const uint8_t *L, int w, int h, int ow, int oh, uint8_t *out) {
+    return ko_resample(L, w, h, ow, oh, 0, out);
+}
+
+KO_API int ko_resample(const uint8_t *L, int w, int h, int ow, int oh, int filter, uint8_t *out) {
     if (w <= 0 || h <= 0 || ow <= 0 || oh <= 0) return -2;
     /* Pillow's Image.resize (PIL/Image.py, observed in 12.2.0): very tall, narrow images
      * shrink vertically first, as two separate single-axis resizes. */
     if ((int64_t)h > (int64_t)w * 100 && oh < h) {
         uint8_t *mid = (uint8_t *)malloc((size_t)w * (size_t)oh);
         if (!mid) return -1;
-        int rc = ko_resample_2pass(L, w, h, w, oh, mid);
-        if (rc == 0) rc = ko_resample_2pass(mid, w, oh, ow, oh, out);
+        int rc = ko_resample_2pass(L, w, h, w, oh, mid, filter);
+        if (rc == 0) rc = ko_resample_2pass(mid, w, oh, ow, oh, out, filter);
         free(mid);
         return rc;
     }
-    return ko_resample_2pass(L, w, h, ow, oh, out);
+    return ko_resample_2pass(L, w, h, ow, oh, out, filter);
 }
 
-static int ko_resample_2pass(const uint8_t *L, int w, int h, int ow, int oh, uint8_t *out) {
+static int ko_resample_2pass(const uint8_t *L, int w, int h, int ow, int oh, uint8_t *out, int filter) {
     int need_h = (ow != w), need_v = (oh != h);
     int32_t *bh = NULL, *kh = NULL, *bv = NULL, *kv = NULL;
     int ksh = 0, ksv = 0;
-    if (need_h && (ksh = ko_lanczos_coeffs(w, ow, &bh, &kh)) < 0) return -1;
-    if (need_v && (ksv = ko_lanczos_coeffs(h, oh, &bv, &kv)) < 0) { free(bh); free(kh); return -1; }
+    if (need_h && (ksh = ko_axis_coeffs(w, ow, filter, &bh, &kh)) < 0) return -1;
+    if (need_v && (ksv = ko_axis_coeffs(h, oh, filter, &bv, &kv)) < 0) { free(bh); free(kh); return -1; }
     const uint8_t *src = L;
     uint8_t *tmp = NULL;
     int src_w = w;
@@ -295,6 +314,24 @@ KO_API int ko_hash_batch(const uint8_t *px, int64_t n, int w, int h, int channel
         if (rc) return rc;
     }
     return 0;
+}
+
+/* Shipped refine stage, src/ui/dup_refine_parallel.py:59-83: side = grid*tile luma thumbnail -> one bit
+ * per pixel (pixel > float64 mean of its tile), order (gy, gx, ty, tx), np.packbits(bitorder="little").
+ * words_out: ceil(side*side/64) little-endian u64 words. */
+KO_API void ko_tile_ahash(const uint8_t *thumb, int grid, int tile, uint64_t *words_out) {
+    int side = grid * tile, nbits = side * side, i = 0;
+    for (int k = 0; k < (nbits + 63) / 64; k++) words_out[k] = 0;
+    for (int gy = 0; gy < grid; gy++)
+        for (int gx = 0; gx < grid; gx++) {
+            double sum = 0.0;
+            for (int ty = 0; ty < tile; ty++)
+                for (int tx = 0; tx < tile; tx++) sum += thumb[(gy * tile + ty) * side + gx * tile + tx];
+            double mean = sum / (double)(tile * tile);
+            for (int ty = 0; ty < tile; ty++)
+                for (int tx = 0; tx < tile; tx++, i++)
+                    if ((double)thumb[(gy * tile + ty) * side + gx * tile + tx] > mean) words_out[i >> 6] |= 1ull << (i & 63);
+        }
 }
 
 /* ------------------------------------------------------------------------- */

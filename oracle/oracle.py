@@ -55,6 +55,10 @@ def lib() -> C.CDLL:
         L.ko_free.argtypes = [C.c_void_p]
         L.ko_resample_lanczos.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.ko_resample_lanczos.restype = C.c_int
+        L.ko_resample.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.ko_resample.restype = C.c_int
+        L.ko_tile_ahash.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.ko_tile_ahash.restype = None
         L.ko_dct8x8.argtypes = [C.c_void_p, C.c_void_p]
         L.ko_phash_from_tile.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         L.ko_phash_from_tile.restype = C.c_uint64
@@ -115,6 +119,35 @@ def resample(L: np.ndarray, ow: int, oh: int) -> np.ndarray:
     if rc:
         raise ValueError(f"ko_resample_lanczos rc={rc}")
     return out
+
+
+def resample_filter(L: np.ndarray, ow: int, oh: int, filter: int) -> np.ndarray:
+    """filter 0 = LANCZOS, 1 = BILINEAR (Pillow's 8-bit resampler either way)."""
+    L = np.ascontiguousarray(L, dtype=np.uint8)
+    out = np.empty((oh, ow), dtype=np.uint8)
+    rc = lib().ko_resample(_ptr(L), L.shape[1], L.shape[0], ow, oh, filter, _ptr(out))
+    if rc:
+        raise ValueError(f"ko_resample rc={rc}")
+    return out
+
+
+def tile_ahash_bits(px: np.ndarray, grid: int = 4, tile: int = 8) -> int:
+    """src/ui/dup_refine_parallel.py:59-83 on decoded pixels (HxW, HxWx3 or HxWx4)."""
+    side = grid * tile
+    thumb = resample_filter(luma(px), side, side, 1)
+    words = np.zeros((side * side + 63) // 64, np.uint64)
+    lib().ko_tile_ahash(_ptr(thumb), grid, tile, _ptr(words))
+    return int.from_bytes(words.tobytes(), "little")
+
+
+def small_gray(px: np.ndarray, size: int = 128) -> np.ndarray:
+    """src/ui/dup_refine_parallel.py:203-207."""
+    return resample_filter(luma(px), size, size, 1)
+
+
+def mae01(a: np.ndarray, b: np.ndarray) -> float:
+    """src/ui/dup_refine_parallel.py:208-210."""
+    return float(np.mean(np.abs(a.astype(np.int16) - b.astype(np.int16))) / 255.0)
 
 
 def dct8x8(tile32: np.ndarray) -> np.ndarray:

@@ -66,3 +66,26 @@ def files_to_arrays(files):
     ids = np.array([f["file_id"] for f in files], dtype=np.int64)
     sizes = np.array([(f["size"] or 0) for f in files], dtype=np.int64)
     return hashes, ids, sizes
+
+
+def refine_parallel_golden():
+    with open(os.path.join(GOLDEN, "refine_parallel_golden.json")) as fh:
+        return json.load(fh)
+
+
+def refine_corpus():
+    """The same (name, pixels) list make_golden.py wrote to PNG files for the reference."""
+    from oracle import oracle as O
+
+    items = []
+    for i in (7, 19, 17, 29, 15, 39, 0, 1):
+        items.append((f"v{i:03d}_256", O.synth_rgb(i, 256, 256)))
+    for (i, w, h) in [(2, 300, 451), (3, 512, 512), (4, 64, 48), (5, 1000, 37), (6, 33, 200), (8, 16, 16)]:
+        items.append((f"s{i:03d}_{w}x{h}", O.synth_rgb(i, w, h)))
+    rng = np.random.default_rng(21)
+    items.append(("gray_L", rng.integers(0, 256, (90, 120), dtype=np.uint8)))
+    items.append(("rgba", rng.integers(0, 256, (77, 91, 4), dtype=np.uint8)))
+    shifted = O.synth_rgb(7, 256, 256).astype(np.int16)
+    shifted[:, :, :] += 2
+    items.append(("v007_plus2", np.clip(shifted, 0, 255).astype(np.uint8)))
+    return items

@@ -317,9 +317,89 @@ def make_ssim():
     print("ssim:", dict(zip(store["names"].tolist(), store["ssim"].round(6).tolist())))
 
 
+# ------------------------------------------------------------------ shipped refine stage
+def refine_corpus():
+    """(name, pixel array) list; PNG round trips are lossless, so tests rebuild the very same files."""
+    items = []
+    for i in (7, 19, 17, 29, 15, 39, 0, 1):                     # bases and their planted variants
+        items.append((f"v{i:03d}_256", O.synth_rgb(i, 256, 256)))
+    for (i, w, h) in [(2, 300, 451), (3, 512, 512), (4, 64, 48), (5, 1000, 37), (6, 33, 200), (8, 16, 16)]:
+        items.append((f"s{i:03d}_{w}x{h}", O.synth_rgb(i, w, h)))
+    rng = np.random.default_rng(21)
+    items.append(("gray_L", rng.integers(0, 256, (90, 120), dtype=np.uint8)))
+    items.append(("rgba", rng.integers(0, 256, (77, 91, 4), dtype=np.uint8)))
+    shifted = O.synth_rgb(7, 256, 256).astype(np.int16)
+    shifted[:, :, :] += 2
+    items.append(("v007_plus2", np.clip(shifted, 0, 255).astype(np.uint8)))
+    return items
+
+
+def make_refine_parallel():
+    import tempfile
+    from dataclasses import dataclass
+
+    import ui.dup_refine_parallel as R
+
+    @dataclass
+    class F:
+        file_id: int
+        path: Path
+
+    @dataclass
+    class E:
+        file: F
+
+    @dataclass
+    class Cl:
+        files: list
+        keeper_id: int
+
+    out = {"cases": {}, "clusters": []}
+    with tempfile.TemporaryDirectory() as td:
+        paths = {}
+        for name, arr in refine_corpus():
+            p = Path(td) / f"{name}.png"
+            Image.fromarray(arr).save(p)
+            paths[name] = p
+        thumbs = {}
+        for name, p in paths.items():
+            thumbs[name] = R._load_small_gray(p, 128)
+            out["cases"][name] = {
+                "ahash": {f"{g}x{t}": format(R.tile_ahash_bits(p, grid=g, tile=t), "x") for g, t in ((4, 8), (2, 16), (8, 4), (3, 5))},
+                "thumb128_sha256": sha(thumbs[name]),
+                "thumb64_sha256": sha(R._load_small_gray(p, 64)),
+            }
+        names = list(paths)
+        out["mae"] = [[a, b, R._mae01(thumbs[a], thumbs[b])] for a, b in
+                      [("v007_256", "v019_256"), ("v017_256", "v029_256"), ("v007_256", "v007_plus2"), ("v000_256", "v001_256"),
+                       ("gray_L", "rgba"), ("s003_512x512", "v007_256")]]
+        ids = {n: k + 1 for k, n in enumerate(names)}
+        groups = [(["v007_256", "v019_256", "v007_plus2", "v000_256"], "v007_256"), (["v017_256", "v029_256"], "v029_256"),
+                  (["v015_256", "v039_256", "s003_512x512"], "v015_256"), (["gray_L", "rgba"], "gray_L"),
+                  (["v000_256", "v001_256"], "v001_256")]
+        clusters = [Cl([E(F(ids[n], paths[n])) for n in members], ids[keeper]) for members, keeper in groups]
+        out["cluster_inputs"] = [{"members": m, "keeper": k} for m, k in groups]
+        for max_bits in (32, 200, 8):
+            res = R.refine_by_tilehash_parallel(clusters, grid=4, tile=8, max_bits=max_bits, io_workers=2)
+            out["clusters"].append({"stage": "tilehash", "max_bits": max_bits,
+                                    "result": [[cl.keeper_id, [e.file.file_id for e in cl.files]] for cl in res]})
+        for thr in (0.004, 0.006, 0.05):
+            res = R.refine_by_pixels_parallel(clusters, mae_thr=thr, thumb_size=128, workers=1)
+            out["clusters"].append({"stage": "pixels", "mae_thr": thr,
+                                    "result": sorted([cl.keeper_id, [e.file.file_id for e in cl.files]] for cl in res)})
+        out["ids"] = ids
+    with open(os.path.join(HERE, "refine_parallel_golden.json"), "w") as fh:
+        json.dump(out, fh, indent=1)
+    print("refine_parallel:", len(out["cases"]), "files;", [(c["stage"], len(c["result"])) for c in out["clusters"]], "mae", [round(m[2], 5) for m in out["mae"]])
+
+
 if __name__ == "__main__":
     logging.basicConfig(level=logging.WARNING)
+    if "--only-refine-parallel" in sys.argv:
+        make_refine_parallel()
+        raise SystemExit(0)
     make_sig()
     make_scan()
     make_rows()
     make_ssim()
+    make_refine_parallel()

@@ -135,3 +135,71 @@ def test_find_duplicates_and_headless_scan(K, tmp_path):
     strict = K.find_duplicates(rows, hamming_threshold=8, ssim_threshold=0.999)
     loose = K.find_duplicates(rows, hamming_threshold=8, ssim_threshold=0.5)
     assert strict == [] and len(loose) == len(plain)
+
+
+def test_shipped_refine_stage_kernels_and_dropins(K, tmp_path):
+    """ke_resize_luma_uniform (BILINEAR) + ke_tile_ahash + ke_sad_pairs and the ui.dup_refine_parallel drop-ins
+    against what the reference itself produced for the same files (tests/golden/refine_parallel_golden.json)."""
+    import hashlib
+    from dataclasses import dataclass
+
+    import _golden as G
+    from kobato_eyes_amd import refine_parallel as RP
+
+    g = G.refine_parallel_golden()
+    ctx = K._native.get_context(0)
+    paths, thumbs = {}, {}
+    for name, px in G.refine_corpus():
+        p = tmp_path / f"{name}.png"
+        Image.fromarray(px).save(p)
+        paths[name] = p
+        exp = g["cases"][name]
+        for key, hexbits in exp["ahash"].items():
+            grid, tile = (int(v) for v in key.split("x"))
+            assert format(K.tile_ahash_bits(p, grid=grid, tile=tile), "x") == hexbits, (name, key)
+        thumbs[name] = RP._load_small_gray(p, 128)
+        assert hashlib.sha256(thumbs[name].tobytes()).hexdigest() == exp["thumb128_sha256"], name
+        assert hashlib.sha256(RP._load_small_gray(p, 64).tobytes()).hexdigest() == exp["thumb64_sha256"], name
+        h, w = px.shape[:2]
+        ch = 1 if px.ndim == 2 else px.shape[2]
+        lan = ctx.resize_luma_uniform(px[None], 1, w, h, ch, 32, 32, filter=0)[0]      # LANCZOS through the same entry point
+        assert np.array_equal(lan, O.hash_image(px, want_tiles=True)[2]), name
+    for a, b, mae in g["mae"]:
+        assert RP._mae01(thumbs[a], thumbs[b]) == mae
+
+    @dataclass
+    class F:
+        file_id: int
+        path: object
+
+    @dataclass
+    class E:
+        file: F
+
+    @dataclass
+    class Cl:
+        files: list
+        keeper_id: int
+
+    ids = g["ids"]
+    clusters = [Cl([E(F(ids[n], paths[n])) for n in c["members"]], ids[c["keeper"]]) for c in g["cluster_inputs"]]
+    ticks = []
+    for case in g["clusters"]:
+        if case["stage"] == "tilehash":
+            res = K.refine_by_tilehash_parallel(clusters, grid=4, tile=8, max_bits=case["max_bits"], io_workers=2,
+                                                tick=lambda d, t, phase: ticks.append((phase, d, t)))
+            got = [[cl.keeper_id, [e.file.file_id for e in cl.files]] for cl in res]
+            assert got == case["result"], case
+            assert all(isinstance(cl, Cl) for cl in res)
+        else:
+            res = K.refine_by_pixels_parallel(clusters, mae_thr=case["mae_thr"], thumb_size=128, workers=2)
+            assert sorted([cl.keeper_id, [e.file.file_id for e in cl.files]] for cl in res) == case["result"], case
+    assert (1, 12, 12) in ticks and (2, 5, 5) in ticks              # progress at the end of each phase
+    assert K.refine_by_tilehash_parallel(clusters, is_cancelled=lambda: True) == []
+    broken = tmp_path / "broken.png"
+    broken.write_bytes(b"nope")
+    bad = [Cl([E(F(1, paths["v007_256"])), E(F(2, broken)), E(F(3, paths["v019_256"]))], 1)]
+    res = K.refine_by_tilehash_parallel(bad, max_bits=200)          # unreadable member skipped, cluster survives
+    assert [[cl.keeper_id, [e.file.file_id for e in cl.files]] for cl in res] == [[1, [1, 3]]]
+    res = K.refine_by_pixels_parallel(bad, mae_thr=0.05)
+    assert [[cl.keeper_id, [e.file.file_id for e in cl.files]] for cl in res] == [[1, [1, 3]]]

@@ -130,3 +130,30 @@ def test_synth_generator_is_stable():
     assert not O.synth_info(18)[2]
     h = O.synth_hashes(1000)
     assert len(np.unique(h[:900])) == 900
+
+
+def test_shipped_refine_stage_matches_reference():
+    """Oracle restatement of ui.dup_refine_parallel (tile aHash, 128x128 BILINEAR thumbnails, MAE) against the
+    values the reference produced on the same images (tests/golden/refine_parallel_golden.json)."""
+    g = G.refine_parallel_golden()
+    thumbs = {}
+    for name, px in G.refine_corpus():
+        exp = g["cases"][name]
+        for key, hexbits in exp["ahash"].items():
+            grid, tile = (int(v) for v in key.split("x"))
+            assert format(O.tile_ahash_bits(px, grid, tile), "x") == hexbits, (name, key)
+        thumbs[name] = O.small_gray(px, 128)
+        assert hashlib.sha256(thumbs[name].tobytes()).hexdigest() == exp["thumb128_sha256"], name
+        assert hashlib.sha256(O.small_gray(px, 64).tobytes()).hexdigest() == exp["thumb64_sha256"], name
+    for a, b, mae in g["mae"]:
+        assert O.mae01(thumbs[a], thumbs[b]) == mae
+
+
+def test_bilinear_resample_matches_installed_pillow():
+    Image = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(8)
+    for (w, h) in [(512, 512), (300, 451), (16, 16), (1000, 37), (2, 500), (127, 129), (4096, 64)]:
+        arr = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        for (ow, oh) in [(32, 32), (128, 128), (16, 24)]:
+            ref = np.asarray(Image.fromarray(arr).resize((ow, oh), Image.Resampling.BILINEAR))
+            assert np.array_equal(O.resample_filter(arr, ow, oh, 1), ref), (w, h, ow, oh)

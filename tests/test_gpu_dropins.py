@@ -203,3 +203,52 @@ def test_shipped_refine_stage_kernels_and_dropins(K, tmp_path):
     assert [[cl.keeper_id, [e.file.file_id for e in cl.files]] for cl in res] == [[1, [1, 3]]]
     res = K.refine_by_pixels_parallel(bad, mae_thr=0.05)
     assert [[cl.keeper_id, [e.file.file_id for e in cl.files]] for cl in res] == [[1, [1, 3]]]
+
+
+def test_cli_scan_dups_over_sqlite(K, tmp_path):
+    """Headless scan of a database laid out like the reference's (files + signatures), CSV in the reference's layout."""
+    import csv
+
+    from kobato_eyes_amd import cli
+
+    db = tmp_path / "kobato.db"
+    conn = sqlite3.connect(db)
+    conn.execute("CREATE TABLE files (id INTEGER PRIMARY KEY AUTOINCREMENT, path TEXT NOT NULL UNIQUE, size INTEGER, "
+                 "is_present INTEGER NOT NULL DEFAULT 1, width INTEGER, height INTEGER)")
+    conn.execute("CREATE TABLE signatures (file_id INTEGER PRIMARY KEY, phash_u64 INTEGER NOT NULL, dhash_u64 INTEGER NOT NULL)")
+    idx = sorted({19, 29, O.synth_info(19)[0], O.synth_info(29)[0], 0, 1, 2})
+    rows, arrays = [], {}
+    for i in idx:
+        arr = O.synth_rgb(i, 256, 256)
+        p = tmp_path / f"f_{i:03d}.png"
+        Image.fromarray(arr).save(p)
+        cur = conn.execute("INSERT INTO files (path, size, width, height) VALUES (?, ?, 256, 256)", (str(p), p.stat().st_size))
+        rows.append({"file_id": cur.lastrowid, "path": str(p), "size": p.stat().st_size, "width": 256, "height": 256})
+        arrays[cur.lastrowid] = arr
+    conn.execute("INSERT INTO files (path, size, is_present) VALUES (?, 1, 0)", (str(tmp_path / "gone.png"),))   # not present
+    conn.execute("INSERT INTO files (path, size) VALUES (?, 1)", (str(tmp_path / "missing.png"),))               # unreadable -> skipped
+    # one signature is already stored (resume): it must be used, not recomputed
+    first = rows[0]["file_id"]
+    ep, ed = O.hash_image(arrays[first])
+    conn.execute("INSERT INTO signatures VALUES (?, ?, ?)", (first, O.to_signed64(ep), O.to_signed64(ed)))
+    conn.commit()
+    conn.close()
+    out_csv = tmp_path / "dups.csv"
+    assert cli.main(["scan-dups", "--db", str(db), "--hamming", "8", "--csv", str(out_csv)]) == 0
+    hashes = np.array([O.hash_image(arrays[r["file_id"]])[0] for r in rows], np.uint64)
+    ids = np.array([r["file_id"] for r in rows], np.int64)
+    e, _ = O.scan_banded(hashes, ids, threshold=8)
+    exp = O.assemble_clusters(rows, [(int(ids[x["a"]]), int(ids[x["b"]]), int(x["h"])) for x in e])
+    with open(out_csv, newline="") as fh:
+        got = list(csv.reader(fh))
+    assert got[0] == ["group", "file_id", "path", "size", "width", "height", "keeper", "hamming"]
+    by_id = {r["file_id"]: r for r in rows}
+    want = []
+    for gi, (keeper, entries) in enumerate(exp, 1):
+        for fid, best in entries:
+            r = by_id[fid]
+            want.append([str(gi), str(fid), Path(r["path"]).as_posix(), str(r["size"]), "256", "256", "1" if fid == keeper else "0",
+                         "" if best is None else str(best)])
+    assert got[1:] == want and len(exp) >= 1
+    stored = sqlite3.connect(db).execute("SELECT COUNT(*) FROM signatures").fetchone()[0]
+    assert stored == len(rows)                                       # every readable present file now has a row

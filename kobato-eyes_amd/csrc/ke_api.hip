@@ -360,19 +360,44 @@ KE_API int ke_hash_images(ke_ctx *ctx, const uint8_t *pixels, const uint64_t *of
         KE_HIP(ctx, hipMemsetAsync(d_dh, 0, (size_t)n * 8, ctx->stream));
     }
     ke_time_begin(ctx, KE_T_HASH);
-    for (auto &kv : groups) {
-        const int w = kv.first.first, h = kv.first.second;
-        const size_t img_bytes = (size_t)w * h * channels;
-        const std::vector<int64_t> &idx = kv.second;
-        const int64_t chunk = std::max<int64_t>(1, (int64_t)(kStageBytes / img_bytes));
-        for (size_t first = 0; first < idx.size(); first += (size_t)chunk) {
-            const int64_t m = (int64_t)std::min<size_t>((size_t)chunk, idx.size() - first);
-            std::vector<uint64_t> goff((size_t)m);
-            std::vector<int64_t> gidx(idx.begin() + first, idx.begin() + first + m);
-            const uint8_t *d_px = pixels;
-            if (in_dev) {
-                for (int64_t k = 0; k < m; ++k) goff[k] = off[gidx[k]];
-            } else {
+    if (in_dev) {
+        // device-resident batch: one metadata upload for all shape groups ([offsets | output slots] per group),
+        // then the groups are launched back to back with no host synchronisation in between
+        std::vector<uint64_t> meta_h((size_t)2 * n);
+        size_t cursor = 0;
+        std::vector<std::pair<size_t, size_t>> spans;   // (meta offset, count) per group, in map order
+        for (auto &kv : groups) {
+            const std::vector<int64_t> &idx = kv.second;
+            spans.emplace_back(cursor, idx.size());
+            for (size_t k = 0; k < idx.size(); ++k) {
+                meta_h[cursor + k] = off[idx[k]];
+                meta_h[cursor + idx.size() + k] = (uint64_t)idx[k];
+            }
+            cursor += 2 * idx.size();
+        }
+        void *meta;
+        KE_TRY(ke_reserve(ctx, KE_BUF_META, std::max<size_t>(cursor, 2) * 8, &meta));
+        if (cursor) KE_HIP(ctx, hipMemcpyAsync(meta, meta_h.data(), cursor * 8, hipMemcpyHostToDevice, ctx->stream));
+        KE_HIP(ctx, hipStreamSynchronize(ctx->stream));   // meta_h is a local
+        size_t gi = 0;
+        for (auto &kv : groups) {
+            const int w = kv.first.first, h = kv.first.second;
+            const uint64_t *d_off = (const uint64_t *)meta + spans[gi].first;
+            const int64_t m = (int64_t)spans[gi].second;
+            KeHashGroup g{pixels, d_off, (uint64_t)w * h * channels, (const int64_t *)(d_off + m), m, w, h, channels};
+            KE_TRY(ke_launch_hash_group(ctx, g, d_ph, d_dh, nullptr, nullptr));
+            ++gi;
+        }
+    } else {
+        for (auto &kv : groups) {
+            const int w = kv.first.first, h = kv.first.second;
+            const size_t img_bytes = (size_t)w * h * channels;
+            const std::vector<int64_t> &idx = kv.second;
+            const int64_t chunk = std::max<int64_t>(1, (int64_t)(kStageBytes / img_bytes));
+            for (size_t first = 0; first < idx.size(); first += (size_t)chunk) {
+                const int64_t m = (int64_t)std::min<size_t>((size_t)chunk, idx.size() - first);
+                std::vector<uint64_t> goff((size_t)m);
+                std::vector<int64_t> gidx(idx.begin() + first, idx.begin() + first + m);
                 // pack this chunk of host images into the staging buffer
                 KE_TRY(ke_reserve(ctx, KE_BUF_PIXELS, (size_t)m * img_bytes, &tmp));
                 for (int64_t k = 0; k < m; ++k) {
@@ -380,17 +405,16 @@ KE_API int ke_hash_images(ke_ctx *ctx, const uint8_t *pixels, const uint64_t *of
                     KE_HIP(ctx, hipMemcpyAsync((uint8_t *)tmp + goff[k], pixels + off[gidx[k]], img_bytes,
                                                hipMemcpyHostToDevice, ctx->stream));
                 }
-                d_px = (const uint8_t *)tmp;
+                void *meta;
+                KE_TRY(ke_reserve(ctx, KE_BUF_META, (size_t)m * 16, &meta));
+                KE_HIP(ctx, hipMemcpyAsync(meta, goff.data(), (size_t)m * 8, hipMemcpyHostToDevice, ctx->stream));
+                KE_HIP(ctx, hipMemcpyAsync((uint8_t *)meta + (size_t)m * 8, gidx.data(), (size_t)m * 8,
+                                           hipMemcpyHostToDevice, ctx->stream));
+                KeHashGroup g{(const uint8_t *)tmp, (const uint64_t *)meta, img_bytes,
+                              (const int64_t *)((uint8_t *)meta + (size_t)m * 8), m, w, h, channels};
+                KE_TRY(ke_launch_hash_group(ctx, g, d_ph, d_dh, nullptr, nullptr));
+                KE_HIP(ctx, hipStreamSynchronize(ctx->stream));  // goff/gidx and the staging buffers are reused
             }
-            void *meta;
-            KE_TRY(ke_reserve(ctx, KE_BUF_META, (size_t)m * 16, &meta));
-            KE_HIP(ctx, hipMemcpyAsync(meta, goff.data(), (size_t)m * 8, hipMemcpyHostToDevice, ctx->stream));
-            KE_HIP(ctx, hipMemcpyAsync((uint8_t *)meta + (size_t)m * 8, gidx.data(), (size_t)m * 8,
-                                       hipMemcpyHostToDevice, ctx->stream));
-            KeHashGroup g{d_px, (const uint64_t *)meta, img_bytes, (const int64_t *)((uint8_t *)meta + (size_t)m * 8),
-                          m, w, h, channels};
-            KE_TRY(ke_launch_hash_group(ctx, g, d_ph, d_dh, nullptr, nullptr));
-            KE_HIP(ctx, hipStreamSynchronize(ctx->stream));  // goff/gidx and the staging buffers are reused
         }
     }
     ke_time_end(ctx, KE_T_HASH);

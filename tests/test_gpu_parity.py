@@ -253,3 +253,47 @@ def test_mixed_resolution_batch_like_config5(ctx):
     assert status.tolist() == [0] * len(imgs)
     for k, im in enumerate(imgs):
         assert (int(ph[k]), int(dh[k])) == O.hash_image(im), shapes[k]
+
+
+def test_abi_edge_cases(ctx):
+    """Empty inputs, per-image failure status (the reference drops failed images, src/core/fastsig.py:36-37),
+    argument validation with the reference's messages where it has them."""
+    import ctypes as C
+
+    lib, h = ctx._lib, ctx._h
+    assert lib.ke_hash_uniform(h, None, 0, 8, 8, 3, None, None) == 0
+    n_edges = C.c_int64(-1)
+    assert lib.ke_hamming_scan(h, None, None, None, 0, 0, 1, 8, 16, 4, 0.0, 0, None, 0, C.byref(n_edges), None) == 0 and n_edges.value == 0
+    one = np.array([5], np.uint64)
+    assert lib.ke_hamming_scan(h, one.ctypes.data, None, None, 1, 0, 1, 8, 16, 4, 0.0, 0, None, 0, C.byref(n_edges), None) == 0
+    assert n_edges.value == 0
+    # ragged batch with a zero-sized member: status 1, hash 0, the others unaffected
+    good = O.synth_rgb(3, 64, 48)
+    flat = np.concatenate([good.reshape(-1), good.reshape(-1)])
+    offsets = np.array([0, good.size, good.size], np.uint64)
+    widths, heights = np.array([64, 0, 64], np.int32), np.array([48, 48, 48], np.int32)
+    ph, dh, st = np.full(3, 7, np.uint64), np.full(3, 7, np.uint64), np.zeros(3, np.int32)
+    rc = lib.ke_hash_images(h, flat.ctypes.data, offsets.ctypes.data, widths.ctypes.data, heights.ctypes.data, 3, 3,
+                            ph.ctypes.data, dh.ctypes.data, st.ctypes.data)
+    assert rc == 0 and st.tolist() == [0, 1, 0]
+    ep, ed = O.hash_image(good)
+    assert ph.tolist() == [ep, 0, ep] and dh.tolist() == [ed, 0, ed]
+    for call, msg in [
+        (lambda: ctx.hamming_scan(np.zeros(4, np.uint64), 4, band_bits=0), "band_bits must be positive"),
+        (lambda: ctx.hamming_scan(np.zeros(4, np.uint64), 4, band_count=0), "band_count must be positive"),
+        (lambda: ctx.hamming_scan(np.zeros(4, np.uint64), 4, threshold=-1), r"hamming_threshold must be in \[0, 64\]"),
+        (lambda: ctx.hamming_scan(np.zeros(4, np.uint64), 4, band_bits=17, band_count=4), "band config too large"),
+        (lambda: ctx.ssim_pairs_uniform(np.zeros((2, 8, 8), np.uint8), 2, 8, 8, 1, [0], [2]), "outside"),
+        (lambda: ctx.sad_pairs(np.zeros((2, 16), np.uint8), 2, 16, [3], [0]), "outside"),
+        (lambda: ctx.resize_luma_uniform(np.zeros((1, 8, 8), np.uint8), 1, 8, 8, 1, 4, 4, filter=7), "unknown filter"),
+        (lambda: ctx.tile_ahash(np.zeros((1, 4, 4), np.uint8), 1, 0, 4), "bad grid"),
+    ]:
+        with pytest.raises(ValueError, match=msg):
+            call()
+    with pytest.raises(RuntimeError, match="needs band_bits <= 24"):
+        ctx.hamming_scan(np.zeros(4, np.uint64), 4, band_bits=32, band_count=2, bucket_pair_cap=10)
+    # a 1 x 1 image and a 1-pixel-wide strip still hash (generic passes)
+    for shape in [(1, 1, 3), (300, 1, 3), (1, 300, 3)]:
+        px = np.random.default_rng(1).integers(0, 256, shape, dtype=np.uint8)
+        p, d = ctx.hash_uniform(px[None], 1, shape[1], shape[0], 3)
+        assert (int(p[0]), int(d[0])) == O.hash_image(px)

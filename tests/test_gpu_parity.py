@@ -297,3 +297,34 @@ def test_abi_edge_cases(ctx):
         px = np.random.default_rng(1).integers(0, 256, shape, dtype=np.uint8)
         p, d = ctx.hash_uniform(px[None], 1, shape[1], shape[0], 3)
         assert (int(p[0]), int(d[0])) == O.hash_image(px)
+
+
+def test_random_shapes_stress(ctx):
+    """Seeded sweep over odd shapes and channel counts (band boundaries, funnel-shift loader, chunk counts,
+    tiny and extreme aspect ratios): tiles and both hashes bit-exact against the oracle."""
+    rng = np.random.default_rng(20260604)
+    shapes = []
+    for _ in range(40):
+        w = int(rng.choice([rng.integers(1, 40), rng.integers(40, 700), rng.integers(700, 2600)]))
+        h = int(rng.choice([rng.integers(1, 40), rng.integers(40, 700), rng.integers(700, 2600)]))
+        shapes.append((w, h, int(rng.choice([1, 3, 3, 3, 4]))))
+    shapes += [(4, 1, 3), (1, 4, 3), (2, 2, 3), (3, 3, 1), (7, 1500, 3), (1500, 7, 3), (2047, 33, 3), (33, 2047, 3), (8192, 8, 3),
+               (5000, 12, 3), (12, 5000, 3), (515, 481, 3), (512, 1537, 3), (256, 15, 3), (384, 32, 3), (511, 512, 4)]
+    for (w, h, ch) in shapes:
+        n = 3 if w * h < 400000 else 1
+        px = rng.integers(0, 256, (n, h, w) if ch == 1 else (n, h, w, ch), dtype=np.uint8)
+        got_p, got_d = ctx.hash_uniform(px, n, w, h, ch)
+        t32, t98 = ctx.luma_tiles_uniform(px, n, w, h, ch)
+        for k in range(n):
+            ep, ed, e32, e98, _ = O.hash_image(px[k], want_tiles=True)
+            assert np.array_equal(t32[k], e32), (w, h, ch, k, "tile32")
+            assert np.array_equal(t98[k], e98), (w, h, ch, k, "tile98")
+            assert (int(got_p[k]), int(got_d[k])) == (ep, ed), (w, h, ch, k)
+        if w >= 7 and h >= 7 and n >= 2:
+            s = ctx.ssim_pairs_uniform(px, n, w, h, ch, [0], [1])[0]
+            la = px[0] if ch == 1 else O.luma(px[0])
+            lb = px[1] if ch == 1 else O.luma(px[1])
+            assert abs(s - O.ssim_luma(la, lb)) <= 1e-6, (w, h, ch)
+        thumbs = ctx.resize_luma_uniform(px, n, w, h, ch, 128, 128, filter=1)
+        for k in range(n):
+            assert np.array_equal(thumbs[k], O.small_gray(px[k], 128)), (w, h, ch, k, "bilinear")

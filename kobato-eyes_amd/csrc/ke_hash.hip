@@ -193,7 +193,11 @@ __device__ __forceinline__ uint32_t luma4_biased(uint32_t d0, uint32_t d1, uint3
     const uint32_t s1 = (__builtin_amdgcn_udot4(p1, CHI, 0u, false) << 8) + __builtin_amdgcn_udot4(p1, CLO, START, false);
     const uint32_t s2 = (__builtin_amdgcn_udot4(p2, CHI, 0u, false) << 8) + __builtin_amdgcn_udot4(p2, CLO, START, false);
     const uint32_t s3 = (__builtin_amdgcn_udot4(p3, CHI, 0u, false) << 8) + __builtin_amdgcn_udot4(p3, CLO, START, false);
-    return ((s0 >> 16) & 0xFFu) | ((s1 >> 8) & 0xFF00u) | (s2 & 0xFF0000u) | ((s3 << 8) & 0xFF000000u);
+    // byte 2 of each sum -> one dword: two v_perm_b32 (selector bytes pick from {s_odd[3:0] = 4..7, s_even[3:0] = 0..3})
+    // and one v_bfi_b32 instead of shift/and/or chains (the VALU issue rate bounds this kernel)
+    const uint32_t lo = __builtin_amdgcn_perm(s1, s0, 0x0C0C0602u);   // [s0.b2, s1.b2, 0, 0]
+    const uint32_t hi = __builtin_amdgcn_perm(s3, s2, 0x06020C0Cu);   // [0, 0, s2.b2, s3.b2]
+    return lo | hi;
 }
 
 __device__ __forceinline__ int combine_planes(int d0, int d1, int d2, int bias) {
@@ -276,14 +280,22 @@ __global__ __launch_bounds__(256, (NDWD > 0 ? 2 : 3)) void ke_phash_fused(const 
     // live inside one iteration only (a loop-carried register set makes hipcc wait for the loads
     // right after issuing them).
     uint32_t raw[QPT][3];
+    // byte offset of this thread's quads inside a tile: loop invariant, so a load is (scalar tile base) +
+    // (clamped 32-bit offset) -- one v_min per load instead of 64-bit address arithmetic
+    uint32_t voff[QPT];
+#pragma unroll
+    for (int q = 0; q < QPT; ++q) voff[q] = (uint32_t)(q * 256 + tid) * 12u;
+    const uint32_t image_bytes = (uint32_t)total_quads * 12u;   // h <= 1536, W <= 512: fits easily
     auto load_tile = [&](int t) {
+        const uint32_t tile_off = (uint32_t)t * (uint32_t)(QUADS_PER_TILE * 12);
+        const uint8_t *tile_ptr = src + tile_off;                 // wave-uniform
+        const uint32_t lim = image_bytes - 12u - tile_off;        // last loadable quad, relative to the tile
 #pragma unroll
         for (int q = 0; q < QPT; ++q) {
             // Unconditional loads (a guarded load makes hipcc wait vmcnt(0) after each one): quads past
             // the image end re-read the last quad; those rows only ever meet zero tap weights.
-            int gq = t * QUADS_PER_TILE + q * 256 + tid;
-            gq = gq < total_quads ? gq : total_quads - 1;
-            const uint32_t *p = reinterpret_cast<const uint32_t *>(src + (size_t)gq * 12);
+            const uint32_t off = voff[q] < lim ? voff[q] : lim;
+            const uint32_t *p = reinterpret_cast<const uint32_t *>(tile_ptr + off);
             // streamed once: non-temporal loads (+1.4 % measured, interleaved A/B on 100k x 512^2)
             raw[q][0] = __builtin_nontemporal_load(p);
             raw[q][1] = __builtin_nontemporal_load(p + 1);
@@ -586,19 +598,23 @@ __global__ __launch_bounds__(256, 3) void ke_hband(const KeBandArgs a) {
     }
 
     uint32_t raw[QPT][DW];
+    // a load = (wave-uniform tile pointer) + (clamped loop-invariant 32-bit byte offset): one v_min per quad
+    const uint32_t image_bytes = (uint32_t)total_pix * C;      // < 2^31 (checked on the host)
     auto load_tile = [&](int ty0) {
-        const int pix0 = ty0 * a.w;
+        const uint32_t tile_off = (uint32_t)(ty0 * a.w) * C;
+        const uint8_t *tile_ptr = src + tile_off;
 #pragma unroll
         for (int q = 0; q < QPT; ++q) {
-            int pix = pix0 + rel_pix[q];
+            const uint32_t rel = (uint32_t)rel_pix[q] * C;
             if (ALIGNED) {
-                pix = pix < total_pix - 4 ? pix : total_pix - 4;   // w % 4 == 0: the last quad ends with the image
-                const uint32_t *p = reinterpret_cast<const uint32_t *>(src + (size_t)pix * C);
+                const uint32_t lim = image_bytes - 4u * C - tile_off;   // w % 4 == 0: the last quad ends with the image
+                const uint32_t off = rel < lim ? rel : lim;
+                const uint32_t *p = reinterpret_cast<const uint32_t *>(tile_ptr + off);
 #pragma unroll
                 for (int k = 0; k < DW; ++k) raw[q][k] = __builtin_nontemporal_load(p + k);
             } else {
-                pix = pix < total_pix - 1 ? pix : total_pix - 1;
-                const uintptr_t ad = (uintptr_t)src + (uintptr_t)pix * C;
+                const uint32_t lim = image_bytes - C - tile_off;
+                const uintptr_t ad = (uintptr_t)tile_ptr + (rel < lim ? rel : lim);
                 const uintptr_t al = ad & ~(uintptr_t)3;
                 const int sb = (int)(ad & 3);
                 uint32_t wv[DW + 1];
@@ -744,7 +760,7 @@ int launch_hband_ndwc(ke_ctx *ctx, const KeBandArgs &a, int64_t n, size_t lds, i
 // (Pillow's vertical-first rule, images under 4 pixels, windows beyond 8 chunks of 32 dwords).
 int resample_banded(ke_ctx *ctx, const KeHashGroup &g, int ow, int oh, uint8_t *d_tiles, int filter = KE_FILTER_LANCZOS) {
     if ((int64_t)g.h > (int64_t)g.w * 100 && oh < g.h) return KE_EUNSUPPORTED;
-    if ((int64_t)g.w * g.h < 4 || g.w > 16384 || g.h > 65536 || (int64_t)g.w * g.h >= (1LL << 30)) return KE_EUNSUPPORTED;
+    if ((int64_t)g.w * g.h < 4 || g.w > 16384 || g.h > 65536 || (int64_t)g.w * g.h * g.channels >= (1LL << 31)) return KE_EUNSUPPORTED;
     const KeAxisCoeffs *chz = ke_get_coeffs(ctx, g.w, ow, filter);
     const KeAxisCoeffs *cvt = ke_get_coeffs(ctx, g.h, oh, filter);
     if (!chz || !cvt) return ke_fail(ctx, KE_EHIP, "coefficient upload failed");

@@ -188,11 +188,11 @@ __device__ __forceinline__ uint32_t luma4_biased(uint32_t d0, uint32_t d1, uint3
     const uint32_t p0 = d0;
     const uint32_t p1 = __builtin_amdgcn_alignbyte(d1, d0, 3);
     const uint32_t p2 = __builtin_amdgcn_alignbyte(d2, d1, 2);
-    const uint32_t p3 = d2 >> 8;
+    // the fourth pixel sits in bytes 1..3 of d2: shift the weights, not the data
     const uint32_t s0 = (__builtin_amdgcn_udot4(p0, CHI, 0u, false) << 8) + __builtin_amdgcn_udot4(p0, CLO, START, false);
     const uint32_t s1 = (__builtin_amdgcn_udot4(p1, CHI, 0u, false) << 8) + __builtin_amdgcn_udot4(p1, CLO, START, false);
     const uint32_t s2 = (__builtin_amdgcn_udot4(p2, CHI, 0u, false) << 8) + __builtin_amdgcn_udot4(p2, CLO, START, false);
-    const uint32_t s3 = (__builtin_amdgcn_udot4(p3, CHI, 0u, false) << 8) + __builtin_amdgcn_udot4(p3, CLO, START, false);
+    const uint32_t s3 = (__builtin_amdgcn_udot4(d2, CHI << 8, 0u, false) << 8) + __builtin_amdgcn_udot4(d2, CLO << 8, START, false);
     // byte 2 of each sum -> one dword: two v_perm_b32 (selector bytes pick from {s_odd[3:0] = 4..7, s_even[3:0] = 0..3})
     // and one v_bfi_b32 instead of shift/and/or chains (the VALU issue rate bounds this kernel)
     const uint32_t lo = __builtin_amdgcn_perm(s1, s0, 0x0C0C0602u);   // [s0.b2, s1.b2, 0, 0]

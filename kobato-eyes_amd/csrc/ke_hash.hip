@@ -229,7 +229,10 @@ struct KeFusedArgs {
 };
 
 template <int W64, int NDWH, int NDWD>
-__global__ __launch_bounds__(256, (NDWD > 0 ? 2 : 3)) void ke_phash_fused(const KeFusedArgs a) {
+#ifndef KE_FUSED_WAVES
+#define KE_FUSED_WAVES 3
+#endif
+__global__ __launch_bounds__(256, (NDWD > 0 ? 2 : KE_FUSED_WAVES)) void ke_phash_fused(const KeFusedArgs a) {
     constexpr int W = 64 * W64;
     constexpr int QPT = W64;                 // 12-byte quads per thread per 16-row tile
     constexpr int QUADS_PER_TILE = kRT * W / 4;

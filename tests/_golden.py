@@ -89,3 +89,58 @@ def refine_corpus():
     shifted[:, :, :] += 2
     items.append(("v007_plus2", np.clip(shifted, 0, 255).astype(np.uint8)))
     return items
+
+
+def write_image_io_files(td):
+    """Files exercising the loader in front of the refine stage; returns [(name, path, kwargs)]."""
+    from PIL import Image
+
+    rng = np.random.default_rng(31)
+    td = str(td)
+    cases = []
+
+    def add(name, img, fmt, kwargs=None, **save):
+        path = os.path.join(td, f"{name}.{fmt.lower()}")
+        img.save(path, format=fmt, **save)
+        cases.append((name, path, kwargs or {}))
+
+    rgb = Image.fromarray(rng.integers(0, 256, (60, 80, 3), dtype=np.uint8))
+    add("rgb_png", rgb, "PNG")
+    add("rgba_png", Image.fromarray(rng.integers(0, 256, (50, 70, 4), dtype=np.uint8)), "PNG")
+    add("la_png", Image.fromarray(rng.integers(0, 256, (40, 30, 2), dtype=np.uint8), mode="LA"), "PNG")
+    add("l_png", Image.fromarray(rng.integers(0, 256, (33, 44), dtype=np.uint8)), "PNG")
+    pal = rgb.convert("P", palette=Image.Palette.ADAPTIVE, colors=16)
+    add("p_png", pal, "PNG")
+    add("p_transparent_png", pal, "PNG", transparency=3)
+    add("i16_png", Image.fromarray((rng.integers(0, 65536, (20, 25))).astype(np.uint16)), "PNG")
+    add("cmyk_jpg", rgb.convert("CMYK"), "JPEG", quality=90)
+    exif = Image.Exif()
+    exif[0x0112] = 6                                       # orientation: rotate 270 on load
+    add("exif_rot_jpg", rgb, "JPEG", quality=95, exif=exif.tobytes())
+    big = Image.fromarray(np.repeat(np.repeat(rng.integers(0, 256, (50, 64, 3), dtype=np.uint8), 100, axis=0), 100, axis=1)[:4500, :6000])
+    add("big_png", big, "PNG", compress_level=1)
+    add("big_jpg", big, "JPEG", quality=85)                # draft mode decodes it reduced
+    add("big_jpg_max1000", big, "JPEG", {"max_side": 1000}, quality=85)
+    add("hard_skip", rgb, "PNG", {"hard_skip_pixels": 1000})
+    add("bomb_skip", rgb, "PNG", {"bomb_pixel_cap": 1000, "skip_on_bomb": True})
+    add("bomb_pass", rgb, "PNG", {"bomb_pixel_cap": 1000})
+    add("bomb_warn_only", rgb, "PNG", {"bomb_pixel_cap": 3000})
+    add("keep_mode", Image.fromarray(rng.integers(0, 256, (50, 70, 4), dtype=np.uint8)), "PNG", {"rgb": False})
+    broken = os.path.join(td, "broken.png")
+    with open(broken, "wb") as fh:
+        fh.write(b"not an image")
+    cases.append(("broken", broken, {}))
+    trunc_src = os.path.join(td, "rgb_png.png")
+    trunc = os.path.join(td, "truncated.png")
+    with open(trunc_src, "rb") as fh:
+        data = fh.read()
+    with open(trunc, "wb") as fh:
+        fh.write(data[: len(data) * 2 // 3])
+    cases.append(("truncated", trunc, {}))
+    cases.append(("missing", os.path.join(td, "does_not_exist.png"), {}))
+    return cases
+
+
+def image_io_golden():
+    with open(os.path.join(GOLDEN, "image_io_golden.json")) as fh:
+        return json.load(fh)

@@ -393,8 +393,41 @@ def make_refine_parallel():
     print("refine_parallel:", len(out["cases"]), "files;", [(c["stage"], len(c["result"])) for c in out["clusters"]], "mae", [round(m[2], 5) for m in out["mae"]])
 
 
+# ------------------------------------------------------------------ decode normalisation
+def image_io_cases(td):
+    """Write the test files into directory td; returns [(name, path, kwargs)].  Shared with tests/_golden.py."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from _golden import write_image_io_files
+    return write_image_io_files(td)
+
+
+def make_image_io():
+    import tempfile
+
+    from utils.image_io import safe_load_image
+
+    out = {}
+    with tempfile.TemporaryDirectory() as td:
+        for name, path, kwargs in image_io_cases(td):
+            import warnings
+            try:
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    img = safe_load_image(path, **kwargs)
+            except Exception as exc:          # e.g. Pillow >= 10 raises DecompressionBombError already in Image.open
+                out[name] = {"raises": type(exc).__name__}
+                continue
+            out[name] = None if img is None else {"mode": img.mode, "size": list(img.size), "sha256": hashlib.sha256(img.tobytes()).hexdigest()}
+    with open(os.path.join(HERE, "image_io_golden.json"), "w") as fh:
+        json.dump(out, fh, indent=1)
+    print("image_io:", {k: (v and (v.get("size") or v.get("raises"))) for k, v in out.items()})
+
+
 if __name__ == "__main__":
     logging.basicConfig(level=logging.WARNING)
+    if "--only-image-io" in sys.argv:
+        make_image_io()
+        raise SystemExit(0)
     if "--only-refine-parallel" in sys.argv:
         make_refine_parallel()
         raise SystemExit(0)
@@ -403,3 +436,4 @@ if __name__ == "__main__":
     make_rows()
     make_ssim()
     make_refine_parallel()
+    make_image_io()

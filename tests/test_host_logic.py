@@ -216,3 +216,33 @@ def test_sharding_helpers_world_size_2_gloo(tmp_path):
     outs = [p.communicate(timeout=180)[0] for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
+
+
+def test_decode_normalisation_matches_reference(K, tmp_path):
+    """kobato_eyes_amd.image_io.safe_load_image against what the reference's utils.image_io.safe_load_image
+    returned for the same files (tests/golden/image_io_golden.json): mode, size and every pixel."""
+    import hashlib
+    import warnings
+
+    from kobato_eyes_amd.image_io import safe_load_image
+
+    golden = G.image_io_golden()
+    seen = 0
+    for name, path, kwargs in G.write_image_io_files(tmp_path):
+        exp = golden[name]
+        try:
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                img = safe_load_image(path, **kwargs)
+        except Exception as exc:
+            assert exp == {"raises": type(exc).__name__}, name
+            seen += 1
+            continue
+        if exp is None:
+            assert img is None, name
+        else:
+            assert img is not None and "raises" not in exp, name
+            got = {"mode": img.mode, "size": list(img.size), "sha256": hashlib.sha256(img.tobytes()).hexdigest()}
+            assert got == exp, name
+        seen += 1
+    assert seen == len(golden) >= 20

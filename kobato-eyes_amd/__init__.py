@@ -8,6 +8,8 @@ include/keyes.h); nothing here falls back to the CPU.
 from . import _native
 from .api import DedupSettings, compute_signature, find_duplicates, run_duplicate_scan
 from .cluster import Cluster, ClusterBuilder
+from .cluster_update import (choose_keeper, cluster_hamming_score, default_checked_entries, rebuild_cluster_after_removal,
+                             rebuild_clusters_after_removal, sort_entries_for_display)
 from .fastsig import bulk_upsert_signatures, compute_signatures_mp, fast_fill_missing_signatures
 from .phash import dhash, hamming64, hash_batch, phash, phash_dhash
 from .refine_parallel import (refine_by_pixels_parallel, refine_by_tilehash_parallel, tile_ahash_bits,
@@ -23,5 +25,7 @@ __all__ = [
     "DuplicateScanConfig", "DuplicateScanner", "assemble_clusters", "fast_fill_missing_signatures",
     "compute_signatures_mp", "bulk_upsert_signatures", "compute_signatures_from_image", "ensure_signatures",
     "tile_ahash_bits", "tile_hamming", "tile_ahash_from_arrays", "refine_by_tilehash_parallel", "refine_by_pixels_parallel",
+    "choose_keeper", "sort_entries_for_display", "rebuild_cluster_after_removal", "rebuild_clusters_after_removal",
+    "cluster_hamming_score", "default_checked_entries",
     "refine_pair", "compute_ssim", "ssim_pairs", "RefinementThresholds", "RefinedMatch", "Cluster", "ClusterBuilder",
 ]

@@ -393,6 +393,26 @@ def make_refine_parallel():
     print("refine_parallel:", len(out["cases"]), "files;", [(c["stage"], len(c["result"])) for c in out["clusters"]], "mae", [round(m[2], 5) for m in out["mae"]])
 
 
+# ------------------------------------------------------------------ cluster maintenance
+def make_cluster_update():
+    import ui.dup_cluster_update as U
+    import ui.dup_tree_state as T
+
+    files = synth_files([int(v) for v in O.synth_hashes(1000)])
+    dfs = [DuplicateFile(file_id=f["file_id"], path=Path(f["path"]), size=f["size"], width=f["width"], height=f["height"],
+                         phash=f["phash"], embedding=None) for f in files]
+    clusters = DuplicateScanner(DuplicateScanConfig(hamming_threshold=12, band_bits=8, band_count=8)).build_clusters(dfs)
+    enc = lambda cs: [[c.keeper_id, [[e.file.file_id, e.best_hamming] for e in c.files]] for c in cs]
+    out = {"scan": {"hamming_threshold": 12, "band_bits": 8, "band_count": 8}, "clusters": enc(clusters), "removals": []}
+    for removed in ([c.keeper_id for c in clusters[::2]], [f["file_id"] for f in files[::3]], [], [f["file_id"] for f in files]):
+        out["removals"].append({"removed": removed, "result": enc(U.rebuild_clusters_after_removal(clusters, set(removed)))})
+    out["hamming_score"] = [T.cluster_hamming_score(c) for c in clusters]
+    out["default_checked"] = [[e.file.file_id for e in T.default_checked_entries(c)] for c in clusters]
+    with open(os.path.join(HERE, "cluster_update_golden.json"), "w") as fh:
+        json.dump(out, fh, separators=(",", ":"))
+    print("cluster_update:", len(clusters), "clusters;", [len(r["result"]) for r in out["removals"]])
+
+
 # ------------------------------------------------------------------ decode normalisation
 def image_io_cases(td):
     """Write the test files into directory td; returns [(name, path, kwargs)].  Shared with tests/_golden.py."""
@@ -425,6 +445,9 @@ def make_image_io():
 
 if __name__ == "__main__":
     logging.basicConfig(level=logging.WARNING)
+    if "--only-cluster-update" in sys.argv:
+        make_cluster_update()
+        raise SystemExit(0)
     if "--only-image-io" in sys.argv:
         make_image_io()
         raise SystemExit(0)
@@ -437,3 +460,4 @@ if __name__ == "__main__":
     make_ssim()
     make_refine_parallel()
     make_image_io()
+    make_cluster_update()

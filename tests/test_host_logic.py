@@ -246,3 +246,26 @@ def test_decode_normalisation_matches_reference(K, tmp_path):
             assert got == exp, name
         seen += 1
     assert seen == len(golden) >= 20
+
+
+def test_cluster_maintenance_matches_reference(K):
+    """rebuild_clusters_after_removal / cluster_hamming_score / default_checked_entries against the reference's
+    ui.dup_cluster_update and ui.dup_tree_state run on the same clusters (tests/golden/cluster_update_golden.json)."""
+    import json
+
+    from oracle import oracle as O
+
+    with open(os.path.join(G.GOLDEN, "cluster_update_golden.json")) as fh:
+        g = json.load(fh)
+    ext = ("png", "jpg", "webp", "jpeg", "bmp", "tif")
+    files = {i + 1: K.DuplicateFile(file_id=i + 1, path=Path(f"dir{i % 3}/img_{i:07d}.{ext[i % 6]}"), size=1000 + (i % 7),
+                                    width=512 - (i % 5), height=512, phash=int(hv)) for i, hv in enumerate(O.synth_hashes(1000))}
+    clusters = [K.DuplicateCluster(files=[K.DuplicateClusterEntry(files[fid], best) for fid, best in entries], keeper_id=keeper)
+                for keeper, entries in g["clusters"]]
+    enc = lambda cs: [[c.keeper_id, [[e.file.file_id, e.best_hamming] for e in c.files]] for c in cs]
+    for case in g["removals"]:
+        assert enc(K.rebuild_clusters_after_removal(clusters, set(case["removed"]))) == case["result"]
+    assert [K.cluster_hamming_score(c) for c in clusters] == g["hamming_score"]
+    assert [[e.file.file_id for e in K.default_checked_entries(c)] for c in clusters] == g["default_checked"]
+    assert K.rebuild_cluster_after_removal(clusters[0], {e.file.file_id for e in clusters[0].files[1:]}) is None
+    assert K.choose_keeper(clusters[0].files) == clusters[0].keeper_id

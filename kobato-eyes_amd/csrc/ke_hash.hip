@@ -456,14 +456,12 @@ __global__ __launch_bounds__(256, (NDWD > 0 ? 2 : KE_FUSED_WAVES)) void ke_phash
     }
 }
 
-bool g_tables_ready = false;
-
 int upload_dct_tables(ke_ctx *ctx) {
-    if (g_tables_ready) return KE_OK;
+    if (ctx->dct_tables_ready) return KE_OK;
     KE_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(c_C32), KE_C32, sizeof(KE_C32)));
     KE_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(c_C16), KE_C16, sizeof(KE_C16)));
     KE_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(c_C8), KE_C8, sizeof(KE_C8)));
-    g_tables_ready = true;
+    ctx->dct_tables_ready = true;
     return KE_OK;
 }
 

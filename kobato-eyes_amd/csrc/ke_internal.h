@@ -89,6 +89,7 @@ struct ke_ctx {
     std::map<std::pair<int, int>, KeAxisCoeffs *> coeffs;   // key: (in_size, out_size * 4 + filter)
     hipEvent_t ev0[KE_T_COUNT] = {}, ev1[KE_T_COUNT] = {};
     bool ev_valid[KE_T_COUNT] = {};
+    bool dct_tables_ready = false;   // __constant__ tables are per device: uploaded once per context
 };
 
 // error helpers ------------------------------------------------------------------------------

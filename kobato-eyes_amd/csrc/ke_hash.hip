@@ -785,15 +785,20 @@ int resample_banded(ke_ctx *ctx, const KeHashGroup &g, int ow, int oh, uint8_t *
     if (a.qr > 2048) return KE_EUNSUPPORTED;
     a.lp = (4 * a.qr + 7) & ~7;
     a.rt = std::max(1, std::min(2048 / a.qr, g.h));
-    // rows per workgroup: about 512 KB of pixels, a whole number of 4-tile groups (so bands start on a multiple
-    // of 4 rows), at most 64 bands per image, and at most 480 rows (the band's output bytes are staged in LDS)
+    // Rows per workgroup.  Upper bounds: about 2 MB of pixels (amortises the tap-plane loads of a workgroup; measured
+    // 4-6 % over 512 KB bands), 480 rows and 24 KB of LDS for the band's staged output bytes.  The image is then cut
+    // into EQUAL bands (a short last band leaves its CU idle at the end), each a whole number of 4-tile groups so that
+    // bands start on a multiple of 4 rows.
     const int unit = 4 * a.rt;
-    int64_t rows = std::max<int64_t>(unit, ((int64_t)(512 << 10) / ((int64_t)g.w * g.channels)) / unit * unit);
-    rows = std::min<int64_t>(rows, std::max(unit, 480 / unit * unit));
-    if ((g.h + rows - 1) / rows > 64 && rows < 480) rows = std::min<int64_t>(std::max(unit, 480 / unit * unit), (((g.h + 63) / 64 + unit - 1) / unit) * unit);
     const int per_launch = std::min(ow, 256 >> best_log2);   // outputs whose virtual columns fit 256 lanes
-    // the band's output bytes (per_launch columns) are staged in LDS: keep that area under 24 KB
-    rows = std::min<int64_t>(rows, std::max<int64_t>(unit, ((24 * 1024) / per_launch - 8) / unit * unit));
+    int64_t cap_rows = std::max<int64_t>(unit, ((int64_t)(2048 << 10) / ((int64_t)g.w * g.channels)) / unit * unit);
+    cap_rows = std::min<int64_t>(cap_rows, std::max(unit, 480 / unit * unit));
+    cap_rows = std::min<int64_t>(cap_rows, std::max<int64_t>(unit, ((24 * 1024) / per_launch - 8) / unit * unit));
+    // small groups still have to fill the chip: aim for at least ~3000 workgroups per launch (4 per SIMD slot)
+    const int64_t min_bands = std::min<int64_t>((3072 + g.n - 1) / g.n, (g.h + unit - 1) / unit);
+    if (min_bands > 1) cap_rows = std::min<int64_t>(cap_rows, std::max<int64_t>(unit, ((g.h + min_bands - 1) / min_bands + unit - 1) / unit * unit));
+    const int64_t want_bands = (g.h + cap_rows - 1) / cap_rows;
+    const int64_t rows = std::min<int64_t>(cap_rows, (((g.h + want_bands - 1) / want_bands + unit - 1) / unit) * unit);
     a.band_rows = (int)rows;
     a.bands = (g.h + a.band_rows - 1) / a.band_rows;
     a.bp = ((a.band_rows + 3) & ~3) + 4;

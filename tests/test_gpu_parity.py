@@ -328,3 +328,22 @@ def test_random_shapes_stress(ctx):
         thumbs = ctx.resize_luma_uniform(px, n, w, h, ch, 128, 128, filter=1)
         for k in range(n):
             assert np.array_equal(thumbs[k], O.small_gray(px[k], 128)), (w, h, ch, k, "bilinear")
+
+
+def test_host_staging_chunks_match_device_path(ctx):
+    """A host batch larger than the 1 GB staging buffer goes through several H2D chunks; the hashes must equal
+    the ones computed from the same images resident in HBM (and the oracle on a sample)."""
+    n, side = 3000, 512                                      # 2.36 GB of pixels -> 3 staging chunks
+    host = ctx.synth_rgb(O.SEED, 500, n, side, side)         # device generator -> host array
+    p_host, d_host = ctx.hash_uniform(host, n, side, side, 3)
+    dev = ctx.malloc(host.nbytes)
+    try:
+        ctx.synth_rgb(O.SEED, 500, n, side, side, out=dev)
+        p_dev, d_dev = ctx.hash_uniform(dev, n, side, side, 3)
+    finally:
+        ctx.free(dev)
+    assert np.array_equal(p_host, p_dev) and np.array_equal(d_host, d_dev)
+    for k in (0, 1, 1365, 1366, 2730, 2999):                 # around the chunk boundaries
+        assert (int(p_host[k]), int(d_host[k])) == O.hash_image(host[k])
+    t32, t98 = ctx.luma_tiles_uniform(host[:1500], 1500, side, side, 3)
+    assert np.array_equal(t32[1499], O.hash_image(host[1499], want_tiles=True)[2])

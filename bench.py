@@ -69,7 +69,19 @@ def cpu_baseline(ctx, args, table_host):
     edges, _ = O.scan_banded(table_host, threshold=args.threshold)
     t_scan = time.perf_counter() - t0
     total = t_hash / m * args.images + t_scan
+    # the reference's own parallelism for this step is 8 worker processes (KE_SIG_WORKERS, src/ui/dup_workers.py:180):
+    # the same oracle on 8 threads (ctypes releases the GIL), reported beside the 1-core figure
+    from concurrent.futures import ThreadPoolExecutor
+
+    threads = min(8, os.cpu_count() or 1)
+    px = ctx.synth_rgb(SEED, 0, 2000, args.side, args.side)
+    parts = np.array_split(np.arange(2000), threads)
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(threads) as ex:
+        list(ex.map(lambda idx: O.hash_batch(px[idx[0]:idx[-1] + 1], want_dhash=args.dhash), parts))
+    t_mt = time.perf_counter() - t0
     return {
+        "threads_8": {"threads": threads, "hash_images_per_s": 2000 / t_mt, "sample": "2000 images, one slice per thread"},
         "value": args.images / total, "unit": "images/s", "cores": 1, "kind": "port",
         "sample": f"{m} of the {args.images} corpus images hashed by oracle/keyes_oracle.c on 1 core ({t_hash:.2f} s, "
                   f"{m / t_hash:.0f} img/s) + reference-shaped banded scan over all {args.images} hashes ({t_scan:.2f} s, "

@@ -43,6 +43,8 @@ def parse_args():
     ap.add_argument("--side", type=int, default=512)
     ap.add_argument("--threshold", type=int, default=8)
     ap.add_argument("--dhash", action="store_true", help="also compute dHash in the hash step")
+    ap.add_argument("--ssim-threshold", type=float, default=None,
+                    help="BASELINE configs[3] flavour (single GPU): re-check every candidate edge with the SSIM kernel inside the step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--phase-timing", action="store_true", help="after the timed run, time each phase of a step with syncs in between (stderr)")
     ap.add_argument("--cpu-sample", type=int, default=16000, help="images hashed by the CPU oracle for the baseline")
@@ -157,6 +159,16 @@ def main():
             all_edges = merged.view(_native.EDGE_DTYPE)
         else:
             all_edges = edges_dev[: edges * 24].cpu().numpy().view(_native.EDGE_DTYPE)
+        # 4b. optional SSIM refine of the candidate edges (both images are resident on one GPU)
+        if args.ssim_threshold is not None:
+            if world != 1:
+                raise SystemExit("--ssim-threshold is a single-GPU mode (the pair's images must be resident)")
+            if len(all_edges):
+                ssim = ctx.ssim_pairs_uniform(pixels.data_ptr(), n_total, side, side, 3, all_edges["a"], all_edges["b"])
+                state["ssim_ms"] = ctx.last_kernel_ms(2)
+                state["ssim_pairs"] = len(all_edges)
+                state["ssim_quartiles"] = [float(q) for q in np.quantile(ssim, [0.0, 0.25, 0.5, 0.75, 1.0])]
+                all_edges = all_edges[ssim >= args.ssim_threshold]
         # 5. cluster membership on the host
         labels = _native.cluster_labels(all_edges, n_total)
         state.update(table=table, edges=all_edges, labels=labels, pairs=int(counters[0]))
@@ -251,12 +263,15 @@ def main():
                             f"band 16x4 (BASELINE configs[{1 if world == 1 else 2}])",
                 "images": n_total, "side": side, "hamming_threshold": args.threshold, "dhash": bool(args.dhash),
                 "partition": f"image i on rank i mod {world}; scan tiles dealt round-robin",
-                "step": "hash kernel -> (all-gather) -> scan kernel -> edges to host -> union-find labels",
+                "step": "hash kernel -> (all-gather) -> scan kernel -> edges to host -> "
+                        + ("SSIM refine of the candidate edges -> " if args.ssim_threshold is not None else "") + "union-find labels",
             },
             "gpairs_per_s": pairs_s * world / 1e9,
             "hash_images_per_s": n_local * world / (hash_avg * 1e-3),
             "edges": int(len(state["edges"])), "clusters": n_clusters,
-            "kernel_ms": {"hash": hash_avg, "scan": scan_avg},
+            "kernel_ms": {"hash": hash_avg, "scan": scan_avg, **({"ssim": state["ssim_ms"]} if "ssim_ms" in state else {})},
+            **({"ssim": {"threshold": args.ssim_threshold, "pairs": state["ssim_pairs"], "quartiles": state["ssim_quartiles"],
+                         "pairs_per_s": state["ssim_pairs"] / (state["ssim_ms"] * 1e-3)}} if "ssim_ms" in state else {}),
             "roofline": {"bound": "hbm", "kernel": "ke_phash_fused", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic},
             "roofline_scan": {"bound": "hbm (16 B/pair convention, SURVEY 8d; operands are reused from LDS/registers so "

@@ -110,6 +110,19 @@ const KeChunkTable *ke_get_chunks(ke_ctx *ctx, const KeAxisCoeffs *cc, int cpo, 
     return t;
 }
 
+const KeMxTable *ke_get_mx(ke_ctx *ctx, const KeAxisCoeffs *cc) {
+    auto *c = const_cast<KeAxisCoeffs *>(cc);
+    if (c->mx) return c->mx;
+    auto *t = new KeMxTable();
+    ke_build_mx(*c, *t);
+    if (upload_i32(ctx, t->frag, &t->d_frag)) {
+        delete t;
+        return nullptr;
+    }
+    c->mx = t;
+    return t;
+}
+
 void ke_time_begin(ke_ctx *ctx, int kind) {
     ctx->ev_valid[kind] = false;
     (void)hipEventRecord(ctx->ev0[kind], ctx->stream);
@@ -179,6 +192,10 @@ KE_API void ke_destroy(ke_ctx *ctx) {
             if (ck.second->d_cpacked) (void)hipFree(ck.second->d_cpacked);
             if (ck.second->d_cxor) (void)hipFree(ck.second->d_cxor);
             delete ck.second;
+        }
+        if (c->mx) {
+            if (c->mx->d_frag) (void)hipFree(c->mx->d_frag);
+            delete c->mx;
         }
         delete c;
     }

@@ -117,6 +117,42 @@ void ke_build_axis_coeffs(int in_size, int out_size, KeAxisCoeffs &c, int filter
     }
 }
 
+// Byte planes of the taps as matrix-core B operands (see KeMxTable).
+void ke_build_mx(const KeAxisCoeffs &c, KeMxTable &t) {
+    t.tiles = (c.out_size + 15) / 16;
+    t.base.assign((size_t)t.tiles, 0);
+    t.ks = 1;
+    for (int j = 0; j < t.tiles; ++j) {
+        int lo = c.in_size, hi = 0;
+        for (int o = 16 * j; o < std::min(16 * j + 16, c.out_size); ++o) {
+            lo = std::min(lo, c.bounds[2 * o]);
+            hi = std::max(hi, c.bounds[2 * o] + c.bounds[2 * o + 1]);
+        }
+        t.base[j] = lo & ~15;
+        t.ks = std::max(t.ks, (hi - t.base[j] + 63) / 64);
+    }
+    t.frag.assign((size_t)t.tiles * t.ks * 3 * 64 * 4, 0);
+    for (int j = 0; j < t.tiles; ++j)
+        for (int s = 0; s < t.ks; ++s)
+            for (int l = 0; l < 64; ++l) {
+                const int o = 16 * j + (l & 15);
+                if (o >= c.out_size) continue;
+                const int lo = c.bounds[2 * o], cnt = c.bounds[2 * o + 1];
+                for (int e = 0; e < 16; ++e) {
+                    const int tap = t.base[j] + 64 * s + 16 * (l >> 4) + e - lo;
+                    const int32_t k = (tap >= 0 && tap < cnt) ? c.kk[(size_t)o * c.ksize + tap] : 0;
+                    const int32_t b0 = ((k + 128) & 255) - 128;
+                    const int32_t r1 = (k - b0) >> 8;
+                    const int32_t b1 = ((r1 + 128) & 255) - 128;
+                    const int32_t b2 = (r1 - b1) >> 8;
+                    const int32_t plane[3] = {b0, b1, b2};
+                    for (int p = 0; p < 3; ++p)
+                        t.frag[((((size_t)j * t.ks + s) * 3 + p) * 64 + l) * 4 + e / 4] |=
+                            (int32_t)((uint32_t)(plane[p] & 255) << (8 * (e % 4)));
+                }
+            }
+}
+
 // Cut every output's packed window into `cpo` equal chunks (see KeChunkTable).
 void ke_build_chunked(const KeAxisCoeffs &c, int cpo, KeChunkTable &t, int ndwc_multiple) {
     t.cpo = cpo;

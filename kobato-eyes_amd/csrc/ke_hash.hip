@@ -228,6 +228,91 @@ struct KeFusedArgs {
     uint8_t *tile98_out;
 };
 
+// K1' (vertical taps out of the transposed horizontal results HT), K2 (DCT corner, mean, bits) and, for the
+// NDWD > 0 instantiations, the dHash vertical taps + K3: the part of the fused kernels behind the row loop.
+// Lt is free by then and is reused as scratch (>= 3328 bytes).
+template <int NDWD>
+__device__ __forceinline__ void fused_tail(const KeFusedArgs &a, uint8_t *Lt, const uint8_t *HT, const uint8_t *HTd,
+                                           const int tid, const int64_t img) {
+    // ---- K1': vertical taps: thread = (output row yy, columns og + 8m)
+    uint8_t *T32 = Lt;
+    double *Td = reinterpret_cast<double *>(Lt + 1024);
+    float *cf = reinterpret_cast<float *>(Lt + 1024 + 2048);
+    {
+        const int yy = tid & 31, og = tid >> 5;
+        const int rotv = (yy >> 4) & 1;
+        const int vst = a.v_start[yy];
+        const int ndwv = a.ndwv;
+        int acc[4][3];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[m][0] = acc[m][1] = acc[m][2] = 0;
+        for (int j = 0; j < ndwv; j += 2) {
+            const int jj = j ^ (2 * rotv);
+            const int32_t *cp = a.v_packed + ((size_t)yy * ndwv + jj) * 3;
+            const int c00 = cp[0], c01 = cp[1], c02 = cp[2], c10 = cp[3], c11 = cp[4], c12 = cp[5];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const uint2 v = *reinterpret_cast<const uint2 *>(
+                    __builtin_assume_aligned(HT + (size_t)(og + 8 * m) * a.hp + vst + 4 * jj, 8));
+                acc[m][0] = __builtin_amdgcn_sdot4((int)v.x, c00, acc[m][0], false);
+                acc[m][1] = __builtin_amdgcn_sdot4((int)v.x, c01, acc[m][1], false);
+                acc[m][2] = __builtin_amdgcn_sdot4((int)v.x, c02, acc[m][2], false);
+                acc[m][0] = __builtin_amdgcn_sdot4((int)v.y, c10, acc[m][0], false);
+                acc[m][1] = __builtin_amdgcn_sdot4((int)v.y, c11, acc[m][1], false);
+                acc[m][2] = __builtin_amdgcn_sdot4((int)v.y, c12, acc[m][2], false);
+            }
+        }
+        const int vbias = a.v_bias[yy];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+            T32[yy * 32 + og + 8 * m] = (uint8_t)clip8_fixed(combine_planes(acc[m][0], acc[m][1], acc[m][2], vbias));
+    }
+    __syncthreads();
+    if (a.tile32_out)
+        reinterpret_cast<uint32_t *>(a.tile32_out + (size_t)img * 1024)[tid] = reinterpret_cast<const uint32_t *>(T32)[tid];
+    // ---- K2: DCT corner, mean, bits
+    const uint64_t hv = tile32_to_phash(T32, Td, cf, tid);
+    if (tid == 0 && a.phash) a.phash[a.out_idx ? a.out_idx[img] : img] = hv;
+    if (NDWD > 0) {
+        // ---- K1' + K3 for dHash: 8 rows x 9 columns, each output = 3 chunk sums (threads 0..215)
+        __syncthreads();
+        int *part = reinterpret_cast<int *>(Lt);                 // 216 ints
+        uint8_t *T98 = Lt + 1024;                                // 72 bytes
+        if (tid < 216) {
+            const int out = tid / 3, chunk = tid % 3;
+            const int yy = out / 9, oc = out % 9;
+            const int vc = yy * 3 + chunk;
+            const int vst = a.vd_cstart[vc];
+            const int nd = a.ndwcv;
+            int d0 = 0, d1 = 0, d2 = 0;
+            for (int j = 0; j < nd; j += 2) {
+                const int32_t *cp = a.vd_cpacked + ((size_t)vc * nd + j) * 3;
+                const uint2 v = *reinterpret_cast<const uint2 *>(__builtin_assume_aligned(HTd + (size_t)oc * a.hpd + vst + 4 * j, 8));
+                d0 = __builtin_amdgcn_sdot4((int)v.x, cp[0], d0, false);
+                d1 = __builtin_amdgcn_sdot4((int)v.x, cp[1], d1, false);
+                d2 = __builtin_amdgcn_sdot4((int)v.x, cp[2], d2, false);
+                d0 = __builtin_amdgcn_sdot4((int)v.y, cp[3], d0, false);
+                d1 = __builtin_amdgcn_sdot4((int)v.y, cp[4], d1, false);
+                d2 = __builtin_amdgcn_sdot4((int)v.y, cp[5], d2, false);
+            }
+            part[tid] = combine_planes(d0, d1, d2, 0);
+        }
+        __syncthreads();
+        if (tid < 72) {
+            const int yy = tid / 9;
+            const uint32_t sum = (uint32_t)part[3 * tid] + (uint32_t)part[3 * tid + 1] + (uint32_t)part[3 * tid + 2] + (uint32_t)a.vd_bias[yy];
+            T98[tid] = (uint8_t)clip8_fixed((int)sum);
+        }
+        __syncthreads();
+        if (a.tile98_out && tid < 72) a.tile98_out[(size_t)img * 72 + tid] = T98[tid];
+        if (tid < 64) {
+            const int r = tid >> 3, c = tid & 7;
+            const unsigned long long m = __ballot(T98[r * 9 + c + 1] > T98[r * 9 + c]);   // src/sig/phash.py:52
+            if (tid == 0 && a.dhash) a.dhash[a.out_idx ? a.out_idx[img] : img] = __brevll(m);
+        }
+    }
+}
+
 template <int W64, int NDWH, int NDWD>
 #ifndef KE_FUSED_WAVES
 #define KE_FUSED_WAVES 3
@@ -327,11 +412,13 @@ __global__ __launch_bounds__(256, (NDWD > 0 ? 2 : KE_FUSED_WAVES)) void ke_phash
                 const int pp = p ^ rot;
                 const uint2 v = *reinterpret_cast<const uint2 *>(__builtin_assume_aligned(lrow + 8 * pp, 8));
                 d0 = __builtin_amdgcn_sdot4((int)v.x, ck[2 * p][0], d0, false);
+                d0 = __builtin_amdgcn_sdot4((int)v.y, ck[2 * p + 1][0], d0, false);
+#ifndef KE_EXP_ONEPLANE
                 d1 = __builtin_amdgcn_sdot4((int)v.x, ck[2 * p][1], d1, false);
                 d2 = __builtin_amdgcn_sdot4((int)v.x, ck[2 * p][2], d2, false);
-                d0 = __builtin_amdgcn_sdot4((int)v.y, ck[2 * p + 1][0], d0, false);
                 d1 = __builtin_amdgcn_sdot4((int)v.y, ck[2 * p + 1][1], d1, false);
                 d2 = __builtin_amdgcn_sdot4((int)v.y, ck[2 * p + 1][2], d2, false);
+#endif
             }
             const int r = clip8_fixed(combine_planes(d0, d1, d2, hbias));
             packed2 |= (uint32_t)(r ^ 0x80) << (8 * rr);  // signed byte again for the vertical dot products
@@ -377,83 +464,7 @@ __global__ __launch_bounds__(256, (NDWD > 0 ? 2 : KE_FUSED_WAVES)) void ke_phash
     hpass(ntiles - 1, Lt + ((ntiles - 1) & 1) * a.lt_half);
     __syncthreads();
 
-    // ---- K1': vertical taps: thread = (output row yy, columns og + 8m)
-    uint8_t *T32 = Lt;
-    double *Td = reinterpret_cast<double *>(Lt + 1024);
-    float *cf = reinterpret_cast<float *>(Lt + 1024 + 2048);
-    {
-        const int yy = tid & 31, og = tid >> 5;
-        const int rotv = (yy >> 4) & 1;
-        const int vst = a.v_start[yy];
-        const int ndwv = a.ndwv;
-        int acc[4][3];
-#pragma unroll
-        for (int m = 0; m < 4; ++m) acc[m][0] = acc[m][1] = acc[m][2] = 0;
-        for (int j = 0; j < ndwv; j += 2) {
-            const int jj = j ^ (2 * rotv);
-            const int32_t *cp = a.v_packed + ((size_t)yy * ndwv + jj) * 3;
-            const int c00 = cp[0], c01 = cp[1], c02 = cp[2], c10 = cp[3], c11 = cp[4], c12 = cp[5];
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const uint2 v = *reinterpret_cast<const uint2 *>(
-                    __builtin_assume_aligned(HT + (size_t)(og + 8 * m) * a.hp + vst + 4 * jj, 8));
-                acc[m][0] = __builtin_amdgcn_sdot4((int)v.x, c00, acc[m][0], false);
-                acc[m][1] = __builtin_amdgcn_sdot4((int)v.x, c01, acc[m][1], false);
-                acc[m][2] = __builtin_amdgcn_sdot4((int)v.x, c02, acc[m][2], false);
-                acc[m][0] = __builtin_amdgcn_sdot4((int)v.y, c10, acc[m][0], false);
-                acc[m][1] = __builtin_amdgcn_sdot4((int)v.y, c11, acc[m][1], false);
-                acc[m][2] = __builtin_amdgcn_sdot4((int)v.y, c12, acc[m][2], false);
-            }
-        }
-        const int vbias = a.v_bias[yy];
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-            T32[yy * 32 + og + 8 * m] = (uint8_t)clip8_fixed(combine_planes(acc[m][0], acc[m][1], acc[m][2], vbias));
-    }
-    __syncthreads();
-    if (a.tile32_out)
-        reinterpret_cast<uint32_t *>(a.tile32_out + (size_t)img * 1024)[tid] = reinterpret_cast<const uint32_t *>(T32)[tid];
-    // ---- K2: DCT corner, mean, bits
-    const uint64_t hv = tile32_to_phash(T32, Td, cf, tid);
-    if (tid == 0 && a.phash) a.phash[a.out_idx ? a.out_idx[img] : img] = hv;
-    if (NDWD > 0) {
-        // ---- K1' + K3 for dHash: 8 rows x 9 columns, each output = 3 chunk sums (threads 0..215)
-        __syncthreads();
-        int *part = reinterpret_cast<int *>(Lt);                 // 216 ints
-        uint8_t *T98 = Lt + 1024;                                // 72 bytes
-        if (tid < 216) {
-            const int out = tid / 3, chunk = tid % 3;
-            const int yy = out / 9, oc = out % 9;
-            const int vc = yy * 3 + chunk;
-            const int vst = a.vd_cstart[vc];
-            const int nd = a.ndwcv;
-            int d0 = 0, d1 = 0, d2 = 0;
-            for (int j = 0; j < nd; j += 2) {
-                const int32_t *cp = a.vd_cpacked + ((size_t)vc * nd + j) * 3;
-                const uint2 v = *reinterpret_cast<const uint2 *>(__builtin_assume_aligned(HTd + (size_t)oc * a.hpd + vst + 4 * j, 8));
-                d0 = __builtin_amdgcn_sdot4((int)v.x, cp[0], d0, false);
-                d1 = __builtin_amdgcn_sdot4((int)v.x, cp[1], d1, false);
-                d2 = __builtin_amdgcn_sdot4((int)v.x, cp[2], d2, false);
-                d0 = __builtin_amdgcn_sdot4((int)v.y, cp[3], d0, false);
-                d1 = __builtin_amdgcn_sdot4((int)v.y, cp[4], d1, false);
-                d2 = __builtin_amdgcn_sdot4((int)v.y, cp[5], d2, false);
-            }
-            part[tid] = combine_planes(d0, d1, d2, 0);
-        }
-        __syncthreads();
-        if (tid < 72) {
-            const int yy = tid / 9;
-            const uint32_t sum = (uint32_t)part[3 * tid] + (uint32_t)part[3 * tid + 1] + (uint32_t)part[3 * tid + 2] + (uint32_t)a.vd_bias[yy];
-            T98[tid] = (uint8_t)clip8_fixed((int)sum);
-        }
-        __syncthreads();
-        if (a.tile98_out && tid < 72) a.tile98_out[(size_t)img * 72 + tid] = T98[tid];
-        if (tid < 64) {
-            const int r = tid >> 3, c = tid & 7;
-            const unsigned long long m = __ballot(T98[r * 9 + c + 1] > T98[r * 9 + c]);   // src/sig/phash.py:52
-            if (tid == 0 && a.dhash) a.dhash[a.out_idx ? a.out_idx[img] : img] = __brevll(m);
-        }
-    }
+    fused_tail<NDWD>(a, Lt, HT, HTd, tid, img);
 }
 
 int upload_dct_tables(ke_ctx *ctx) {
@@ -499,6 +510,149 @@ int launch_fused(ke_ctx *ctx, const KeHashGroup &g, const KeAxisCoeffs *ch, cons
     const size_t lds = (size_t)a.lt_bytes + (size_t)32 * a.hp + (NDWD > 0 ? (size_t)9 * a.hpd : 0);
     if (lds > 64 * 1024) return KE_EUNSUPPORTED;
     hipLaunchKernelGGL((ke_phash_fused<W64, NDWH, NDWD>), dim3((unsigned)g.n), dim3(256), lds, ctx->stream, a);
+    KE_HIP(ctx, hipGetLastError());
+    return KE_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// Fused pHash kernel, horizontal taps on the matrix cores.  Same chain and the same integers as
+// ke_phash_fused; what changes is K1b: the horizontal resample of a 32-row tile is the banded product
+// H[row][o] = sum_x luma[row][x] * k[o][x], and v_mfma_i32_16x16x64_i8 accumulates it exactly in int32 --
+// A = 16 rows x 64 signed luma bytes straight out of LDS (one ds_read_b128 per lane), B = one byte plane
+// of the taps of 16 outputs (KeMxTable, resident in registers), three planes combined as before.  Wave w
+// owns rows 16(w>>1).. of the tile and outputs 16(w&1)..; the result registers already hold four
+// consecutive rows of one output column, i.e. one dword of the transposed HT.  This takes the 144
+// v_dot4 per lane and 16 rows off the VALU, which was co-limiting the dot-product kernel at 6.5 TB/s.
+// LDS rows are padded by 16 bytes so the 16 rows of an A operand fall into distinct banks.
+// ---------------------------------------------------------------------------------------
+constexpr int kRTM = 32;
+typedef int ke_v4i __attribute__((ext_vector_type(4)));
+
+struct KeFusedMxArgs {
+    KeFusedArgs f;
+    const int32_t *mx_frag;   // KeMxTable::frag of the horizontal axis
+    int mx_base0, mx_base1;   // first tap column of the two output tiles (multiples of 16)
+    int lp;                   // LDS pitch of one luma row = W + 16
+};
+
+#ifndef KE_MX_WAVES
+#define KE_MX_WAVES 2
+#endif
+template <int W64, int KS>
+__global__ __launch_bounds__(256, KE_MX_WAVES) void ke_phash_fused_mx(const KeFusedMxArgs am) {
+    const KeFusedArgs &a = am.f;
+    constexpr int W = 64 * W64;
+    constexpr int QW = W / 4;                    // 12-byte quads per row
+    constexpr int QPT = kRTM * QW / 256;         // quads per thread per 32-row tile
+    constexpr int QUADS_PER_TILE = kRTM * QW;
+    constexpr int LP = W + 16;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t *Lt = smem;
+    uint8_t *HT = smem + a.lt_bytes;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int64_t img = blockIdx.x;
+    const uint8_t *src = a.pixels + (a.offsets ? a.offsets[img] : (uint64_t)img * a.stride);
+    const int h = a.h;
+    const uint32_t image_bytes = (uint32_t)h * (uint32_t)QW * 12u;
+
+    // this wave's slice of the product: rows 16*mt.., outputs 16*jt..
+    const int mt = wv >> 1, jt = wv & 1;
+    ke_v4i bf[KS][3];
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+            bf[s][p] = reinterpret_cast<const ke_v4i *>(am.mx_frag)[((jt * KS + s) * 3 + p) * 64 + lane];
+    const int ocol = 16 * jt + (lane & 15);
+    const int hbias = a.h_bias[ocol];
+    const int a_off = (16 * mt + (lane & 15)) * LP + (jt ? am.mx_base1 : am.mx_base0) + 16 * (lane >> 4);
+    uint8_t *ht_dst = HT + (size_t)ocol * a.hp + 16 * mt + 4 * (lane >> 4);
+
+    uint32_t raw[QPT][3];
+    auto load_tile = [&](int t) {
+        const uint32_t tile_off = (uint32_t)t * (uint32_t)(QUADS_PER_TILE * 12);
+        const uint8_t *tile_ptr = src + tile_off;                 // wave-uniform
+        const uint32_t lim = image_bytes - 12u - tile_off;        // last loadable quad, relative to the tile
+#pragma unroll
+        for (int q = 0; q < QPT; ++q) {
+            // unconditional, clamped, non-temporal: see ke_phash_fused
+            const uint32_t vo = (uint32_t)(q * 256 + tid) * 12u;
+            const uint32_t off = vo < lim ? vo : lim;
+            const uint32_t *p = reinterpret_cast<const uint32_t *>(tile_ptr + off);
+            raw[q][0] = __builtin_nontemporal_load(p);
+            raw[q][1] = __builtin_nontemporal_load(p + 1);
+            raw[q][2] = __builtin_nontemporal_load(p + 2);
+        }
+    };
+    auto store_luma = [&](uint8_t *dst) {
+#pragma unroll
+        for (int q = 0; q < QPT; ++q) {
+            const int i = q * 256 + tid;
+            *reinterpret_cast<uint32_t *>(dst + (i / QW) * LP + (i % QW) * 4) = luma4_biased(raw[q][0], raw[q][1], raw[q][2]);
+        }
+    };
+    auto hpass = [&](int t, const uint8_t *cur) {
+        ke_v4i acc[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) acc[p] = ke_v4i{0, 0, 0, 0};
+        const uint8_t *ap = cur + a_off;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const ke_v4i av = *reinterpret_cast<const ke_v4i *>(__builtin_assume_aligned(ap + 64 * s, 16));
+#pragma unroll
+            for (int p = 0; p < 3; ++p) acc[p] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, bf[s][p], acc[p], 0, 0, 0);
+        }
+        uint32_t packed = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            packed |= (uint32_t)clip8_fixed(combine_planes(acc[0][i], acc[1][i], acc[2][i], hbias)) << (8 * i);
+        *reinterpret_cast<uint32_t *>(ht_dst + t * kRTM) = packed ^ 0x80808080u;   // signed bytes for the vertical pass
+    };
+
+    const int ntiles = (h + kRTM - 1) / kRTM;
+    load_tile(0);
+    store_luma(Lt);
+    __syncthreads();
+    for (int t = 0; t + 1 < ntiles; ++t) {      // same pipeline as ke_phash_fused; last tile peeled
+        load_tile(t + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        hpass(t, Lt + (t & 1) * a.lt_half);
+        __builtin_amdgcn_sched_barrier(0);
+        store_luma(Lt + ((t + 1) & 1) * a.lt_half);
+        __syncthreads();
+    }
+    hpass(ntiles - 1, Lt + ((ntiles - 1) & 1) * a.lt_half);
+    __syncthreads();
+    fused_tail<0>(a, Lt, HT, nullptr, tid, img);
+}
+
+template <int W64, int KS>
+int launch_fused_mx(ke_ctx *ctx, const KeHashGroup &g, const KeAxisCoeffs *ch, const KeAxisCoeffs *cv, uint64_t *d_phash,
+                    uint8_t *d_tile32) {
+    constexpr int W = 64 * W64;
+    const KeMxTable *mx = ke_get_mx(ctx, ch);
+    if (!mx) return ke_fail(ctx, KE_EHIP, "coefficient upload failed");
+    if (mx->tiles != 2 || mx->ks != KS) return KE_EUNSUPPORTED;
+    KeFusedMxArgs am;
+    std::memset(&am, 0, sizeof am);
+    KeFusedArgs &a = am.f;
+    a.pixels = g.pixels; a.offsets = g.offsets; a.stride = g.stride; a.out_idx = g.out_idx; a.h = g.h;
+    a.h_bias = ch->d_bias;
+    a.v_packed = cv->d_packed; a.v_start = cv->d_start; a.v_bias = cv->d_bias;
+    a.ndwv = cv->ndw;
+    am.mx_frag = mx->d_frag; am.mx_base0 = mx->base[0]; am.mx_base1 = mx->base[1];
+    am.lp = W + 16;
+    const int rows_padded = ((g.h + kRTM - 1) / kRTM) * kRTM;
+    // one tile buffer: 32 padded rows + the part of the last row's operand window that overhangs the row
+    const int overhang = std::max(0, std::max(mx->base[0], mx->base[1]) + 64 * KS - W);
+    a.lt_half = (kRTM * am.lp + overhang + 15) & ~15;
+    a.lt_bytes = 2 * a.lt_half;
+    a.hp = ((std::max(cv->span, rows_padded) + 7) & ~7) + 8;
+    a.phash = d_phash; a.tile32_out = d_tile32;
+    const size_t lds = (size_t)a.lt_bytes + (size_t)32 * a.hp;
+    if (lds > 64 * 1024) return KE_EUNSUPPORTED;
+    hipLaunchKernelGGL((ke_phash_fused_mx<W64, KS>), dim3((unsigned)g.n), dim3(256), lds, ctx->stream, am);
     KE_HIP(ctx, hipGetLastError());
     return KE_OK;
 }
@@ -900,6 +1054,13 @@ int ke_launch_hash_group(ke_ctx *ctx, const KeHashGroup &g, uint64_t *d_phash, u
             else if (g.w == 384 && ch->ndw == 20) rc = launch_fused<6, 20, 24>(ctx, g, ch, cv, d_phash, d_tile32_out, d_dhash, d_tile98_out);
             else if (g.w == 512 && ch->ndw == 24) rc = launch_fused<8, 24, 32>(ctx, g, ch, cv, d_phash, d_tile32_out, d_dhash, d_tile98_out);
             if (rc == KE_OK) p_done = d_done = true;
+            else if (rc != KE_EUNSUPPORTED) return rc;
+        }
+        if (!p_done && !getenv("KE_NO_MX")) {   // horizontal taps on the matrix cores
+            if (g.w == 256) rc = launch_fused_mx<4, 3>(ctx, g, ch, cv, d_phash, d_tile32_out);
+            else if (g.w == 384) rc = launch_fused_mx<6, 4>(ctx, g, ch, cv, d_phash, d_tile32_out);
+            else if (g.w == 512) rc = launch_fused_mx<8, 5>(ctx, g, ch, cv, d_phash, d_tile32_out);
+            if (rc == KE_OK) p_done = true;
             else if (rc != KE_EUNSUPPORTED) return rc;
         }
         if (!p_done) {

@@ -37,6 +37,20 @@ struct KeAxisCoeffs {
     int32_t *d_bounds = nullptr, *d_kk = nullptr, *d_start = nullptr, *d_bias = nullptr, *d_packed = nullptr;
     // chunked byte-plane layouts, by chunks-per-output (see KeChunkTable)
     std::map<int, struct KeChunkTable *> chunked;
+    // matrix-core operand layout of the same byte planes (see KeMxTable), built on first use
+    struct KeMxTable *mx = nullptr;
+};
+
+// The tap matrix as B operands of v_mfma_i32_16x16x64_i8: the resample of one axis is the banded product
+// out[row][o] = sum_x luma[row][x] * k[o][x]; outputs are taken 16 at a time (tile j = o / 16), the taps of a tile
+// live in x in [base[j], base[j] + 64*ks), and step s of tile j, byte plane p is one 64x16 operand whose lane l
+// holds the 16 bytes k_p[o = 16j + (l & 15)][x = base[j] + 64s + 16(l >> 4) + 0..15] (zero outside the window
+// and for o >= out_size).  frag index: (((j*ks + s)*3 + p)*64 + l)*4 dwords.
+struct KeMxTable {
+    int tiles = 0, ks = 0;
+    std::vector<int32_t> base;   // tiles, multiples of 16
+    std::vector<int32_t> frag;
+    int32_t *d_frag = nullptr;
 };
 
 // Chunked byte-plane layout for long windows: every output's packed window is cut into `cpo` chunks of
@@ -54,6 +68,7 @@ struct KeChunkTable {
 
 void ke_build_axis_coeffs(int in_size, int out_size, KeAxisCoeffs &out, int filter = KE_FILTER_LANCZOS);
 void ke_build_chunked(const KeAxisCoeffs &c, int cpo, KeChunkTable &out, int ndwc_multiple = 4);
+void ke_build_mx(const KeAxisCoeffs &c, KeMxTable &out);
 
 struct KeDevBuf {
     void *ptr = nullptr;
@@ -115,6 +130,7 @@ int ke_reserve(ke_ctx *ctx, int which, size_t bytes, void **out);
 int ke_to_device(ke_ctx *ctx, const void *p, size_t bytes, int which, const void **dev);
 const KeAxisCoeffs *ke_get_coeffs(ke_ctx *ctx, int in_size, int out_size, int filter = KE_FILTER_LANCZOS);
 const KeChunkTable *ke_get_chunks(ke_ctx *ctx, const KeAxisCoeffs *c, int cpo, int ndwc_multiple = 4);
+const KeMxTable *ke_get_mx(ke_ctx *ctx, const KeAxisCoeffs *c);
 void ke_time_begin(ke_ctx *ctx, int kind);
 void ke_time_end(ke_ctx *ctx, int kind);
 

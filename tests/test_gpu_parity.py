@@ -59,6 +59,26 @@ def test_hash_batch_matches_oracle(ctx, w, h, n):
         assert np.array_equal(t32[k], O.hash_image(px[k], want_tiles=True)[2])
 
 
+@pytest.mark.parametrize("w", [256, 384, 512])
+def test_phash_only_matrix_core_path(ctx, w):
+    """pHash alone takes the kernel whose horizontal taps run on v_mfma_i32_16x16x64_i8 (32-row tiles, two
+    16-output tiles): heights around the tile size, ragged ends, full-range noise (clip on both sides) and the
+    heights where the launch falls back to the dot-product kernel (LDS) all give the oracle's tile and bits."""
+    rng = np.random.default_rng(w)
+    for h in (16, 17, 31, 33, 47, 64, 65, 100, 333, 512, 700, 900, 1000, 1536):
+        n = 5
+        px = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
+        px[1] = (rng.integers(0, 2, (h, w, 3)) * 255).astype(np.uint8)
+        px[2] = 255
+        px[3, :, ::2] = 0
+        got_p, _ = ctx.hash_uniform(px, n, w, h, 3, want_dhash=False)
+        t32, _ = ctx.luma_tiles_uniform(px, n, w, h, 3, want98=False)
+        for k in range(n):
+            ep, _, e32, _, _ = O.hash_image(px[k], want_tiles=True)
+            assert np.array_equal(t32[k], e32), (w, h, k, "tile32")
+            assert int(got_p[k]) == ep, (w, h, k)
+
+
 def test_extreme_pixels_fused(ctx):
     """Saturated inputs exercise the clip after each pass and the signed-byte bias."""
     rng = np.random.default_rng(0)

@@ -128,8 +128,10 @@ void ke_build_mx(const KeAxisCoeffs &c, KeMxTable &t) {
             lo = std::min(lo, c.bounds[2 * o]);
             hi = std::max(hi, c.bounds[2 * o] + c.bounds[2 * o + 1]);
         }
-        t.base[j] = lo & ~15;
-        t.ks = std::max(t.ks, (hi - t.base[j] + 63) / 64);
+        // 64-aligned when that costs no extra step (the kernel's dHash leg shares A operands between axes then)
+        const int ks16 = (hi - (lo & ~15) + 63) / 64, ks64 = (hi - (lo & ~63) + 63) / 64;
+        t.base[j] = ks64 == ks16 ? (lo & ~63) : (lo & ~15);
+        t.ks = std::max(t.ks, ks16);
     }
     t.frag.assign((size_t)t.tiles * t.ks * 3 * 64 * 4, 0);
     for (int j = 0; j < t.tiles; ++j)

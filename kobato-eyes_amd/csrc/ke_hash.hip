@@ -15,6 +15,8 @@
 //     signed bytes, both resample passes run on v_dot4_i32_i8 with the 22-bit tap weights
 //     split into three signed byte planes.  HBM-bound by design: 3*W*H bytes in, 8 out.
 //   * generic passes (ke_resample_pass) for every other shape, channel count and for dHash.
+#include <type_traits>
+
 #include "ke_internal.h"
 #include "dct_table.h"
 
@@ -530,25 +532,32 @@ typedef int ke_v4i __attribute__((ext_vector_type(4)));
 
 struct KeFusedMxArgs {
     KeFusedArgs f;
-    const int32_t *mx_frag;   // KeMxTable::frag of the horizontal axis
-    int mx_base0, mx_base1;   // first tap column of the two output tiles (multiples of 16)
-    int lp;                   // LDS pitch of one luma row = W + 16
+    const int32_t *mx_frag;    // KeMxTable::frag of the 32-output horizontal axis
+    const int32_t *mxd_frag;   // ... of the 9-output dHash axis (DH instantiations)
+    int mx_base0, mx_base1;    // first tap column of the two 16-output tiles
+    int x_off;                 // LDS offset of the dHash exchange buffer (DH instantiations)
 };
 
-#ifndef KE_MX_WAVES
-#define KE_MX_WAVES 2
-#endif
-template <int W64, int KS>
-__global__ __launch_bounds__(256, KE_MX_WAVES) void ke_phash_fused_mx(const KeFusedMxArgs am) {
+// dHash leg (DH): the 9-output axis is one more 16-column operand tile whose taps span the whole row, W/64
+// steps.  Each wave runs the half of those steps whose A operands it already holds for its pHash outputs
+// (wave jt = 0: columns [0, W/2), jt = 1: [W/2, W) = its steps SD.. with SD = (W/2 - base1)/64); the jt = 1
+// wave hands its plane-combined partial sums to its partner through a 1 KB LDS slot, and the partner adds,
+// clips and writes the transposed dHash column one tile later (after the tile's barrier).
+template <int W64, int KS, bool DH>
+__global__ __launch_bounds__(256, 2) void ke_phash_fused_mx(const KeFusedMxArgs am) {
     const KeFusedArgs &a = am.f;
     constexpr int W = 64 * W64;
     constexpr int QW = W / 4;                    // 12-byte quads per row
     constexpr int QPT = kRTM * QW / 256;         // quads per thread per 32-row tile
     constexpr int QUADS_PER_TILE = kRTM * QW;
     constexpr int LP = W + 16;
+    constexpr int KD = W64 / 2;                  // dHash steps per wave
+    constexpr int SD1 = KS - KD;                 // first dHash step of the jt = 1 wave (checked on the host)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *Lt = smem;
     uint8_t *HT = smem + a.lt_bytes;
+    uint8_t *HTd = HT + 32 * a.hp;
+    uint8_t *X = smem + am.x_off;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
     const int64_t img = blockIdx.x;
@@ -564,10 +573,23 @@ __global__ __launch_bounds__(256, KE_MX_WAVES) void ke_phash_fused_mx(const KeFu
 #pragma unroll
         for (int p = 0; p < 3; ++p)
             bf[s][p] = reinterpret_cast<const ke_v4i *>(am.mx_frag)[((jt * KS + s) * 3 + p) * 64 + lane];
+    constexpr int KDR = DH ? KD : 1;
+    ke_v4i bd[KDR][3];
+    int dbias = 0;
+    if (DH) {
+#pragma unroll
+        for (int d = 0; d < KDR; ++d)
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                bd[d][p] = reinterpret_cast<const ke_v4i *>(am.mxd_frag)[((jt * KD + d) * 3 + p) * 64 + lane];
+        dbias = a.hd_bias[(lane & 15) < 9 ? (lane & 15) : 8];
+    }
     const int ocol = 16 * jt + (lane & 15);
     const int hbias = a.h_bias[ocol];
     const int a_off = (16 * mt + (lane & 15)) * LP + (jt ? am.mx_base1 : am.mx_base0) + 16 * (lane >> 4);
     uint8_t *ht_dst = HT + (size_t)ocol * a.hp + 16 * mt + 4 * (lane >> 4);
+    uint8_t *htd_dst = HTd + (size_t)(lane & 15) * a.hpd + 16 * mt + 4 * (lane >> 4);
+    ke_v4i *x_slot = reinterpret_cast<ke_v4i *>(X + mt * 1024 + lane * 16);     // + 2048 for odd tiles
 
     uint32_t raw[QPT][3];
     auto load_tile = [&](int t) {
@@ -592,22 +614,53 @@ __global__ __launch_bounds__(256, KE_MX_WAVES) void ke_phash_fused_mx(const KeFu
             *reinterpret_cast<uint32_t *>(dst + (i / QW) * LP + (i % QW) * 4) = luma4_biased(raw[q][0], raw[q][1], raw[q][2]);
         }
     };
-    auto hpass = [&](int t, const uint8_t *cur) {
-        ke_v4i acc[3];
+    auto pack_rows = [](const ke_v4i &v0, const ke_v4i &v1, const ke_v4i &v2, int bias) {
+        uint32_t packed = 0;
 #pragma unroll
-        for (int p = 0; p < 3; ++p) acc[p] = ke_v4i{0, 0, 0, 0};
+        for (int i = 0; i < 4; ++i) packed |= (uint32_t)clip8_fixed(combine_planes(v0[i], v1[i], v2[i], bias)) << (8 * i);
+        return packed ^ 0x80808080u;    // signed bytes for the vertical pass
+    };
+    // products of one tile; returns this wave's dHash partial (plane-combined, no bias)
+    auto products = [&](int t, const uint8_t *cur, auto sd_tag) -> ke_v4i {
+        constexpr int SD = decltype(sd_tag)::value;
+        ke_v4i acc[3], dacc[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) acc[p] = dacc[p] = ke_v4i{0, 0, 0, 0};
         const uint8_t *ap = cur + a_off;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             const ke_v4i av = *reinterpret_cast<const ke_v4i *>(__builtin_assume_aligned(ap + 64 * s, 16));
 #pragma unroll
             for (int p = 0; p < 3; ++p) acc[p] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, bf[s][p], acc[p], 0, 0, 0);
-        }
-        uint32_t packed = 0;
+            if (DH && s >= SD && s < SD + KD) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            packed |= (uint32_t)clip8_fixed(combine_planes(acc[0][i], acc[1][i], acc[2][i], hbias)) << (8 * i);
-        *reinterpret_cast<uint32_t *>(ht_dst + t * kRTM) = packed ^ 0x80808080u;   // signed bytes for the vertical pass
+                for (int p = 0; p < 3; ++p)
+                    dacc[p] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, bd[(s - SD) % KDR][p], dacc[p], 0, 0, 0);
+            }
+        }
+        *reinterpret_cast<uint32_t *>(ht_dst + t * kRTM) = pack_rows(acc[0], acc[1], acc[2], hbias);
+        ke_v4i part;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) part[i] = combine_planes(dacc[0][i], dacc[1][i], dacc[2][i], 0);
+        return part;
+    };
+    ke_v4i carry = {0, 0, 0, 0};
+    auto finish_dhash = [&](int t) {     // jt = 0 waves: tile t's dHash column from both halves
+        const ke_v4i other = x_slot[(t & 1) * 128];
+        const ke_v4i zero = {0, 0, 0, 0};
+        const ke_v4i sum = carry + other;
+        const uint32_t packed = pack_rows(sum, zero, zero, dbias);
+        if ((lane & 15) < 9) *reinterpret_cast<uint32_t *>(htd_dst + t * kRTM) = packed;
+    };
+    auto hpass = [&](int t, const uint8_t *cur) {
+        if (!DH) {
+            products(t, cur, std::integral_constant<int, 0>{});
+        } else if (jt) {
+            x_slot[(t & 1) * 128] = products(t, cur, std::integral_constant<int, SD1>{});
+        } else {
+            if (t > 0) finish_dhash(t - 1);
+            carry = products(t, cur, std::integral_constant<int, 0>{});
+        }
     };
 
     const int ntiles = (h + kRTM - 1) / kRTM;
@@ -624,12 +677,16 @@ __global__ __launch_bounds__(256, KE_MX_WAVES) void ke_phash_fused_mx(const KeFu
     }
     hpass(ntiles - 1, Lt + ((ntiles - 1) & 1) * a.lt_half);
     __syncthreads();
-    fused_tail<0>(a, Lt, HT, nullptr, tid, img);
+    if (DH) {
+        if (!jt) finish_dhash(ntiles - 1);
+        __syncthreads();
+    }
+    fused_tail<(DH ? 1 : 0)>(a, Lt, HT, HTd, tid, img);
 }
 
-template <int W64, int KS>
+template <int W64, int KS, bool DH>
 int launch_fused_mx(ke_ctx *ctx, const KeHashGroup &g, const KeAxisCoeffs *ch, const KeAxisCoeffs *cv, uint64_t *d_phash,
-                    uint8_t *d_tile32) {
+                    uint8_t *d_tile32, uint64_t *d_dhash, uint8_t *d_tile98) {
     constexpr int W = 64 * W64;
     const KeMxTable *mx = ke_get_mx(ctx, ch);
     if (!mx) return ke_fail(ctx, KE_EHIP, "coefficient upload failed");
@@ -642,17 +699,38 @@ int launch_fused_mx(ke_ctx *ctx, const KeHashGroup &g, const KeAxisCoeffs *ch, c
     a.v_packed = cv->d_packed; a.v_start = cv->d_start; a.v_bias = cv->d_bias;
     a.ndwv = cv->ndw;
     am.mx_frag = mx->d_frag; am.mx_base0 = mx->base[0]; am.mx_base1 = mx->base[1];
-    am.lp = W + 16;
     const int rows_padded = ((g.h + kRTM - 1) / kRTM) * kRTM;
     // one tile buffer: 32 padded rows + the part of the last row's operand window that overhangs the row
     const int overhang = std::max(0, std::max(mx->base[0], mx->base[1]) + 64 * KS - W);
-    a.lt_half = (kRTM * am.lp + overhang + 15) & ~15;
+    a.lt_half = (kRTM * (W + 16) + overhang + 15) & ~15;
     a.lt_bytes = 2 * a.lt_half;
     a.hp = ((std::max(cv->span, rows_padded) + 7) & ~7) + 8;
+    a.hpd = 8;
     a.phash = d_phash; a.tile32_out = d_tile32;
-    const size_t lds = (size_t)a.lt_bytes + (size_t)32 * a.hp;
+    size_t lds = (size_t)a.lt_bytes + (size_t)32 * a.hp;
+    if (DH) {
+        const KeAxisCoeffs *chd = ke_get_coeffs(ctx, g.w, 9), *cvd = ke_get_coeffs(ctx, g.h, 8);
+        if (!chd || !cvd) return ke_fail(ctx, KE_EHIP, "coefficient upload failed");
+        const KeMxTable *mxd = ke_get_mx(ctx, chd);
+        const KeChunkTable *tv = ke_get_chunks(ctx, cvd, 3);
+        if (!mxd || !tv) return ke_fail(ctx, KE_EHIP, "coefficient upload failed");
+        // the two halves of the dHash steps must be the A operands the waves already read for pHash
+        if (mxd->tiles != 1 || mxd->base[0] != 0 || mxd->ks != W64 || mx->base[0] != 0 ||
+            mx->base[1] + 64 * (KS - W64 / 2) != W / 2)
+            return KE_EUNSUPPORTED;
+        am.mxd_frag = mxd->d_frag;
+        a.hd_bias = chd->d_bias;
+        a.vd_cpacked = tv->d_cpacked; a.vd_cstart = tv->d_cstart; a.vd_bias = cvd->d_bias;
+        a.ndwcv = tv->ndwc;
+        a.hpd = ((std::max(tv->cspan, rows_padded) + 7) & ~7) + 8;
+        a.dhash = d_dhash; a.tile98_out = d_tile98;
+        lds += (size_t)9 * a.hpd;
+        lds = (lds + 15) & ~(size_t)15;
+        am.x_off = (int)lds;
+        lds += 4096;
+    }
     if (lds > 64 * 1024) return KE_EUNSUPPORTED;
-    hipLaunchKernelGGL((ke_phash_fused_mx<W64, KS>), dim3((unsigned)g.n), dim3(256), lds, ctx->stream, am);
+    hipLaunchKernelGGL((ke_phash_fused_mx<W64, KS, DH>), dim3((unsigned)g.n), dim3(256), lds, ctx->stream, am);
     KE_HIP(ctx, hipGetLastError());
     return KE_OK;
 }
@@ -1049,17 +1127,27 @@ int ke_launch_hash_group(ke_ctx *ctx, const KeHashGroup &g, uint64_t *d_phash, u
         if (!ch || !cv) return ke_fail(ctx, KE_EHIP, "coefficient upload failed");
         int rc = KE_EUNSUPPORTED;
         // offsets (ragged groups) are only 4-byte aligned when every image size is; w % 64 == 0 makes it so
+        const bool mx_on = !getenv("KE_NO_MX");      // horizontal taps on the matrix cores
         if (want_d && g.h != 8) {   // pHash + dHash in one pass over the pixels
-            if (g.w == 256 && ch->ndw == 16) rc = launch_fused<4, 16, 16>(ctx, g, ch, cv, d_phash, d_tile32_out, d_dhash, d_tile98_out);
-            else if (g.w == 384 && ch->ndw == 20) rc = launch_fused<6, 20, 24>(ctx, g, ch, cv, d_phash, d_tile32_out, d_dhash, d_tile98_out);
-            else if (g.w == 512 && ch->ndw == 24) rc = launch_fused<8, 24, 32>(ctx, g, ch, cv, d_phash, d_tile32_out, d_dhash, d_tile98_out);
+            if (mx_on) {
+                if (g.w == 256) rc = launch_fused_mx<4, 3, true>(ctx, g, ch, cv, d_phash, d_tile32_out, d_dhash, d_tile98_out);
+                else if (g.w == 384) rc = launch_fused_mx<6, 4, true>(ctx, g, ch, cv, d_phash, d_tile32_out, d_dhash, d_tile98_out);
+                else if (g.w == 512) rc = launch_fused_mx<8, 5, true>(ctx, g, ch, cv, d_phash, d_tile32_out, d_dhash, d_tile98_out);
+                if (rc != KE_OK && rc != KE_EUNSUPPORTED) return rc;
+            }
+            if (rc != KE_OK) {
+                if (g.w == 256 && ch->ndw == 16) rc = launch_fused<4, 16, 16>(ctx, g, ch, cv, d_phash, d_tile32_out, d_dhash, d_tile98_out);
+                else if (g.w == 384 && ch->ndw == 20) rc = launch_fused<6, 20, 24>(ctx, g, ch, cv, d_phash, d_tile32_out, d_dhash, d_tile98_out);
+                else if (g.w == 512 && ch->ndw == 24) rc = launch_fused<8, 24, 32>(ctx, g, ch, cv, d_phash, d_tile32_out, d_dhash, d_tile98_out);
+            }
             if (rc == KE_OK) p_done = d_done = true;
             else if (rc != KE_EUNSUPPORTED) return rc;
         }
-        if (!p_done && !getenv("KE_NO_MX")) {   // horizontal taps on the matrix cores
-            if (g.w == 256) rc = launch_fused_mx<4, 3>(ctx, g, ch, cv, d_phash, d_tile32_out);
-            else if (g.w == 384) rc = launch_fused_mx<6, 4>(ctx, g, ch, cv, d_phash, d_tile32_out);
-            else if (g.w == 512) rc = launch_fused_mx<8, 5>(ctx, g, ch, cv, d_phash, d_tile32_out);
+        if (!p_done && mx_on) {
+            rc = KE_EUNSUPPORTED;
+            if (g.w == 256) rc = launch_fused_mx<4, 3, false>(ctx, g, ch, cv, d_phash, d_tile32_out, nullptr, nullptr);
+            else if (g.w == 384) rc = launch_fused_mx<6, 4, false>(ctx, g, ch, cv, d_phash, d_tile32_out, nullptr, nullptr);
+            else if (g.w == 512) rc = launch_fused_mx<8, 5, false>(ctx, g, ch, cv, d_phash, d_tile32_out, nullptr, nullptr);
             if (rc == KE_OK) p_done = true;
             else if (rc != KE_EUNSUPPORTED) return rc;
         }

@@ -272,7 +272,7 @@ def main():
             "kernel_ms": {"hash": hash_avg, "scan": scan_avg, **({"ssim": state["ssim_ms"]} if "ssim_ms" in state else {})},
             **({"ssim": {"threshold": args.ssim_threshold, "pairs": state["ssim_pairs"], "quartiles": state["ssim_quartiles"],
                          "pairs_per_s": state["ssim_pairs"] / (state["ssim_ms"] * 1e-3)}} if "ssim_ms" in state else {}),
-            "roofline": {"bound": "hbm", "kernel": "ke_phash_fused", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "ke_phash_fused_mx", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic},
             "roofline_scan": {"bound": "hbm (16 B/pair convention, SURVEY 8d; operands are reused from LDS/registers so "
                                        "this can exceed 1; the real limiter is VALU)",

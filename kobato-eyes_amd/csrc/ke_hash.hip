@@ -10,10 +10,11 @@
 //   K3  dHash from the 9x8 tile
 //
 // Two paths, same arithmetic:
-//   * ke_phash_fused<W64,NDWH>: one workgroup per image, the whole chain in one launch; the
+//   * ke_phash_fused_mx<W64,KS,DH>: one workgroup per image, the whole chain in one launch; the
 //     image is streamed once from HBM (12 B/lane coalesced loads), luma goes to LDS as
-//     signed bytes, both resample passes run on v_dot4_i32_i8 with the 22-bit tap weights
-//     split into three signed byte planes.  HBM-bound by design: 3*W*H bytes in, 8 out.
+//     signed bytes, the 22-bit tap weights are split into three signed byte planes; the
+//     horizontal taps run on v_mfma_i32_16x16x64_i8, the (32x smaller) vertical taps on
+//     v_dot4_i32_i8.  HBM-bound by design: 3*W*H bytes in, 8 (16 with dHash) out.
 //   * generic passes (ke_resample_pass) for every other shape, channel count and for dHash.
 #include <type_traits>
 
@@ -176,12 +177,9 @@ __global__ __launch_bounds__(256) void ke_tiles_to_hashes(const uint8_t *__restr
 }
 
 // ---------------------------------------------------------------------------------------
-// Fused pHash kernel.  Template: W = 64*W64 pixels per row (RGB, 3 bytes/pixel), NDWH =
-// window dwords of the horizontal taps (multiple of 4).  One workgroup (256 threads) per
-// image; rows are streamed in tiles of RT = 16.
+// Pieces shared by the fused kernel and the banded path: luma of four packed RGB pixels, the byte-plane
+// recombination, the kernel arguments and the part of the chain behind the row loop.
 // ---------------------------------------------------------------------------------------
-constexpr int kRT = 16;
-
 __device__ __forceinline__ uint32_t luma4_biased(uint32_t d0, uint32_t d1, uint32_t d2) {
     // 19595 = 76*256+139, 38470 = 150*256+70, 7471 = 29*256+47: two u8 dot products per pixel.
     // The accumulator start folds in the +0x8000 rounding and the -128 bias of the signed
@@ -212,20 +210,24 @@ struct KeFusedArgs {
     uint64_t stride;
     const int64_t *out_idx;
     int h;
-    const int32_t *h_packed, *h_start, *h_bias;          // 32 outputs, NDWH dwords
-    const int32_t *v_packed, *v_start, *v_bias;          // 32 outputs, ndwv dwords
+    // horizontal axis (32 outputs): matrix-core operands (KeMxTable::frag), first tap column of the two
+    // 16-output tiles, rounding/bias term per output
+    const int32_t *mx_frag;
+    int mx_base0, mx_base1;
+    const int32_t *h_bias;
+    const int32_t *v_packed, *v_start, *v_bias;          // vertical axis: 32 outputs, ndwv window dwords
     int ndwv;
-    int lt_half;    // LDS bytes of ONE luma tile buffer (two are allocated; >= 1792 so 2 halves hold the DCT scratch)
+    int lt_half;    // LDS bytes of ONE luma tile buffer (two are allocated; the tail reuses them as scratch)
     int lt_bytes;   // = 2 * lt_half
     int hp;         // pitch of one HT column (bytes, multiple of 8)
     uint64_t *phash;
     uint8_t *tile32_out;  // nullable debug output
-    // dHash side (only read by the NDWD > 0 instantiations): 9 output columns x 3 chunks horizontally,
-    // 8 output rows x 3 chunks vertically
-    const int32_t *hd_cpacked, *hd_cstart, *hd_bias;
+    // dHash side (DH instantiations): operands of the 9-output horizontal axis, 8 output rows x 3 chunks vertically
+    const int32_t *mxd_frag, *hd_bias;
     const int32_t *vd_cpacked, *vd_cstart, *vd_bias;
     int ndwcv;      // chunk dwords of the vertical dHash axis
     int hpd;        // pitch of one dHash HT column (bytes, multiple of 8)
+    int x_off;      // LDS offset of the exchange buffer of the two half-row waves
     uint64_t *dhash;
     uint8_t *tile98_out;
 };
@@ -315,160 +317,6 @@ __device__ __forceinline__ void fused_tail(const KeFusedArgs &a, uint8_t *Lt, co
     }
 }
 
-template <int W64, int NDWH, int NDWD>
-#ifndef KE_FUSED_WAVES
-#define KE_FUSED_WAVES 3
-#endif
-__global__ __launch_bounds__(256, (NDWD > 0 ? 2 : KE_FUSED_WAVES)) void ke_phash_fused(const KeFusedArgs a) {
-    constexpr int W = 64 * W64;
-    constexpr int QPT = W64;                 // 12-byte quads per thread per 16-row tile
-    constexpr int QUADS_PER_TILE = kRT * W / 4;
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint8_t *Lt = smem;
-    uint8_t *HT = smem + a.lt_bytes;
-    uint8_t *HTd = HT + 32 * a.hp;          // 9 columns x hpd bytes (dHash instantiations only)
-    const int tid = threadIdx.x;
-    const int64_t img = blockIdx.x;
-    const uint8_t *src = a.pixels + (a.offsets ? a.offsets[img] : (uint64_t)img * a.stride);
-    const int h = a.h;
-    const int total_quads = h * (W / 4);
-
-    // horizontal tap planes of this thread's output column -> registers
-    const int o = tid & 31, rg = tid >> 5;
-    // hipcc pairs the two rows' reads into ds_read2st64_b64 (16-lane groups, 32 banks): lanes o and o+8 would
-    // hit the same banks, so every other group of 8 visits the dword pairs in swapped order
-    const int rot = (o >> 3) & 1;
-    int ck[NDWH][3];
-#pragma unroll
-    for (int p = 0; p < NDWH / 2; ++p) {
-        const int pp = p ^ rot;
-#pragma unroll
-        for (int e = 0; e < 2; ++e)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) ck[2 * p + e][c] = a.h_packed[((size_t)o * NDWH + 2 * pp + e) * 3 + c];
-    }
-    const int hst = a.h_start[o];
-    const int hbias = a.h_bias[o];
-    // dHash: lane o < 27 is virtual column (output o/3, chunk o%3) of the 9-wide axis
-    constexpr int ND = NDWD > 0 ? NDWD : 4;
-    int cd[ND][3];
-    int dst = 0, dbias = 0;
-    const bool d_lane = NDWD > 0 && o < 27;
-    if (NDWD > 0) {
-        const int vcol = o < 27 ? o : 26;
-#pragma unroll
-        for (int j = 0; j < ND; ++j)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) cd[j][c] = a.hd_cpacked[((size_t)vcol * ND + j) * 3 + c];
-        dst = a.hd_cstart[vcol];
-        dbias = a.hd_bias[vcol / 3];
-    }
-
-    // Software pipeline with the luma tile double-buffered in LDS: while the dot products of tile t
-    // run out of Lt[t&1], the 12-byte loads of tile t+1 are in flight; they are converted and
-    // written to Lt[(t+1)&1] at the end of the iteration.  One barrier per tile; the raw registers
-    // live inside one iteration only (a loop-carried register set makes hipcc wait for the loads
-    // right after issuing them).
-    uint32_t raw[QPT][3];
-    // byte offset of this thread's quads inside a tile: loop invariant, so a load is (scalar tile base) +
-    // (clamped 32-bit offset) -- one v_min per load instead of 64-bit address arithmetic
-    uint32_t voff[QPT];
-#pragma unroll
-    for (int q = 0; q < QPT; ++q) voff[q] = (uint32_t)(q * 256 + tid) * 12u;
-    const uint32_t image_bytes = (uint32_t)total_quads * 12u;   // h <= 1536, W <= 512: fits easily
-    auto load_tile = [&](int t) {
-        const uint32_t tile_off = (uint32_t)t * (uint32_t)(QUADS_PER_TILE * 12);
-        const uint8_t *tile_ptr = src + tile_off;                 // wave-uniform
-        const uint32_t lim = image_bytes - 12u - tile_off;        // last loadable quad, relative to the tile
-#pragma unroll
-        for (int q = 0; q < QPT; ++q) {
-            // Unconditional loads (a guarded load makes hipcc wait vmcnt(0) after each one): quads past
-            // the image end re-read the last quad; those rows only ever meet zero tap weights.
-            const uint32_t off = voff[q] < lim ? voff[q] : lim;
-            const uint32_t *p = reinterpret_cast<const uint32_t *>(tile_ptr + off);
-            // streamed once: non-temporal loads (+1.4 % measured, interleaved A/B on 100k x 512^2)
-            raw[q][0] = __builtin_nontemporal_load(p);
-            raw[q][1] = __builtin_nontemporal_load(p + 1);
-            raw[q][2] = __builtin_nontemporal_load(p + 2);
-        }
-    };
-    auto store_luma = [&](uint8_t *dst) {
-#pragma unroll
-        for (int q = 0; q < QPT; ++q)
-            reinterpret_cast<uint32_t *>(dst)[q * 256 + tid] = luma4_biased(raw[q][0], raw[q][1], raw[q][2]);
-    };
-
-    const int ntiles = (h + kRT - 1) / kRT;
-    load_tile(0);
-    store_luma(Lt);
-    __syncthreads();
-    auto hpass = [&](int t, const uint8_t *cur) {
-        // ---- K1b: horizontal taps: thread = (output column o, rows 2rg, 2rg+1)
-        uint32_t packed2 = 0;
-#pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-            const uint8_t *lrow = cur + (2 * rg + rr) * W + hst;
-            int d0 = 0, d1 = 0, d2 = 0;
-#pragma unroll
-            for (int p = 0; p < NDWH / 2; ++p) {
-                const int pp = p ^ rot;
-                const uint2 v = *reinterpret_cast<const uint2 *>(__builtin_assume_aligned(lrow + 8 * pp, 8));
-                d0 = __builtin_amdgcn_sdot4((int)v.x, ck[2 * p][0], d0, false);
-                d0 = __builtin_amdgcn_sdot4((int)v.y, ck[2 * p + 1][0], d0, false);
-#ifndef KE_EXP_ONEPLANE
-                d1 = __builtin_amdgcn_sdot4((int)v.x, ck[2 * p][1], d1, false);
-                d2 = __builtin_amdgcn_sdot4((int)v.x, ck[2 * p][2], d2, false);
-                d1 = __builtin_amdgcn_sdot4((int)v.y, ck[2 * p + 1][1], d1, false);
-                d2 = __builtin_amdgcn_sdot4((int)v.y, ck[2 * p + 1][2], d2, false);
-#endif
-            }
-            const int r = clip8_fixed(combine_planes(d0, d1, d2, hbias));
-            packed2 |= (uint32_t)(r ^ 0x80) << (8 * rr);  // signed byte again for the vertical dot products
-        }
-        *reinterpret_cast<uint16_t *>(HT + (size_t)o * a.hp + t * kRT + 2 * rg) = (uint16_t)packed2;
-        if (NDWD > 0) {
-            // ---- K1b for the 9-wide dHash axis: 27 lanes, chunk sums added across 3 adjacent lanes
-            uint32_t dp2 = 0;
-#pragma unroll
-            for (int rr = 0; rr < 2; ++rr) {
-                const uint8_t *lrow = cur + (2 * rg + rr) * W + dst;
-                int d0 = 0, d1 = 0, d2 = 0;
-#pragma unroll
-                for (int p = 0; p < ND / 2; ++p) {
-                    const uint2 v = *reinterpret_cast<const uint2 *>(__builtin_assume_aligned(lrow + 8 * p, 8));
-                    d0 = __builtin_amdgcn_sdot4((int)v.x, cd[2 * p][0], d0, false);
-                    d1 = __builtin_amdgcn_sdot4((int)v.x, cd[2 * p][1], d1, false);
-                    d2 = __builtin_amdgcn_sdot4((int)v.x, cd[2 * p][2], d2, false);
-                    d0 = __builtin_amdgcn_sdot4((int)v.y, cd[2 * p + 1][0], d0, false);
-                    d1 = __builtin_amdgcn_sdot4((int)v.y, cd[2 * p + 1][1], d1, false);
-                    d2 = __builtin_amdgcn_sdot4((int)v.y, cd[2 * p + 1][2], d2, false);
-                }
-                int part = combine_planes(d0, d1, d2, 0);
-                part += __shfl_down(part, 1) + __shfl_down(part, 2);      // chunks sit in lanes 3k, 3k+1, 3k+2
-                const int r = clip8_fixed((int)((uint32_t)part + (uint32_t)dbias));
-                dp2 |= (uint32_t)(r ^ 0x80) << (8 * rr);
-            }
-            if (d_lane && o % 3 == 0)
-                *reinterpret_cast<uint16_t *>(HTd + (size_t)(o / 3) * a.hpd + t * kRT + 2 * rg) = (uint16_t)dp2;
-        }
-    };
-    // the last tile is peeled: it has nothing to prefetch (a guarded prefetch would make hipcc wait for the
-    // loads right after issuing them, an unguarded one would fetch 1/ntiles more bytes from HBM)
-    for (int t = 0; t + 1 < ntiles; ++t) {
-        load_tile(t + 1);
-        __builtin_amdgcn_sched_barrier(0);   // keep the loads at the top: hipcc otherwise sinks them next to their use
-        hpass(t, Lt + (t & 1) * a.lt_half);
-        // ---- K1a for the next tile: luma of the loads issued above -> the other LDS buffer
-        __builtin_amdgcn_sched_barrier(0);   // ...and keep their first use down here, behind the dot products
-        store_luma(Lt + ((t + 1) & 1) * a.lt_half);
-        __syncthreads();
-    }
-    hpass(ntiles - 1, Lt + ((ntiles - 1) & 1) * a.lt_half);
-    __syncthreads();
-
-    fused_tail<NDWD>(a, Lt, HT, HTd, tid, img);
-}
-
 int upload_dct_tables(ke_ctx *ctx) {
     if (ctx->dct_tables_ready) return KE_OK;
     KE_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(c_C32), KE_C32, sizeof(KE_C32)));
@@ -478,65 +326,31 @@ int upload_dct_tables(ke_ctx *ctx) {
     return KE_OK;
 }
 
-template <int W64, int NDWH, int NDWD>
-int launch_fused(ke_ctx *ctx, const KeHashGroup &g, const KeAxisCoeffs *ch, const KeAxisCoeffs *cv, uint64_t *d_phash,
-                 uint8_t *d_tile32, uint64_t *d_dhash, uint8_t *d_tile98) {
-    constexpr int W = 64 * W64;
-    KeFusedArgs a;
-    std::memset(&a, 0, sizeof a);
-    a.pixels = g.pixels; a.offsets = g.offsets; a.stride = g.stride; a.out_idx = g.out_idx; a.h = g.h;
-    a.h_packed = ch->d_packed; a.h_start = ch->d_start; a.h_bias = ch->d_bias;
-    a.v_packed = cv->d_packed; a.v_start = cv->d_start; a.v_bias = cv->d_bias;
-    a.ndwv = cv->ndw;
-    int hspan = ch->span;
-    const int rows_padded = ((g.h + kRT - 1) / kRT) * kRT;
-    a.hpd = 8;
-    if (NDWD > 0) {
-        const KeAxisCoeffs *chd = ke_get_coeffs(ctx, g.w, 9), *cvd = ke_get_coeffs(ctx, g.h, 8);
-        if (!chd || !cvd) return ke_fail(ctx, KE_EHIP, "coefficient upload failed");
-        const KeChunkTable *th = ke_get_chunks(ctx, chd, 3), *tv = ke_get_chunks(ctx, cvd, 3);
-        if (!th || !tv) return ke_fail(ctx, KE_EHIP, "coefficient upload failed");
-        if (th->ndwc != NDWD) return KE_EUNSUPPORTED;
-        a.hd_cpacked = th->d_cpacked; a.hd_cstart = th->d_cstart; a.hd_bias = chd->d_bias;
-        a.vd_cpacked = tv->d_cpacked; a.vd_cstart = tv->d_cstart; a.vd_bias = cvd->d_bias;
-        a.ndwcv = tv->ndwc;
-        hspan = std::max(hspan, th->cspan);
-        a.hpd = ((std::max(tv->cspan, rows_padded) + 7) & ~7) + 8;
-    }
-    int lt = kRT * W + std::max(0, hspan - W) + 16;
-    if (lt < 1792) lt = 1792;
-    a.lt_half = (lt + 15) & ~15;
-    a.lt_bytes = 2 * a.lt_half;
-    a.hp = ((std::max(cv->span, rows_padded) + 7) & ~7) + 8;
-    a.phash = d_phash; a.tile32_out = d_tile32; a.dhash = d_dhash; a.tile98_out = d_tile98;
-    const size_t lds = (size_t)a.lt_bytes + (size_t)32 * a.hp + (NDWD > 0 ? (size_t)9 * a.hpd : 0);
-    if (lds > 64 * 1024) return KE_EUNSUPPORTED;
-    hipLaunchKernelGGL((ke_phash_fused<W64, NDWH, NDWD>), dim3((unsigned)g.n), dim3(256), lds, ctx->stream, a);
-    KE_HIP(ctx, hipGetLastError());
-    return KE_OK;
-}
-
 // ---------------------------------------------------------------------------------------
-// Fused pHash kernel, horizontal taps on the matrix cores.  Same chain and the same integers as
-// ke_phash_fused; what changes is K1b: the horizontal resample of a 32-row tile is the banded product
-// H[row][o] = sum_x luma[row][x] * k[o][x], and v_mfma_i32_16x16x64_i8 accumulates it exactly in int32 --
-// A = 16 rows x 64 signed luma bytes straight out of LDS (one ds_read_b128 per lane), B = one byte plane
-// of the taps of 16 outputs (KeMxTable, resident in registers), three planes combined as before.  Wave w
-// owns rows 16(w>>1).. of the tile and outputs 16(w&1)..; the result registers already hold four
-// consecutive rows of one output column, i.e. one dword of the transposed HT.  This takes the 144
-// v_dot4 per lane and 16 rows off the VALU, which was co-limiting the dot-product kernel at 6.5 TB/s.
+// Fused pHash (+ dHash) kernel.  Template: W = 64*W64 pixels per row (RGB, 3 bytes/pixel), KS = operand
+// steps of the horizontal taps, DH = also produce dHash.  One workgroup (256 threads) per image; rows are
+// streamed in tiles of 32 and the luma tile is double-buffered in LDS as signed bytes (L - 128).
+//
+// K1b on the matrix cores: the horizontal resample of a tile is the banded product
+// H[row][o] = sum_x luma[row][x] * k[o][x], which v_mfma_i32_16x16x64_i8 accumulates exactly in int32 --
+// A = 16 rows x 64 luma bytes straight out of LDS (one ds_read_b128 per lane), B = one byte plane of the
+// taps of 16 outputs (KeMxTable, resident in registers); the three planes of the 22-bit weights are combined
+// afterwards, k = b0 + 256 b1 + 65536 b2.  Wave w owns rows 16(w>>1).. of the tile and outputs 16(w&1)..;
+// its result registers hold four consecutive rows of one output column, i.e. one dword of the transposed
+// HT the vertical pass reads.  With the taps on the VALU (v_dot4_i32_i8, 144 per lane and 16 rows) the kernel
+// was co-limited by VALU issue at 6.5 TB/s; one byte plane less in an experiment already reached the
+// streaming-read ceiling (benchmarks/micro/hbm_read.hip: 7.0-7.1 TB/s), which is where this version sits.
 // LDS rows are padded by 16 bytes so the 16 rows of an A operand fall into distinct banks.
+//
+// Software pipeline: while the products of tile t run out of Lt[t&1], the 12-byte loads of tile t+1 are in
+// flight; they are converted and written to Lt[(t+1)&1] at the end of the iteration.  One barrier per tile;
+// the raw registers live inside one iteration only (a loop-carried register set makes hipcc wait for the
+// loads right after issuing them), and two sched_barriers keep the loads at the top and their first use at
+// the bottom.  The last tile is peeled: it has nothing to prefetch (a guarded prefetch would make hipcc wait
+// for the loads right after issuing them, an unguarded one would fetch 1/ntiles more bytes from HBM).
 // ---------------------------------------------------------------------------------------
 constexpr int kRTM = 32;
 typedef int ke_v4i __attribute__((ext_vector_type(4)));
-
-struct KeFusedMxArgs {
-    KeFusedArgs f;
-    const int32_t *mx_frag;    // KeMxTable::frag of the 32-output horizontal axis
-    const int32_t *mxd_frag;   // ... of the 9-output dHash axis (DH instantiations)
-    int mx_base0, mx_base1;    // first tap column of the two 16-output tiles
-    int x_off;                 // LDS offset of the dHash exchange buffer (DH instantiations)
-};
 
 // dHash leg (DH): the 9-output axis is one more 16-column operand tile whose taps span the whole row, W/64
 // steps.  Each wave runs the half of those steps whose A operands it already holds for its pHash outputs
@@ -544,8 +358,7 @@ struct KeFusedMxArgs {
 // wave hands its plane-combined partial sums to its partner through a 1 KB LDS slot, and the partner adds,
 // clips and writes the transposed dHash column one tile later (after the tile's barrier).
 template <int W64, int KS, bool DH>
-__global__ __launch_bounds__(256, 2) void ke_phash_fused_mx(const KeFusedMxArgs am) {
-    const KeFusedArgs &a = am.f;
+__global__ __launch_bounds__(256, 2) void ke_phash_fused_mx(const KeFusedArgs a) {
     constexpr int W = 64 * W64;
     constexpr int QW = W / 4;                    // 12-byte quads per row
     constexpr int QPT = kRTM * QW / 256;         // quads per thread per 32-row tile
@@ -557,7 +370,7 @@ __global__ __launch_bounds__(256, 2) void ke_phash_fused_mx(const KeFusedMxArgs 
     uint8_t *Lt = smem;
     uint8_t *HT = smem + a.lt_bytes;
     uint8_t *HTd = HT + 32 * a.hp;
-    uint8_t *X = smem + am.x_off;
+    uint8_t *X = smem + a.x_off;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
     const int64_t img = blockIdx.x;
@@ -572,7 +385,7 @@ __global__ __launch_bounds__(256, 2) void ke_phash_fused_mx(const KeFusedMxArgs 
     for (int s = 0; s < KS; ++s)
 #pragma unroll
         for (int p = 0; p < 3; ++p)
-            bf[s][p] = reinterpret_cast<const ke_v4i *>(am.mx_frag)[((jt * KS + s) * 3 + p) * 64 + lane];
+            bf[s][p] = reinterpret_cast<const ke_v4i *>(a.mx_frag)[((jt * KS + s) * 3 + p) * 64 + lane];
     constexpr int KDR = DH ? KD : 1;
     ke_v4i bd[KDR][3];
     int dbias = 0;
@@ -581,12 +394,12 @@ __global__ __launch_bounds__(256, 2) void ke_phash_fused_mx(const KeFusedMxArgs 
         for (int d = 0; d < KDR; ++d)
 #pragma unroll
             for (int p = 0; p < 3; ++p)
-                bd[d][p] = reinterpret_cast<const ke_v4i *>(am.mxd_frag)[((jt * KD + d) * 3 + p) * 64 + lane];
+                bd[d][p] = reinterpret_cast<const ke_v4i *>(a.mxd_frag)[((jt * KD + d) * 3 + p) * 64 + lane];
         dbias = a.hd_bias[(lane & 15) < 9 ? (lane & 15) : 8];
     }
     const int ocol = 16 * jt + (lane & 15);
     const int hbias = a.h_bias[ocol];
-    const int a_off = (16 * mt + (lane & 15)) * LP + (jt ? am.mx_base1 : am.mx_base0) + 16 * (lane >> 4);
+    const int a_off = (16 * mt + (lane & 15)) * LP + (jt ? a.mx_base1 : a.mx_base0) + 16 * (lane >> 4);
     uint8_t *ht_dst = HT + (size_t)ocol * a.hp + 16 * mt + 4 * (lane >> 4);
     uint8_t *htd_dst = HTd + (size_t)(lane & 15) * a.hpd + 16 * mt + 4 * (lane >> 4);
     ke_v4i *x_slot = reinterpret_cast<ke_v4i *>(X + mt * 1024 + lane * 16);     // + 2048 for odd tiles
@@ -598,7 +411,8 @@ __global__ __launch_bounds__(256, 2) void ke_phash_fused_mx(const KeFusedMxArgs 
         const uint32_t lim = image_bytes - 12u - tile_off;        // last loadable quad, relative to the tile
 #pragma unroll
         for (int q = 0; q < QPT; ++q) {
-            // unconditional, clamped, non-temporal: see ke_phash_fused
+            // Unconditional loads (a guarded load makes hipcc wait vmcnt(0) after each one): quads past the image
+            // end re-read the last quad; those rows only ever meet zero tap weights.  Streamed once: non-temporal.
             const uint32_t vo = (uint32_t)(q * 256 + tid) * 12u;
             const uint32_t off = vo < lim ? vo : lim;
             const uint32_t *p = reinterpret_cast<const uint32_t *>(tile_ptr + off);
@@ -667,7 +481,7 @@ __global__ __launch_bounds__(256, 2) void ke_phash_fused_mx(const KeFusedMxArgs 
     load_tile(0);
     store_luma(Lt);
     __syncthreads();
-    for (int t = 0; t + 1 < ntiles; ++t) {      // same pipeline as ke_phash_fused; last tile peeled
+    for (int t = 0; t + 1 < ntiles; ++t) {
         load_tile(t + 1);
         __builtin_amdgcn_sched_barrier(0);
         hpass(t, Lt + (t & 1) * a.lt_half);
@@ -691,14 +505,13 @@ int launch_fused_mx(ke_ctx *ctx, const KeHashGroup &g, const KeAxisCoeffs *ch, c
     const KeMxTable *mx = ke_get_mx(ctx, ch);
     if (!mx) return ke_fail(ctx, KE_EHIP, "coefficient upload failed");
     if (mx->tiles != 2 || mx->ks != KS) return KE_EUNSUPPORTED;
-    KeFusedMxArgs am;
-    std::memset(&am, 0, sizeof am);
-    KeFusedArgs &a = am.f;
+    KeFusedArgs a;
+    std::memset(&a, 0, sizeof a);
     a.pixels = g.pixels; a.offsets = g.offsets; a.stride = g.stride; a.out_idx = g.out_idx; a.h = g.h;
     a.h_bias = ch->d_bias;
     a.v_packed = cv->d_packed; a.v_start = cv->d_start; a.v_bias = cv->d_bias;
     a.ndwv = cv->ndw;
-    am.mx_frag = mx->d_frag; am.mx_base0 = mx->base[0]; am.mx_base1 = mx->base[1];
+    a.mx_frag = mx->d_frag; a.mx_base0 = mx->base[0]; a.mx_base1 = mx->base[1];
     const int rows_padded = ((g.h + kRTM - 1) / kRTM) * kRTM;
     // one tile buffer: 32 padded rows + the part of the last row's operand window that overhangs the row
     const int overhang = std::max(0, std::max(mx->base[0], mx->base[1]) + 64 * KS - W);
@@ -718,7 +531,7 @@ int launch_fused_mx(ke_ctx *ctx, const KeHashGroup &g, const KeAxisCoeffs *ch, c
         if (mxd->tiles != 1 || mxd->base[0] != 0 || mxd->ks != W64 || mx->base[0] != 0 ||
             mx->base[1] + 64 * (KS - W64 / 2) != W / 2)
             return KE_EUNSUPPORTED;
-        am.mxd_frag = mxd->d_frag;
+        a.mxd_frag = mxd->d_frag;
         a.hd_bias = chd->d_bias;
         a.vd_cpacked = tv->d_cpacked; a.vd_cstart = tv->d_cstart; a.vd_bias = cvd->d_bias;
         a.ndwcv = tv->ndwc;
@@ -726,11 +539,15 @@ int launch_fused_mx(ke_ctx *ctx, const KeHashGroup &g, const KeAxisCoeffs *ch, c
         a.dhash = d_dhash; a.tile98_out = d_tile98;
         lds += (size_t)9 * a.hpd;
         lds = (lds + 15) & ~(size_t)15;
-        am.x_off = (int)lds;
+        a.x_off = (int)lds;
         lds += 4096;
     }
-    if (lds > 64 * 1024) return KE_EUNSUPPORTED;
-    hipLaunchKernelGGL((ke_phash_fused_mx<W64, KS, DH>), dim3((unsigned)g.n), dim3(256), lds, ctx->stream, am);
+    // two workgroups per CU either way (registers), so a workgroup may take up to half of the 160 KB
+    if (lds > 80 * 1024) return KE_EUNSUPPORTED;
+    if (lds > 64 * 1024)
+        KE_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&ke_phash_fused_mx<W64, KS, DH>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((ke_phash_fused_mx<W64, KS, DH>), dim3((unsigned)g.n), dim3(256), lds, ctx->stream, a);
     KE_HIP(ctx, hipGetLastError());
     return KE_OK;
 }
@@ -909,7 +726,7 @@ __global__ __launch_bounds__(256, 3) void ke_hband(const KeBandArgs a) {
             if (writer) hb_col[t * a.rt + r] = (uint8_t)(clip8_fixed((int)((uint32_t)part + (uint32_t)obias)) ^ 0x80);
         }
     };
-    for (int t = 0; t + 1 < ntiles; ++t) {     // last tile peeled: nothing to prefetch (see ke_phash_fused)
+    for (int t = 0; t + 1 < ntiles; ++t) {     // last tile peeled: nothing to prefetch (see ke_phash_fused_mx)
         load_tile(y_begin + (t + 1) * a.rt);
         __builtin_amdgcn_sched_barrier(0);
         hpass(t, smem + (t & 1) * a.lt_half);
@@ -1127,34 +944,18 @@ int ke_launch_hash_group(ke_ctx *ctx, const KeHashGroup &g, uint64_t *d_phash, u
         if (!ch || !cv) return ke_fail(ctx, KE_EHIP, "coefficient upload failed");
         int rc = KE_EUNSUPPORTED;
         // offsets (ragged groups) are only 4-byte aligned when every image size is; w % 64 == 0 makes it so
-        const bool mx_on = !getenv("KE_NO_MX");      // horizontal taps on the matrix cores
         if (want_d && g.h != 8) {   // pHash + dHash in one pass over the pixels
-            if (mx_on) {
-                if (g.w == 256) rc = launch_fused_mx<4, 3, true>(ctx, g, ch, cv, d_phash, d_tile32_out, d_dhash, d_tile98_out);
-                else if (g.w == 384) rc = launch_fused_mx<6, 4, true>(ctx, g, ch, cv, d_phash, d_tile32_out, d_dhash, d_tile98_out);
-                else if (g.w == 512) rc = launch_fused_mx<8, 5, true>(ctx, g, ch, cv, d_phash, d_tile32_out, d_dhash, d_tile98_out);
-                if (rc != KE_OK && rc != KE_EUNSUPPORTED) return rc;
-            }
-            if (rc != KE_OK) {
-                if (g.w == 256 && ch->ndw == 16) rc = launch_fused<4, 16, 16>(ctx, g, ch, cv, d_phash, d_tile32_out, d_dhash, d_tile98_out);
-                else if (g.w == 384 && ch->ndw == 20) rc = launch_fused<6, 20, 24>(ctx, g, ch, cv, d_phash, d_tile32_out, d_dhash, d_tile98_out);
-                else if (g.w == 512 && ch->ndw == 24) rc = launch_fused<8, 24, 32>(ctx, g, ch, cv, d_phash, d_tile32_out, d_dhash, d_tile98_out);
-            }
+            if (g.w == 256) rc = launch_fused_mx<4, 3, true>(ctx, g, ch, cv, d_phash, d_tile32_out, d_dhash, d_tile98_out);
+            else if (g.w == 384) rc = launch_fused_mx<6, 4, true>(ctx, g, ch, cv, d_phash, d_tile32_out, d_dhash, d_tile98_out);
+            else if (g.w == 512) rc = launch_fused_mx<8, 5, true>(ctx, g, ch, cv, d_phash, d_tile32_out, d_dhash, d_tile98_out);
             if (rc == KE_OK) p_done = d_done = true;
             else if (rc != KE_EUNSUPPORTED) return rc;
         }
-        if (!p_done && mx_on) {
+        if (!p_done) {              // pHash alone (or the image is too tall for both columns sets to fit in LDS)
             rc = KE_EUNSUPPORTED;
             if (g.w == 256) rc = launch_fused_mx<4, 3, false>(ctx, g, ch, cv, d_phash, d_tile32_out, nullptr, nullptr);
             else if (g.w == 384) rc = launch_fused_mx<6, 4, false>(ctx, g, ch, cv, d_phash, d_tile32_out, nullptr, nullptr);
             else if (g.w == 512) rc = launch_fused_mx<8, 5, false>(ctx, g, ch, cv, d_phash, d_tile32_out, nullptr, nullptr);
-            if (rc == KE_OK) p_done = true;
-            else if (rc != KE_EUNSUPPORTED) return rc;
-        }
-        if (!p_done) {
-            if (g.w == 256 && ch->ndw == 16) rc = launch_fused<4, 16, 0>(ctx, g, ch, cv, d_phash, d_tile32_out, nullptr, nullptr);
-            else if (g.w == 384 && ch->ndw == 20) rc = launch_fused<6, 20, 0>(ctx, g, ch, cv, d_phash, d_tile32_out, nullptr, nullptr);
-            else if (g.w == 512 && ch->ndw == 24) rc = launch_fused<8, 24, 0>(ctx, g, ch, cv, d_phash, d_tile32_out, nullptr, nullptr);
             if (rc == KE_OK) p_done = true;
             else if (rc != KE_EUNSUPPORTED) return rc;
         }

@@ -137,13 +137,21 @@ int ke_ssim_pairs_uniform(ke_ctx *ctx, const uint8_t *images, int64_t n_images, 
  *
  * ke_resize_luma_uniform: n equally sized images -> n luma thumbnails of out_h rows x out_w bytes, exactly
  * image.convert("L").resize((out_w, out_h), filter) of Pillow; filter 0 = LANCZOS (src/sig/phash.py:24),
- * 1 = BILINEAR (src/ui/dup_refine_parallel.py:70, :204).
+ * 1 = BILINEAR (src/ui/dup_refine_parallel.py:70, :204), 2 = BICUBIC (src/dup/refine.py:48).
  * ke_tile_ahash: thumbnails of side grid*tile -> ceil((grid*tile)^2 / 64) little-endian u64 words per image;
  * bit i (order gy, gx, ty, tx) = pixel > mean of its tile.
  * ke_sad_pairs: sum |a - b| over two thumbnails of `pixels` bytes; MAE = sad / pixels / 255 on the host. */
-enum { KE_FILTER_LANCZOS = 0, KE_FILTER_BILINEAR = 1 };
+enum { KE_FILTER_LANCZOS = 0, KE_FILTER_BILINEAR = 1, KE_FILTER_BICUBIC = 2 };
 int ke_resize_luma_uniform(ke_ctx *ctx, const uint8_t *pixels, int64_t n, int32_t width, int32_t height,
                            int32_t channels, int32_t out_w, int32_t out_h, int32_t filter, uint8_t *tiles_out);
+/* ke_fit_luma_uniform: ImageOps.fit(image.convert("L"), (out_w, out_h), filter) of Pillow for n equally sized
+ * images -- centre crop to the target aspect ratio (default bleed 0, centering 0.5/0.5; the crop box is formed
+ * in Python's float arithmetic and handed to the resampler in single precision, as Pillow does), then
+ * Image.resize(size, filter, box=crop).  This is how src/dup/refine.py:44-49 brings two images of different
+ * size to the common (min width, min height) before SSIM; filter 2 = BICUBIC is the reference's choice.
+ * A target equal to the input size is a plain luma conversion. */
+int ke_fit_luma_uniform(ke_ctx *ctx, const uint8_t *pixels, int64_t n, int32_t width, int32_t height,
+                        int32_t channels, int32_t out_w, int32_t out_h, int32_t filter, uint8_t *tiles_out);
 int ke_tile_ahash(ke_ctx *ctx, const uint8_t *tiles, int64_t n, int32_t grid, int32_t tile, uint64_t *bits_out);
 int ke_sad_pairs(ke_ctx *ctx, const uint8_t *thumbs, int64_t n_thumbs, int64_t pixels, const int64_t *pair_a,
                  const int64_t *pair_b, int64_t n_pairs, uint64_t *sad_out);

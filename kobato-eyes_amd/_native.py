@@ -20,11 +20,13 @@ KE_OK = 0
 EDGE_DTYPE = np.dtype([("a", "<i8"), ("b", "<i8"), ("h", "<i4"), ("bands", "<i4")])
 
 # every symbol include/keyes.h declares (tests check the library exports all of them)
+FILTER_LANCZOS, FILTER_BILINEAR, FILTER_BICUBIC = 0, 1, 2   # include/keyes.h KE_FILTER_*
+
 EXPORTS = (
     "ke_abi_version", "ke_create", "ke_create_error", "ke_destroy", "ke_last_error", "ke_set_stream",
     "ke_get_stream", "ke_synchronize", "ke_device_info", "ke_malloc", "ke_free", "ke_memcpy",
     "ke_hash_images", "ke_hash_uniform", "ke_luma_tiles_uniform", "ke_hamming_scan", "ke_cluster_labels",
-    "ke_ssim_pairs_uniform", "ke_resize_luma_uniform", "ke_tile_ahash", "ke_sad_pairs", "ke_synth_rgb",
+    "ke_ssim_pairs_uniform", "ke_resize_luma_uniform", "ke_fit_luma_uniform", "ke_tile_ahash", "ke_sad_pairs", "ke_synth_rgb",
     "ke_synth_hashes", "ke_last_kernel_ms",
 )
 
@@ -76,6 +78,7 @@ def load_library() -> C.CDLL:
         lib.ke_cluster_labels.argtypes = [vp, i64, i64, vp]
         lib.ke_ssim_pairs_uniform.argtypes = [vp, vp, i64, i32, i32, i32, vp, vp, i64, vp]
         lib.ke_resize_luma_uniform.argtypes = [vp, vp, i64, i32, i32, i32, i32, i32, i32, vp]
+        lib.ke_fit_luma_uniform.argtypes = [vp, vp, i64, i32, i32, i32, i32, i32, i32, vp]
         lib.ke_tile_ahash.argtypes = [vp, vp, i64, i32, i32, vp]
         lib.ke_sad_pairs.argtypes = [vp, vp, i64, i64, vp, vp, i64, vp]
         lib.ke_synth_rgb.argtypes = [vp, u64, i64, i64, i32, i32, vp]
@@ -84,7 +87,7 @@ def load_library() -> C.CDLL:
         lib.ke_last_kernel_ms.restype = dbl
         for name in ("ke_set_stream", "ke_synchronize", "ke_device_info", "ke_malloc", "ke_free", "ke_memcpy",
                      "ke_hash_images", "ke_hash_uniform", "ke_luma_tiles_uniform", "ke_hamming_scan",
-                     "ke_cluster_labels", "ke_ssim_pairs_uniform", "ke_resize_luma_uniform", "ke_tile_ahash",
+                     "ke_cluster_labels", "ke_ssim_pairs_uniform", "ke_resize_luma_uniform", "ke_fit_luma_uniform", "ke_tile_ahash",
                      "ke_sad_pairs", "ke_synth_rgb", "ke_synth_hashes"):
             getattr(lib, name).restype = C.c_int
         _lib = lib
@@ -267,6 +270,19 @@ class Context:
         with self._lock:
             self._check(self._lib.ke_resize_luma_uniform(self._h, _addr(pixels), n, width, height, channels, out_w, out_h,
                                                          filter, _addr(out)), "ke_resize_luma_uniform")
+        return out
+
+    def fit_luma_uniform(self, pixels, n: int, width: int, height: int, channels: int, out_w: int, out_h: int,
+                         filter: int = 2, out=None):
+        """n images -> (n, out_h, out_w) u8: ImageOps.fit(image.convert("L"), (out_w, out_h), filter) of Pillow
+        (centre crop to the aspect ratio + resize); filter 2 = BICUBIC as src/dup/refine.py:48 uses."""
+        if isinstance(pixels, np.ndarray):
+            pixels = np.ascontiguousarray(pixels, dtype=np.uint8)
+        if out is None:
+            out = np.empty((n, out_h, out_w), np.uint8)
+        with self._lock:
+            self._check(self._lib.ke_fit_luma_uniform(self._h, _addr(pixels), n, width, height, channels, out_w, out_h,
+                                                      filter, _addr(out)), "ke_fit_luma_uniform")
         return out
 
     def tile_ahash(self, tiles, n: int, grid: int, tile: int):

@@ -78,12 +78,47 @@ static int upload_i32(ke_ctx *ctx, const std::vector<int32_t> &v, int32_t **out)
     return KE_OK;
 }
 
-const KeAxisCoeffs *ke_get_coeffs(ke_ctx *ctx, int in_size, int out_size, int filter) {
-    auto key = std::make_pair(in_size, out_size * 4 + filter);
+// Tap tables are cached per (axis length, outputs, filter, source interval).  A library of many image shapes would
+// grow the cache without bound, so the public entry points drop it once it holds more than kMaxCoeffTables tables
+// (after draining the stream: kernels in flight may still read them).
+constexpr size_t kMaxCoeffTables = 2048;
+
+static void free_coeff_cache(ke_ctx *ctx) {
+    for (auto &kv : ctx->coeffs) {
+        KeAxisCoeffs *c = kv.second;
+        for (int32_t *p : {c->d_bounds, c->d_kk, c->d_start, c->d_bias, c->d_packed})
+            if (p) (void)hipFree(p);
+        for (auto &ck : c->chunked) {
+            if (ck.second->d_cstart) (void)hipFree(ck.second->d_cstart);
+            if (ck.second->d_cpacked) (void)hipFree(ck.second->d_cpacked);
+            if (ck.second->d_cxor) (void)hipFree(ck.second->d_cxor);
+            delete ck.second;
+        }
+        if (c->mx) {
+            if (c->mx->d_frag) (void)hipFree(c->mx->d_frag);
+            delete c->mx;
+        }
+        delete c;
+    }
+    ctx->coeffs.clear();
+}
+
+static void trim_coeff_cache(ke_ctx *ctx) {
+    if (ctx->coeffs.size() <= kMaxCoeffTables) return;
+    (void)hipStreamSynchronize(ctx->stream);
+    free_coeff_cache(ctx);
+}
+
+const KeAxisCoeffs *ke_get_coeffs(ke_ctx *ctx, int in_size, int out_size, int filter, float in0, float in1) {
+    if (in1 < 0.0f) { in0 = 0.0f; in1 = (float)in_size; }
+    uint32_t b0, b1;
+    std::memcpy(&b0, &in0, 4);
+    std::memcpy(&b1, &in1, 4);
+    auto key = std::make_tuple(in_size, out_size * 4 + filter, b0, b1);
     auto it = ctx->coeffs.find(key);
     if (it != ctx->coeffs.end()) return it->second;
     auto *c = new KeAxisCoeffs();
-    ke_build_axis_coeffs(in_size, out_size, *c, filter);
+    ke_build_axis_coeffs(in_size, out_size, *c, filter, in0, in1);
     if (upload_i32(ctx, c->bounds, &c->d_bounds) || upload_i32(ctx, c->kk, &c->d_kk) ||
         upload_i32(ctx, c->start, &c->d_start) || upload_i32(ctx, c->bias, &c->d_bias) ||
         upload_i32(ctx, c->packed, &c->d_packed)) {
@@ -183,22 +218,7 @@ KE_API void ke_destroy(ke_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     for (auto &b : ctx->buf)
         if (b.ptr) (void)hipFree(b.ptr);
-    for (auto &kv : ctx->coeffs) {
-        KeAxisCoeffs *c = kv.second;
-        for (int32_t *p : {c->d_bounds, c->d_kk, c->d_start, c->d_bias, c->d_packed})
-            if (p) (void)hipFree(p);
-        for (auto &ck : c->chunked) {
-            if (ck.second->d_cstart) (void)hipFree(ck.second->d_cstart);
-            if (ck.second->d_cpacked) (void)hipFree(ck.second->d_cpacked);
-            if (ck.second->d_cxor) (void)hipFree(ck.second->d_cxor);
-            delete ck.second;
-        }
-        if (c->mx) {
-            if (c->mx->d_frag) (void)hipFree(c->mx->d_frag);
-            delete c->mx;
-        }
-        delete c;
-    }
+    free_coeff_cache(ctx);
     for (int k = 0; k < KE_T_COUNT; ++k) {
         (void)hipEventDestroy(ctx->ev0[k]);
         (void)hipEventDestroy(ctx->ev1[k]);
@@ -282,6 +302,7 @@ int hash_uniform_impl(ke_ctx *ctx, const uint8_t *pixels, int64_t n, int w, int 
     if (ch != 1 && ch != 3 && ch != 4) return ke_fail(ctx, KE_EINVAL, "channels must be 1, 3 or 4 (got %d)", ch);
     if (n == 0) return KE_OK;
     KE_HIP(ctx, hipSetDevice(ctx->device));
+    trim_coeff_cache(ctx);
     const size_t img_bytes = (size_t)w * h * ch;
     const bool in_dev = ke_is_device_ptr(pixels);
     HashOutputs o;
@@ -348,6 +369,7 @@ KE_API int ke_hash_images(ke_ctx *ctx, const uint8_t *pixels, const uint64_t *of
         return ke_fail(ctx, KE_EINVAL, "offsets/widths/heights/status are metadata and must be host arrays");
     if (n == 0) return KE_OK;
     KE_HIP(ctx, hipSetDevice(ctx->device));
+    trim_coeff_cache(ctx);
     // byte offset of every image, then group equal shapes (one launch group per distinct size)
     std::vector<uint64_t> off((size_t)n);
     uint64_t run = 0;
@@ -561,15 +583,42 @@ KE_API int ke_ssim_pairs_uniform(ke_ctx *ctx, const uint8_t *images, int64_t n_i
 }
 
 // ---- shipped refine stage: thumbnails, tile aHash, pixel MAE --------------------------------------
+static int resize_luma_common(ke_ctx *ctx, const uint8_t *pixels, int64_t n, int32_t width, int32_t height, int32_t channels,
+                              int32_t out_w, int32_t out_h, int32_t filter, const float *box, uint8_t *tiles_out);
+
 KE_API int ke_resize_luma_uniform(ke_ctx *ctx, const uint8_t *pixels, int64_t n, int32_t width, int32_t height,
                                   int32_t channels, int32_t out_w, int32_t out_h, int32_t filter, uint8_t *tiles_out) {
+    return resize_luma_common(ctx, pixels, n, width, height, channels, out_w, out_h, filter, nullptr, tiles_out);
+}
+
+KE_API int ke_fit_luma_uniform(ke_ctx *ctx, const uint8_t *pixels, int64_t n, int32_t width, int32_t height,
+                               int32_t channels, int32_t out_w, int32_t out_h, int32_t filter, uint8_t *tiles_out) {
+    if (!ctx) return KE_EINVAL;
+    if (width <= 0 || height <= 0 || out_w <= 0 || out_h <= 0) return ke_fail(ctx, KE_EINVAL, "sizes must be positive");
+    // PIL/ImageOps.py fit(): the same double-precision steps in the same order
+    const double live_ratio = (double)width / (double)height, out_ratio = (double)out_w / (double)out_h;
+    double cw, chh;
+    if (live_ratio == out_ratio) { cw = width; chh = height; }
+    else if (live_ratio >= out_ratio) { cw = out_ratio * height; chh = height; }
+    else { cw = width; chh = width / out_ratio; }
+    const double left = (width - cw) * 0.5, top = (height - chh) * 0.5;
+    const float box[4] = {(float)left, (float)top, (float)(left + cw), (float)(top + chh)};
+    if (box[0] < 0 || box[1] < 0 || box[2] > width || box[3] > height)   // Pillow raises ValueError here
+        return ke_fail(ctx, KE_EINVAL, "crop box outside the image");
+    return resize_luma_common(ctx, pixels, n, width, height, channels, out_w, out_h, filter, box, tiles_out);
+}
+
+static int resize_luma_common(ke_ctx *ctx, const uint8_t *pixels, int64_t n, int32_t width, int32_t height, int32_t channels,
+                              int32_t out_w, int32_t out_h, int32_t filter, const float *box, uint8_t *tiles_out) {
     if (!ctx) return KE_EINVAL;
     if (n < 0 || (n > 0 && (!pixels || !tiles_out))) return ke_fail(ctx, KE_EINVAL, "NULL argument");
     if (width <= 0 || height <= 0 || out_w <= 0 || out_h <= 0) return ke_fail(ctx, KE_EINVAL, "sizes must be positive");
     if (channels != 1 && channels != 3 && channels != 4) return ke_fail(ctx, KE_EINVAL, "channels must be 1, 3 or 4");
-    if (filter != KE_FILTER_LANCZOS && filter != KE_FILTER_BILINEAR) return ke_fail(ctx, KE_EINVAL, "unknown filter %d", filter);
+    if (filter != KE_FILTER_LANCZOS && filter != KE_FILTER_BILINEAR && filter != KE_FILTER_BICUBIC)
+        return ke_fail(ctx, KE_EINVAL, "unknown filter %d", filter);
     if (n == 0) return KE_OK;
     KE_HIP(ctx, hipSetDevice(ctx->device));
+    trim_coeff_cache(ctx);
     const size_t img_bytes = (size_t)width * height * channels, out_bytes = (size_t)out_w * out_h;
     const bool in_dev = ke_is_device_ptr(pixels), out_dev = ke_is_device_ptr(tiles_out);
     const int64_t chunk = in_dev ? n : std::max<int64_t>(1, (int64_t)(kStageBytes / img_bytes));
@@ -582,7 +631,7 @@ KE_API int ke_resize_luma_uniform(ke_ctx *ctx, const uint8_t *pixels, int64_t n,
         void *tmp;
         if (!out_dev) { KE_TRY(ke_reserve(ctx, KE_BUF_SSIM_IN, (size_t)m * out_bytes, &tmp)); d_out = (uint8_t *)tmp; }
         KeHashGroup g{(const uint8_t *)d_px, nullptr, img_bytes, nullptr, m, width, height, channels};
-        KE_TRY(ke_launch_resize_group(ctx, g, out_w, out_h, filter, d_out));
+        KE_TRY(ke_launch_resize_group(ctx, g, out_w, out_h, filter, d_out, box));
         if (!out_dev)
             KE_HIP(ctx, hipMemcpyAsync(tiles_out + (size_t)f * out_bytes, d_out, (size_t)m * out_bytes, hipMemcpyDeviceToHost, ctx->stream));
         if (!in_dev || !out_dev) KE_HIP(ctx, hipStreamSynchronize(ctx->stream));

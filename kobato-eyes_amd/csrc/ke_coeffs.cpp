@@ -33,13 +33,25 @@ inline double triangle(double x) {
     return x < 1.0 ? 1.0 - x : 0.0;
 }
 
+// Pillow's BICUBIC (Keys cubic convolution, a = -0.5, support 2): the resize inside ImageOps.fit of the SSIM
+// refine step (src/dup/refine.py:48-49)
+inline double bicubic(double x) {
+    const double a = -0.5;
+    if (x < 0.0) x = -x;
+    if (x < 1.0) return ((a + 2.0) * x - (a + 3.0)) * x * x + 1;
+    if (x < 2.0) return (((x - 5) * x + 8) * x - 4) * a;
+    return 0.0;
+}
+
 }  // namespace
 
-void ke_build_axis_coeffs(int in_size, int out_size, KeAxisCoeffs &c, int filter) {
+// [in0, in1): the source interval of the axis that maps onto the out_size outputs (Pillow's `box`, in the single
+// precision its C entry point receives); the whole axis is (0, in_size).
+void ke_build_axis_coeffs(int in_size, int out_size, KeAxisCoeffs &c, int filter, float in0, float in1) {
     c.in_size = in_size;
     c.out_size = out_size;
     c.bounds.assign(2 * (size_t)out_size, 0);
-    if (in_size == out_size) {
+    if (in_size == out_size && in0 == 0.0f && in1 == (float)in_size) {
         c.ksize = 1;
         c.kk.assign((size_t)out_size, 1 << kPrecisionBits);
         for (int o = 0; o < out_size; ++o) {
@@ -47,15 +59,15 @@ void ke_build_axis_coeffs(int in_size, int out_size, KeAxisCoeffs &c, int filter
             c.bounds[2 * o + 1] = 1;
         }
     } else {
-        const double scale = (double)in_size / (double)out_size;
+        const double scale = (double)(in1 - in0) / (double)out_size;
         const double fscale = scale < 1.0 ? 1.0 : scale;
-        const double support = (filter == KE_FILTER_BILINEAR ? 1.0 : 3.0) * fscale;
+        const double support = (filter == KE_FILTER_BILINEAR ? 1.0 : filter == KE_FILTER_BICUBIC ? 2.0 : 3.0) * fscale;
         const double inv = 1.0 / fscale;
         c.ksize = (int)std::ceil(support) * 2 + 1;
         c.kk.assign((size_t)out_size * c.ksize, 0);
         std::vector<double> w((size_t)c.ksize);
         for (int o = 0; o < out_size; ++o) {
-            const double center = (o + 0.5) * scale;
+            const double center = in0 + (o + 0.5) * scale;
             int lo = (int)(center - support + 0.5);
             if (lo < 0) lo = 0;
             int hi = (int)(center + support + 0.5);
@@ -64,7 +76,7 @@ void ke_build_axis_coeffs(int in_size, int out_size, KeAxisCoeffs &c, int filter
             double total = 0.0;
             for (int t = 0; t < cnt; ++t) {
                 const double arg = (t + lo - center + 0.5) * inv;
-                w[t] = filter == KE_FILTER_BILINEAR ? triangle(arg) : lanczos3(arg);
+                w[t] = filter == KE_FILTER_BILINEAR ? triangle(arg) : filter == KE_FILTER_BICUBIC ? bicubic(arg) : lanczos3(arg);
                 total += w[t];
             }
             int32_t *k = &c.kk[(size_t)o * c.ksize];

@@ -808,11 +808,12 @@ int launch_hband_ndwc(ke_ctx *ctx, const KeBandArgs &a, int64_t n, size_t lds, i
 
 // Banded target: src images -> (oh x ow) u8 tiles.  Returns KE_EUNSUPPORTED for shapes it does not take
 // (Pillow's vertical-first rule, images under 4 pixels, windows beyond 8 chunks of 32 dwords).
-int resample_banded(ke_ctx *ctx, const KeHashGroup &g, int ow, int oh, uint8_t *d_tiles, int filter = KE_FILTER_LANCZOS) {
+int resample_banded(ke_ctx *ctx, const KeHashGroup &g, int ow, int oh, uint8_t *d_tiles, int filter = KE_FILTER_LANCZOS,
+                    const float *box = nullptr) {
     if ((int64_t)g.h > (int64_t)g.w * 100 && oh < g.h) return KE_EUNSUPPORTED;
     if ((int64_t)g.w * g.h < 4 || g.w > 16384 || g.h > 65536 || (int64_t)g.w * g.h * g.channels >= (1LL << 31)) return KE_EUNSUPPORTED;
-    const KeAxisCoeffs *chz = ke_get_coeffs(ctx, g.w, ow, filter);
-    const KeAxisCoeffs *cvt = ke_get_coeffs(ctx, g.h, oh, filter);
+    const KeAxisCoeffs *chz = box ? ke_get_coeffs(ctx, g.w, ow, filter, box[0], box[2]) : ke_get_coeffs(ctx, g.w, ow, filter);
+    const KeAxisCoeffs *cvt = box ? ke_get_coeffs(ctx, g.h, oh, filter, box[1], box[3]) : ke_get_coeffs(ctx, g.h, oh, filter);
     if (!chz || !cvt) return ke_fail(ctx, KE_EHIP, "coefficient upload failed");
     // chunks per output: the power of two that wastes the fewest padded dwords, chunk <= 32 dwords; when the
     // virtual columns of all outputs do not fit the 256 lanes, the outputs are split over several launches
@@ -890,9 +891,10 @@ int resample_banded(ke_ctx *ctx, const KeHashGroup &g, int ow, int oh, uint8_t *
 }
 
 // Generic target: src images -> (oh x ow) u8 tiles, two single-axis passes in Pillow's order.
-int resample_generic(ke_ctx *ctx, const KeHashGroup &g, int ow, int oh, uint8_t *d_tiles, int filter = KE_FILTER_LANCZOS) {
-    const KeAxisCoeffs *chz = ke_get_coeffs(ctx, g.w, ow, filter);
-    const KeAxisCoeffs *cvt = ke_get_coeffs(ctx, g.h, oh, filter);
+int resample_generic(ke_ctx *ctx, const KeHashGroup &g, int ow, int oh, uint8_t *d_tiles, int filter = KE_FILTER_LANCZOS,
+                     const float *box = nullptr) {
+    const KeAxisCoeffs *chz = box ? ke_get_coeffs(ctx, g.w, ow, filter, box[0], box[2]) : ke_get_coeffs(ctx, g.w, ow, filter);
+    const KeAxisCoeffs *cvt = box ? ke_get_coeffs(ctx, g.h, oh, filter, box[1], box[3]) : ke_get_coeffs(ctx, g.h, oh, filter);
     if (!chz || !cvt) return ke_fail(ctx, KE_EHIP, "coefficient upload failed");
     // Pillow's Image.resize shrinks very tall, narrow images vertically first (PIL/Image.py).
     const bool vertical_first = (int64_t)g.h > (int64_t)g.w * 100 && oh < g.h;
@@ -904,7 +906,7 @@ int resample_generic(ke_ctx *ctx, const KeHashGroup &g, int ow, int oh, uint8_t 
             KeHashGroup s = g;
             s.n = std::min(max_n, g.n - f);
             if (g.offsets) s.offsets = g.offsets + f; else s.pixels = g.pixels + (size_t)f * g.stride;
-            KE_TRY(resample_generic(ctx, s, ow, oh, d_tiles + (size_t)f * ow * oh, filter));
+            KE_TRY(resample_generic(ctx, s, ow, oh, d_tiles + (size_t)f * ow * oh, filter, box));
         }
         return KE_OK;
     }
@@ -1005,7 +1007,7 @@ int ke_launch_hash_group(ke_ctx *ctx, const KeHashGroup &g, uint64_t *d_phash, u
 
 // Luma + resize of a group to (oh x ow) tiles: what _to_grayscale does for the hashes (LANCZOS) and what
 // the shipped refine stage does for its 32x32 / 128x128 thumbnails (BILINEAR).
-int ke_launch_resize_group(ke_ctx *ctx, const KeHashGroup &g, int ow, int oh, int filter, uint8_t *d_tiles) {
+int ke_launch_resize_group(ke_ctx *ctx, const KeHashGroup &g, int ow, int oh, int filter, uint8_t *d_tiles, const float *box) {
     if (ow <= 0 || oh <= 0 || ow > 4096 || oh > 4096) return ke_fail(ctx, KE_EINVAL, "bad output size %dx%d", ow, oh);
     const size_t per_img = (size_t)(ow + 8) * (std::max(g.h, oh) + 1024);
     const int64_t chunk = std::max<int64_t>(1, (int64_t)(((size_t)512 << 20) / per_img));
@@ -1014,8 +1016,8 @@ int ke_launch_resize_group(ke_ctx *ctx, const KeHashGroup &g, int ow, int oh, in
         s.n = std::min(chunk, g.n - f);
         if (g.offsets) s.offsets = g.offsets + f; else s.pixels = g.pixels + (size_t)f * g.stride;
         uint8_t *dst = d_tiles + (size_t)f * ow * oh;
-        int rc = resample_banded(ctx, s, ow, oh, dst, filter);
-        if (rc == KE_EUNSUPPORTED) rc = resample_generic(ctx, s, ow, oh, dst, filter);
+        int rc = resample_banded(ctx, s, ow, oh, dst, filter, box);
+        if (rc == KE_EUNSUPPORTED) rc = resample_generic(ctx, s, ow, oh, dst, filter, box);
         KE_TRY(rc);
     }
     return KE_OK;

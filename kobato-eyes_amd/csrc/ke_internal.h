@@ -7,6 +7,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <tuple>
 #include <utility>
 #include <vector>
 
@@ -66,7 +67,7 @@ struct KeChunkTable {
 };
 
 
-void ke_build_axis_coeffs(int in_size, int out_size, KeAxisCoeffs &out, int filter = KE_FILTER_LANCZOS);
+void ke_build_axis_coeffs(int in_size, int out_size, KeAxisCoeffs &out, int filter, float in0, float in1);
 void ke_build_chunked(const KeAxisCoeffs &c, int cpo, KeChunkTable &out, int ndwc_multiple = 4);
 void ke_build_mx(const KeAxisCoeffs &c, KeMxTable &out);
 
@@ -101,7 +102,7 @@ struct ke_ctx {
     hipStream_t stream = nullptr;
     std::string err;
     KeDevBuf buf[KE_BUF_COUNT];
-    std::map<std::pair<int, int>, KeAxisCoeffs *> coeffs;   // key: (in_size, out_size * 4 + filter)
+    std::map<std::tuple<int, int, uint32_t, uint32_t>, KeAxisCoeffs *> coeffs;   // key: (in_size, out_size * 4 + filter, bits of in0, in1)
     hipEvent_t ev0[KE_T_COUNT] = {}, ev1[KE_T_COUNT] = {};
     bool ev_valid[KE_T_COUNT] = {};
     bool dct_tables_ready = false;   // __constant__ tables are per device: uploaded once per context
@@ -128,7 +129,9 @@ int ke_reserve(ke_ctx *ctx, int which, size_t bytes, void **out);
 // Returns in *dev a device pointer holding `bytes` of `p` (p itself if it already is device memory,
 // else a staged copy in buffer `which`).
 int ke_to_device(ke_ctx *ctx, const void *p, size_t bytes, int which, const void **dev);
-const KeAxisCoeffs *ke_get_coeffs(ke_ctx *ctx, int in_size, int out_size, int filter = KE_FILTER_LANCZOS);
+// taps of one axis; (in0, in1) = source interval (Pillow's box), in1 < 0 means the whole axis
+const KeAxisCoeffs *ke_get_coeffs(ke_ctx *ctx, int in_size, int out_size, int filter = KE_FILTER_LANCZOS, float in0 = 0.0f,
+                                  float in1 = -1.0f);
 const KeChunkTable *ke_get_chunks(ke_ctx *ctx, const KeAxisCoeffs *c, int cpo, int ndwc_multiple = 4);
 const KeMxTable *ke_get_mx(ke_ctx *ctx, const KeAxisCoeffs *c);
 void ke_time_begin(ke_ctx *ctx, int kind);
@@ -146,7 +149,9 @@ struct KeHashGroup {
 int ke_launch_hash_group(ke_ctx *ctx, const KeHashGroup &g, uint64_t *d_phash, uint64_t *d_dhash,
                          uint8_t *d_tile32_out, uint8_t *d_tile98_out);
 // luma + resize of a group to (oh x ow) u8 tiles with the given filter (banded path, generic fallback)
-int ke_launch_resize_group(ke_ctx *ctx, const KeHashGroup &g, int ow, int oh, int filter, uint8_t *d_tiles);
+// box = {x0, y0, x1, y1} source rectangle (Pillow's resize box), NULL = the whole image
+int ke_launch_resize_group(ke_ctx *ctx, const KeHashGroup &g, int ow, int oh, int filter, uint8_t *d_tiles,
+                           const float *box = nullptr);
 int ke_launch_tile_ahash(ke_ctx *ctx, const uint8_t *d_tiles, int64_t n, int grid, int tile, uint64_t *d_bits);
 int ke_launch_sad_pairs(ke_ctx *ctx, const uint8_t *d_thumbs, int64_t pixels, const int64_t *d_pa, const int64_t *d_pb,
                         int64_t n_pairs, uint64_t *d_out);

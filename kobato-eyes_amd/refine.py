@@ -7,6 +7,7 @@ always None and the decision is ``ssim >= thresholds.ssim`` alone.
 """
 from __future__ import annotations
 
+import importlib
 import logging
 from dataclasses import dataclass
 from pathlib import Path
@@ -16,6 +17,8 @@ import numpy as np
 
 from . import _native
 from .image_io import load_rgb
+
+_phash = importlib.import_module(".phash", __package__)   # the package also exports a function named phash
 
 logger = logging.getLogger(__name__)
 
@@ -36,30 +39,35 @@ class RefinedMatch:
     reason: str
 
 
-def _gray_pair(img_a, img_b) -> tuple[np.ndarray, np.ndarray]:
-    """Both images as equally sized luma arrays, as src/dup/refine.py:45-49 prepares them:
-    common size = per-axis minimum, ImageOps.fit (centre crop + BICUBIC) -- an identity when the
-    sizes already agree, which is the only case the synthetic BASELINE configs exercise.  The
-    Pillow resize of the unequal case stays on the host (decode-side step)."""
-    from PIL import Image, ImageOps
-
+def _common_size(img_a, img_b) -> tuple[int, int]:
+    """(min width, min height) of the two images (src/dup/refine.py:45-47)."""
     size = (min(img_a.width, img_b.width), min(img_a.height, img_b.height))
     if size[0] == 0 or size[1] == 0:
         size = (max(img_a.width, img_b.width), max(img_a.height, img_b.height))
-    ga = ImageOps.fit(img_a.convert("L"), size, Image.Resampling.BICUBIC)
-    gb = ImageOps.fit(img_b.convert("L"), size, Image.Resampling.BICUBIC)
-    return np.asarray(ga), np.asarray(gb)
+    return size
 
 
 def compute_ssim(img_a, img_b, *, device: int = 0) -> float:
-    """SSIM of two PIL images (src/dup/refine.py:44-52)."""
-    ga, gb = _gray_pair(img_a, img_b)
-    h, w = ga.shape
+    """SSIM of two PIL images of any two sizes (src/dup/refine.py:44-52).
+
+    Both are brought to the common size the way the reference does -- ``ImageOps.fit(image.convert("L"), size,
+    BICUBIC)``: centre crop to the aspect ratio, Pillow's fixed-point bicubic resize -- by ``ke_fit_luma_uniform``;
+    the two luma planes stay in device memory for the SSIM kernel.
+    """
+    ctx = _native.get_context(device)
+    w, h = _common_size(img_a, img_b)
     if w < 7 or h < 7:
         raise ValueError("win_size exceeds image extent")  # what skimage raises for tiny images
-    stack = np.stack([ga, gb])
-    out = _native.get_context(device).ssim_pairs_uniform(stack, 2, w, h, 1, [0], [1])
-    return float(out[0])
+    planes = ctx.malloc(2 * w * h)
+    try:
+        for k, image in enumerate((img_a, img_b)):
+            arr = _phash.image_to_array(image)
+            channels = 1 if arr.ndim == 2 else arr.shape[2]
+            ctx.fit_luma_uniform(arr, 1, arr.shape[1], arr.shape[0], channels, w, h, _native.FILTER_BICUBIC,
+                                 out=planes + k * w * h)
+        return float(ctx.ssim_pairs_uniform(planes, 2, w, h, 1, [0], [1])[0])
+    finally:
+        ctx.free(planes)
 
 
 def ssim_pairs(images: np.ndarray, pair_a: Sequence[int], pair_b: Sequence[int], *, device: int = 0) -> np.ndarray:

@@ -66,19 +66,34 @@ static double ko_triangle(double x) {
     return x < 1.0 ? 1.0 - x : 0.0;
 }
 
-/* Fills bounds[2*out_size] = (first tap, tap count) and kk[out_size*ksize].
- * Returns ksize, or <0 on allocation failure.  Caller frees *bounds_p, *kk_p. */
-static int ko_axis_coeffs(int in_size, int out_size, int filter, int32_t **bounds_p, int32_t **kk_p);
-
-KO_API int ko_lanczos_coeffs(int in_size, int out_size, int32_t **bounds_p, int32_t **kk_p) {
-    return ko_axis_coeffs(in_size, out_size, 0, bounds_p, kk_p);
+/* Pillow BICUBIC (Keys cubic convolution, a = -0.5, support 2): the resize inside ImageOps.fit at
+ * src/dup/refine.py:48-49 (SSIM of two images of different size). */
+static double ko_bicubic(double x) {
+    const double a = -0.5;
+    if (x < 0.0) x = -x;
+    if (x < 1.0) return ((a + 2.0) * x - (a + 3.0)) * x * x + 1;
+    if (x < 2.0) return (((x - 5) * x + 8) * x - 4) * a;
+    return 0.0;
 }
 
-/* filter: 0 = LANCZOS, 1 = BILINEAR */
-static int ko_axis_coeffs(int in_size, int out_size, int filter, int32_t **bounds_p, int32_t **kk_p) {
-    double scale = (double)in_size / (double)out_size;
+static double ko_filter(int filter, double x) {
+    return filter == 1 ? ko_triangle(x) : filter == 2 ? ko_bicubic(x) : ko_lanczos3(x);
+}
+
+/* Fills bounds[2*out_size] = (first tap, tap count) and kk[out_size*ksize] for the source interval
+ * [in0, in1) of an axis of in_size samples (Pillow's `box`; single precision, as the C entry point
+ * receives it).  Returns ksize, or <0 on allocation failure.  Caller frees *bounds_p, *kk_p. */
+static int ko_axis_coeffs(int in_size, float in0, float in1, int out_size, int filter, int32_t **bounds_p, int32_t **kk_p);
+
+KO_API int ko_lanczos_coeffs(int in_size, int out_size, int32_t **bounds_p, int32_t **kk_p) {
+    return ko_axis_coeffs(in_size, 0.0f, (float)in_size, out_size, 0, bounds_p, kk_p);
+}
+
+/* filter: 0 = LANCZOS, 1 = BILINEAR, 2 = BICUBIC */
+static int ko_axis_coeffs(int in_size, float in0, float in1, int out_size, int filter, int32_t **bounds_p, int32_t **kk_p) {
+    double scale = (double)(in1 - in0) / (double)out_size;
     double filterscale = scale < 1.0 ? 1.0 : scale;
-    double support = (filter == 1 ? 1.0 : 3.0) * filterscale;
+    double support = (filter == 1 ? 1.0 : filter == 2 ? 2.0 : 3.0) * filterscale;
     int ksize = (int)ceil(support) * 2 + 1;
     int32_t *bounds = (int32_t *)malloc(sizeof(int32_t) * 2 * (size_t)out_size);
     int32_t *kk = (int32_t *)calloc((size_t)out_size * (size_t)ksize, sizeof(int32_t));
@@ -89,7 +104,7 @@ static int ko_axis_coeffs(int in_size, int out_size, int filter, int32_t **bound
     }
     double ss = 1.0 / filterscale;
     for (int xx = 0; xx < out_size; xx++) {
-        double center = (xx + 0.5) * scale;
+        double center = in0 + (xx + 0.5) * scale;
         int xmin = (int)(center - support + 0.5);
         if (xmin < 0) xmin = 0;
         int xmax = (int)(center + support + 0.5);
@@ -97,7 +112,7 @@ static int ko_axis_coeffs(int in_size, int out_size, int filter, int32_t **bound
         xmax -= xmin;
         double ww = 0.0;
         for (int x = 0; x < xmax; x++) {
-            w[x] = filter == 1 ? ko_triangle((x + xmin - center + 0.5) * ss) : ko_lanczos3((x + xmin - center + 0.5) * ss);
+            w[x] = ko_filter(filter, (x + xmin - center + 0.5) * ss);
             ww += w[x];
         }
         int32_t *k = kk + (size_t)xx * ksize;
@@ -124,34 +139,63 @@ static inline uint8_t ko_clip8(int32_t v) {
 
 /* L (h x w) -> out (oh x ow).  Horizontal pass first (only the rows the vertical
  * pass reads), u8 clip after each pass; a pass whose size is unchanged is skipped. */
-static int ko_resample_2pass(const uint8_t *L, int w, int h, int ow, int oh, uint8_t *out, int filter);
+static int ko_resample_2pass(const uint8_t *L, int w, int h, int ow, int oh, uint8_t *out, int filter, const float *box);
 KO_API int ko_resample(const uint8_t *L, int w, int h, int ow, int oh, int filter, uint8_t *out);
+KO_API int ko_resample_box(const uint8_t *L, int w, int h, int ow, int oh, int filter, const float *box, uint8_t *out);
 
 KO_API int ko_resample_lanczos(const uint8_t *L, int w, int h, int ow, int oh, uint8_t *out) {
     return ko_resample(L, w, h, ow, oh, 0, out);
 }
 
 KO_API int ko_resample(const uint8_t *L, int w, int h, int ow, int oh, int filter, uint8_t *out) {
+    const float box[4] = {0.0f, 0.0f, (float)w, (float)h};
+    return ko_resample_box(L, w, h, ow, oh, filter, box, out);
+}
+
+/* Image.resize(size, filter, box) on an "L" image (PIL/Image.py + ImagingResample). */
+KO_API int ko_resample_box(const uint8_t *L, int w, int h, int ow, int oh, int filter, const float *box, uint8_t *out) {
     if (w <= 0 || h <= 0 || ow <= 0 || oh <= 0) return -2;
+    if (box[0] < 0 || box[1] < 0 || box[2] > w || box[3] > h || box[2] - box[0] < 0 || box[3] - box[1] < 0) return -2;
     /* Pillow's Image.resize (PIL/Image.py, observed in 12.2.0): very tall, narrow images
      * shrink vertically first, as two separate single-axis resizes. */
     if ((int64_t)h > (int64_t)w * 100 && oh < h) {
         uint8_t *mid = (uint8_t *)malloc((size_t)w * (size_t)oh);
         if (!mid) return -1;
-        int rc = ko_resample_2pass(L, w, h, w, oh, mid, filter);
-        if (rc == 0) rc = ko_resample_2pass(mid, w, oh, ow, oh, out, filter);
+        const float b1[4] = {0.0f, box[1], (float)w, box[3]}, b2[4] = {box[0], 0.0f, box[2], (float)oh};
+        int rc = ko_resample_2pass(L, w, h, w, oh, mid, filter, b1);
+        if (rc == 0) rc = ko_resample_2pass(mid, w, oh, ow, oh, out, filter, b2);
         free(mid);
         return rc;
     }
-    return ko_resample_2pass(L, w, h, ow, oh, out, filter);
+    return ko_resample_2pass(L, w, h, ow, oh, out, filter, box);
 }
 
-static int ko_resample_2pass(const uint8_t *L, int w, int h, int ow, int oh, uint8_t *out, int filter) {
-    int need_h = (ow != w), need_v = (oh != h);
+/* ImageOps.fit(image, (ow, oh), method) with the default bleed = 0 and centering = (0.5, 0.5): the crop box
+ * in Python's float arithmetic (PIL/ImageOps.py), then Image.resize(size, method, box=crop), which is a copy
+ * when nothing changes.  src/dup/refine.py:48-49. */
+KO_API void ko_fit_box(int w, int h, int ow, int oh, float *box) {
+    const double live_ratio = (double)w / (double)h, out_ratio = (double)ow / (double)oh;
+    double cw, chh;
+    if (live_ratio == out_ratio) { cw = w; chh = h; }
+    else if (live_ratio >= out_ratio) { cw = out_ratio * h; chh = h; }
+    else { cw = w; chh = w / out_ratio; }
+    const double left = (w - cw) * 0.5, top = (h - chh) * 0.5;
+    box[0] = (float)left; box[1] = (float)top; box[2] = (float)(left + cw); box[3] = (float)(top + chh);
+}
+
+KO_API int ko_fit_luma(const uint8_t *L, int w, int h, int ow, int oh, int filter, uint8_t *out) {
+    float box[4];
+    ko_fit_box(w, h, ow, oh, box);
+    return ko_resample_box(L, w, h, ow, oh, filter, box, out);
+}
+
+static int ko_resample_2pass(const uint8_t *L, int w, int h, int ow, int oh, uint8_t *out, int filter, const float *box) {
+    int need_h = (ow != w) || box[0] != 0.0f || box[2] != (float)ow;
+    int need_v = (oh != h) || box[1] != 0.0f || box[3] != (float)oh;
     int32_t *bh = NULL, *kh = NULL, *bv = NULL, *kv = NULL;
     int ksh = 0, ksv = 0;
-    if (need_h && (ksh = ko_axis_coeffs(w, ow, filter, &bh, &kh)) < 0) return -1;
-    if (need_v && (ksv = ko_axis_coeffs(h, oh, filter, &bv, &kv)) < 0) { free(bh); free(kh); return -1; }
+    if (need_h && (ksh = ko_axis_coeffs(w, box[0], box[2], ow, filter, &bh, &kh)) < 0) return -1;
+    if (need_v && (ksv = ko_axis_coeffs(h, box[1], box[3], oh, filter, &bv, &kv)) < 0) { free(bh); free(kh); return -1; }
     const uint8_t *src = L;
     uint8_t *tmp = NULL;
     int src_w = w;

@@ -57,6 +57,10 @@ def lib() -> C.CDLL:
         L.ko_resample_lanczos.restype = C.c_int
         L.ko_resample.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.ko_resample.restype = C.c_int
+        L.ko_fit_luma.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.ko_fit_luma.restype = C.c_int
+        L.ko_fit_box.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.ko_fit_box.restype = None
         L.ko_tile_ahash.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.ko_tile_ahash.restype = None
         L.ko_dct8x8.argtypes = [C.c_void_p, C.c_void_p]
@@ -129,6 +133,31 @@ def resample_filter(L: np.ndarray, ow: int, oh: int, filter: int) -> np.ndarray:
     if rc:
         raise ValueError(f"ko_resample rc={rc}")
     return out
+
+
+def fit_luma(L: np.ndarray, ow: int, oh: int, filter: int = 2) -> np.ndarray:
+    """ImageOps.fit(L-image, (ow, oh), BICUBIC) -- centre crop to the target aspect, then Pillow's resize with
+    that box (src/dup/refine.py:48-49).  filter 2 = BICUBIC."""
+    L = np.ascontiguousarray(L, dtype=np.uint8)
+    out = np.empty((oh, ow), dtype=np.uint8)
+    rc = lib().ko_fit_luma(_ptr(L), L.shape[1], L.shape[0], ow, oh, filter, _ptr(out))
+    if rc:
+        raise ValueError(f"ko_fit_luma rc={rc}")
+    return out
+
+
+def fit_box(w: int, h: int, ow: int, oh: int) -> np.ndarray:
+    box = np.empty(4, dtype=np.float32)
+    lib().ko_fit_box(w, h, ow, oh, _ptr(box))
+    return box
+
+
+def ssim_fit(px_a: np.ndarray, px_b: np.ndarray) -> float:
+    """src/dup/refine.py:44-52 on decoded pixels of any two sizes."""
+    la = luma(px_a) if px_a.ndim == 3 else px_a
+    lb = luma(px_b) if px_b.ndim == 3 else px_b
+    w, h = min(la.shape[1], lb.shape[1]), min(la.shape[0], lb.shape[0])
+    return ssim_luma(fit_luma(la, w, h), fit_luma(lb, w, h))
 
 
 def tile_ahash_bits(px: np.ndarray, grid: int = 4, tile: int = 8) -> int:

@@ -60,6 +60,26 @@ def ssim_cases():
         yield name, g["a_" + name], g["b_" + name], float(g["ssim"][k])
 
 
+def fit_cases():
+    """ImageOps.fit + BICUBIC vectors: yields (name, px_a, px_b, (w, h), fitted_a, fitted_b, ssim)."""
+    from oracle import oracle as O
+
+    g = np.load(os.path.join(GOLDEN, "fit_golden.npz"))
+    for k, name in enumerate(g["names"]):
+        name = str(name)
+        ia, wa, ha = (int(v) for v in g["pa_" + name])
+        ib, wb, hb = (int(v) for v in g["pb_" + name])
+        yield (name, O.synth_rgb(ia, wa, ha), O.synth_rgb(ib, wb, hb), tuple(int(v) for v in g["size"][k]),
+               g["fa_" + name], g["fb_" + name], float(g["ssim"][k]))
+
+
+def fit_extra_cases():
+    """(luma input, (out_w, out_h), expected) for explicit target sizes, including upscaling."""
+    g = np.load(os.path.join(GOLDEN, "fit_golden.npz"))
+    for k in range(int(g["n_extra"])):
+        yield g[f"xin_{k}"], tuple(int(v) for v in g[f"xsize_{k}"]), g[f"xout_{k}"]
+
+
 def files_to_arrays(files):
     """(hashes u64, ids i64, sizes i64 with None->0) in list order."""
     hashes = np.array([f["phash"] & 0xFFFFFFFFFFFFFFFF for f in files], dtype=np.uint64)

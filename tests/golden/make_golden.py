@@ -317,6 +317,45 @@ def make_ssim():
     print("ssim:", dict(zip(store["names"].tolist(), store["ssim"].round(6).tolist())))
 
 
+# ------------------------------------------------------------------ ImageOps.fit + BICUBIC of the SSIM step
+def make_fit():
+    """What src/dup/refine.py:45-49 does to two images of different size before SSIM: both go through
+    ImageOps.fit(image.convert("L"), (min w, min h), BICUBIC).  Pillow is installed here, so these are the
+    reference's own pixels; the SSIM values beside them come from the SciPy restatement above."""
+    from PIL import ImageOps
+    # (synthetic image index, its w x h) pairs; sizes cover: wider / taller source, both axes resampled, one axis
+    # cropped only (integer box = plain crop), identity, odd sizes, Pillow's tall-image rule, tiny images
+    pairs = [((19, 160, 120), (O.synth_info(19)[0], 96, 96)), ((29, 200, 150), (O.synth_info(29)[0], 120, 150)),
+             ((3, 131, 77), (4, 64, 99)), ((5, 128, 128), (6, 128, 128)), ((7, 100, 80), (8, 80, 80)),
+             ((9, 90, 60), (10, 45, 30)), ((11, 33, 31), (12, 29, 37)), ((13, 3, 420), (14, 3, 200)),
+             ((15, 257, 64), (16, 64, 257))]
+    store = {"names": [], "ssim": [], "size": []}
+    for (ia, wa, ha), (ib, wb, hb) in pairs:
+        a, b = Image.fromarray(O.synth_rgb(ia, wa, ha)), Image.fromarray(O.synth_rgb(ib, wb, hb))
+        size = (min(a.width, b.width), min(a.height, b.height))
+        fa = np.asarray(ImageOps.fit(a.convert("L"), size, Image.Resampling.BICUBIC))
+        fb = np.asarray(ImageOps.fit(b.convert("L"), size, Image.Resampling.BICUBIC))
+        name = f"{ia}_{wa}x{ha}__{ib}_{wb}x{hb}"
+        store["names"].append(name)
+        store["size"].append(size)
+        store["ssim"].append(skimage_ssim_restated(fa, fb) if min(size) >= 7 else np.nan)
+        store["fa_" + name], store["fb_" + name] = fa, fb
+        store["pa_" + name], store["pb_" + name] = np.array([ia, wa, ha]), np.array([ib, wb, hb])
+    # upscaling and explicit target sizes (ImageOps.fit is also the thumbnail helper of Pillow)
+    rng = np.random.default_rng(23)
+    extra = []
+    for (w, h, ow, oh) in [(40, 30, 64, 64), (64, 48, 100, 20), (50, 50, 50, 49), (31, 17, 31, 17), (120, 9, 60, 9), (2, 2, 5, 3)]:
+        px = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        extra.append((px, (ow, oh), np.asarray(ImageOps.fit(Image.fromarray(px, "L"), (ow, oh), Image.Resampling.BICUBIC))))
+    store["n_extra"] = np.array(len(extra))
+    for k, (px, size, out) in enumerate(extra):
+        store[f"xin_{k}"], store[f"xsize_{k}"], store[f"xout_{k}"] = px, np.array(size), out
+    store["names"], store["ssim"], store["size"] = np.array(store["names"]), np.array(store["ssim"]), np.array(store["size"])
+    store["source"] = np.array(f"Pillow {Image.__version__} ImageOps.fit(convert('L'), size, BICUBIC); ssim = SciPy restatement")
+    np.savez_compressed(os.path.join(HERE, "fit_golden.npz"), **store)
+    print("fit:", dict(zip(store["names"].tolist(), np.round(store["ssim"], 6).tolist())))
+
+
 # ------------------------------------------------------------------ shipped refine stage (SURVEY 8f rank 1)
 def refine_corpus():
     """(name, pixel array) list; PNG round trips are lossless, so tests rebuild the very same files."""
@@ -451,6 +490,9 @@ if __name__ == "__main__":
     if "--only-image-io" in sys.argv:
         make_image_io()
         raise SystemExit(0)
+    if "--only-fit" in sys.argv:
+        make_fit()
+        raise SystemExit(0)
     if "--only-refine-parallel" in sys.argv:
         make_refine_parallel()
         raise SystemExit(0)
@@ -458,6 +500,7 @@ if __name__ == "__main__":
     make_scan()
     make_rows()
     make_ssim()
+    make_fit()
     make_refine_parallel()
     make_image_io()
     make_cluster_update()

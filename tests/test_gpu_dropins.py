@@ -104,6 +104,18 @@ def test_refine_pair_like_the_reference_tests(K, tmp_path):
     Image.new("RGB", (5, 5)).save(tiny)
     r = K.refine_pair(1, 2, tiny, tiny)                              # SSIM raises for < 7 px -> "ssim unavailable"
     assert r.ssim is None and not r.is_duplicate and r.reason == "ssim unavailable"
+    # two sizes of the same picture (the usual near-duplicate): both go through ImageOps.fit + BICUBIC on the GPU
+    big, small = tmp_path / "big.png", tmp_path / "small.png"
+    src = Image.fromarray(O.synth_rgb(5, 320, 240))
+    src.save(big)
+    src.resize((200, 160), Image.Resampling.LANCZOS).save(small)
+    r = K.refine_pair(7, 8, big, small, thresholds=K.RefinementThresholds(ssim=0.5))
+    exp = O.ssim_fit(np.asarray(Image.open(big).convert("RGB")), np.asarray(Image.open(small).convert("RGB")))
+    assert abs(r.ssim - exp) <= 1e-6 and r.is_duplicate == (exp >= 0.5)
+    from PIL import ImageOps
+    fa = np.asarray(ImageOps.fit(Image.open(big).convert("L"), (200, 160), Image.Resampling.BICUBIC))
+    fb = np.asarray(ImageOps.fit(Image.open(small).convert("L"), (200, 160), Image.Resampling.BICUBIC))
+    assert abs(r.ssim - O.ssim_luma(fa, fb)) <= 1e-6                 # the reference's own preprocessing, Pillow-made
 
 
 def test_find_duplicates_and_headless_scan(K, tmp_path):

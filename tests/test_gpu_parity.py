@@ -217,6 +217,38 @@ def test_ssim_matches_golden_and_oracle(ctx):
     assert np.isnan(ctx.ssim_pairs_uniform(tiny, 2, 9, 6, 1, [0], [1])[0])
 
 
+def test_fit_bicubic_matches_pillow_golden_and_oracle(ctx):
+    """ke_fit_luma_uniform = ImageOps.fit(convert("L"), size, BICUBIC) (src/dup/refine.py:45-49): Pillow's own
+    tiles from tests/golden/fit_golden.npz, bit for bit; then a seeded sweep against the oracle (itself pinned
+    against the installed Pillow on CPU) over channel counts, odd sizes, up- and downscaling, the tall-image
+    rule and batches."""
+    for name, px_a, px_b, (w, h), fa, fb, ssim in G.fit_cases():
+        for px, exp in ((px_a, fa), (px_b, fb)):
+            got = ctx.fit_luma_uniform(px[None], 1, px.shape[1], px.shape[0], 3, w, h)
+            assert np.array_equal(got[0], exp), name
+        if min(w, h) >= 7:
+            planes = np.stack([fa, fb])
+            assert abs(ctx.ssim_pairs_uniform(planes, 2, w, h, 1, [0], [1])[0] - ssim) <= 1e-6, name
+    for px, (ow, oh), exp in G.fit_extra_cases():
+        assert np.array_equal(ctx.fit_luma_uniform(px[None], 1, px.shape[1], px.shape[0], 1, ow, oh)[0], exp)
+    rng = np.random.default_rng(99)
+    shapes = [(640, 480, 3, 512, 384), (640, 480, 3, 400, 400), (1000, 800, 3, 500, 500), (1024, 768, 3, 1024, 700),
+              (513, 700, 4, 511, 699), (300, 451, 1, 256, 200), (2000, 5, 3, 900, 4), (5, 2000, 3, 4, 900), (3, 1000, 3, 3, 500),
+              (64, 64, 3, 100, 90), (1920, 1080, 3, 1280, 720), (512, 512, 3, 512, 512), (800, 600, 3, 600, 600)]
+    for _ in range(12):
+        shapes.append((int(rng.integers(8, 900)), int(rng.integers(8, 900)), int(rng.choice([1, 3, 4])),
+                       int(rng.integers(7, 600)), int(rng.integers(7, 600))))
+    for (w, h, ch, ow, oh) in shapes:
+        n = 2
+        px = rng.integers(0, 256, (n, h, w) if ch == 1 else (n, h, w, ch), dtype=np.uint8)
+        got = ctx.fit_luma_uniform(px, n, w, h, ch, ow, oh)
+        for k in range(n):
+            L = px[k] if ch == 1 else O.luma(px[k])
+            assert np.array_equal(got[k], O.fit_luma(L, ow, oh)), (w, h, ch, ow, oh, k)
+    with pytest.raises(ValueError):
+        ctx.fit_luma_uniform(px, n, w, h, ch, ow, oh, filter=7)
+
+
 def test_dropin_phash_module(ctx):
     from PIL import Image
 

@@ -115,6 +115,34 @@ def test_ssim_matches_restated_skimage():
     assert cases["ref_green_blue"] < 0.95
 
 
+def test_fit_bicubic_matches_pillow_golden():
+    """src/dup/refine.py:45-49: ImageOps.fit(convert("L"), (min w, min h), BICUBIC) -- the golden tiles are
+    Pillow's own output for these inputs; SSIM beside them is the SciPy restatement (unpinned vs skimage)."""
+    n = 0
+    for name, px_a, px_b, (w, h), fa, fb, ssim in G.fit_cases():
+        assert np.array_equal(O.fit_luma(O.luma(px_a), w, h), fa), name
+        assert np.array_equal(O.fit_luma(O.luma(px_b), w, h), fb), name
+        if min(w, h) >= 7:
+            assert abs(O.ssim_fit(px_a, px_b) - ssim) <= 1e-6, name
+        n += 1
+    for px, (ow, oh), exp in G.fit_extra_cases():
+        assert np.array_equal(O.fit_luma(px, ow, oh), exp), (px.shape, ow, oh)
+        n += 1
+    assert n >= 15
+
+
+def test_fit_bicubic_matches_installed_pillow():
+    Image = pytest.importorskip("PIL.Image")
+    from PIL import ImageOps
+    rng = np.random.default_rng(7)
+    for _ in range(60):
+        w, h = int(rng.integers(1, 300)), int(rng.integers(1, 300))
+        ow, oh = int(rng.integers(1, 200)), int(rng.integers(1, 200))
+        L = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        ref = np.asarray(ImageOps.fit(Image.fromarray(L, "L"), (ow, oh), Image.Resampling.BICUBIC))
+        assert np.array_equal(O.fit_luma(L, ow, oh), ref), (w, h, ow, oh)
+
+
 def test_cluster_builder_matches_reference_test():
     # tests/dup/test_cluster.py:9-23
     out = O.cluster_builder([(1, 2, True), (2, 3, True), (4, 5, True), (3, 5, False)])

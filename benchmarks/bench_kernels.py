@@ -65,7 +65,7 @@ def main():
             t = float(np.median(ms)) * 1e-3
             pairs = n * (n - 1) // 2
             emit(case="scan", n=n, ms=t * 1e3, edges=ne, gpairs_per_s=pairs / t / 1e9, hbm_convention_gbs=pairs * 16 / t / 1e9,
-                 frac_hbm_convention=pairs * 16 / t / 8e12, valu_frac=pairs * 4.5 / t / (256 * 4 * 32 * 2.4e9))
+                 frac_hbm_convention=pairs * 16 / t / 8e12, mfma_fp4_tflops=pairs * 256 / t / 1e12, frac_mfma_fp4=pairs * 256 / t / 1e16)
     if "ssim" in cases:
         for (w, h, n_img, n_pairs) in [(512, 512, 4000, 20000), (256, 256, 8000, 40000)]:
             px = torch.empty(n_img * w * h * 3, dtype=torch.uint8, device=dev)

@@ -90,6 +90,7 @@ enum {
     KE_BUF_SCAN_EDGES,
     KE_BUF_SCAN_CNT,
     KE_BUF_SCAN_HIST,
+    KE_BUF_SCAN_EXP,     // hashes expanded to matrix-core operands (64 B each)
     KE_BUF_SSIM_IN,
     KE_BUF_SSIM_AUX,
     KE_BUF_COUNT

@@ -1,28 +1,39 @@
 // ke_scan.hip -- K4: all-pairs Hamming candidate scan for gfx950.
 //
 // Replaces the bucket build + in-bucket pair loop of DuplicateScanner.build_clusters
-// (src/dup/scanner.py:227-299).  The pair space i<j is cut into TILE x TILE tiles of the upper
-// triangle; a workgroup owns one tile: each thread keeps RI row hashes in registers, the
-// column block sits in LDS and is read as wave-uniform (broadcast) 16-byte loads.  The hot
-// loop is 2 xor + 2 popcount + a running minimum per pair; only when the minimum of a group
-// of columns drops to the threshold does the thread re-walk that group and apply the full
-// predicate (band lanes, ids, size ratio, bucket cap) and append edges through one atomic
-// cursor.  No MFMA: nothing here is a contraction.
+// (src/dup/scanner.py:227-299).  The pair space i<j is cut into 1024 x 1024 tiles of the upper
+// triangle; a workgroup owns one tile.
+//
+// The Hamming distance itself runs on the matrix cores: with every hash written out as 128 one-bit
+// values [bits of x | bits of ~x], <row(x), row(y)> = popc(x & y) + popc(~x & ~y) = 64 - popc(x ^ y), so one
+// v_mfma_scale_f32_16x16x128_f8f6f4 with fp4 (E2M1) operands -- bit 1 = 1.0, exact, sums <= 64 exact in
+// f32 -- yields the 256 similarities of 16 x 16 hashes in 16 cycles.  A pre-pass expands the hashes once
+// (64 B each, already in operand order); a wave keeps the operands of 128 row hashes in registers and
+// walks the tile's columns out of LDS: 8 MFMAs per 16 columns, then one running maximum over the 32
+// results per lane.  Only when a 128 x 16 block holds a similarity >= 64 - threshold does the wave
+// re-inspect it and apply the full predicate (band lanes, ids, size ratio, bucket cap) to the original
+// 64-bit hashes and append edges through one atomic cursor.  The VALU version of the same loop
+// (2 xor + 2 popcount + min per pair) topped out at 7-8 Tpairs/s on VALU issue.
 #include <cmath>
 
 #include "ke_internal.h"
 
 namespace {
 
-constexpr int kThreads = 256;
-constexpr int kRI = 4;                      // row hashes per thread
-constexpr int kTile = kThreads * kRI;       // 1024 rows per workgroup ...
-constexpr int kCols = 256;                  // ... against 256 columns: fine-grained tiles keep the tail short at N = 100k
+constexpr int kThreads = 512;               // 8 waves
+constexpr int kRT = 8;                      // 16-hash row tiles per wave
+constexpr int kTile = 8 * kRT * 16;         // 1024 rows per workgroup ...
+constexpr int kCols = 1024;                 // ... against 1024 columns
 constexpr int kCPR = kTile / kCols;         // column chunks per row block
-constexpr int kGroup = 8;                   // columns between threshold checks
+constexpr int kChunk = 256;                 // columns staged in LDS at a time (16 operand tiles, 16 KB)
+
+typedef int ke_v8i __attribute__((ext_vector_type(8)));
+typedef int ke_v4i __attribute__((ext_vector_type(4)));
+typedef float ke_v4f __attribute__((ext_vector_type(4)));
 
 struct ScanArgs {
     const uint64_t *hashes;
+    const ke_v4i *expanded;  // operand tiles: [hash / 16][lane = group * 16 + hash % 16] x 16 B, zero beyond n
     const int64_t *ids;
     const int64_t *sizes;
     int64_t n;
@@ -76,9 +87,36 @@ __device__ void consider_pair(const ScanArgs &a, int64_t gi, int64_t gj, uint64_
     }
 }
 
+// 8 bits -> 8 E2M1 nibbles (bit n -> nibble n = 0b0010 = 1.0 or 0)
+__device__ __forceinline__ uint32_t spread8(uint32_t b) {
+    uint32_t t = (b | (b << 12)) & 0x000F000Fu;
+    t = (t | (t << 6)) & 0x03030303u;
+    t = (t | (t << 3)) & 0x11111111u;
+    return t << 1;
+}
+
+// Operand image of the hashes.  Lane group g of a 16-hash tile holds 32 of the 128 values of each hash:
+// g = 0, 1: bits 0..31 / 32..63 of x; g = 2, 3: the same bits of ~x.  A and B operands use the same image
+// (the k <-> (group, nibble) map of the instruction is the same for both, so any fixed order works).
+__global__ __launch_bounds__(256) void ke_scan_expand(const uint64_t *__restrict__ hashes, int64_t n, int64_t n_pad,
+                                                       ke_v4i *__restrict__ out) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;     // = tile * 64 + lane
+    if (e >= n_pad * 4) return;
+    const int64_t i = (e >> 6) * 16 + (e & 15);
+    const int g = (int)(e >> 4) & 3;
+    ke_v4i v = {0, 0, 0, 0};
+    if (i < n) {
+        const uint64_t x = g < 2 ? hashes[i] : ~hashes[i];
+        const uint32_t half = (uint32_t)(x >> (32 * (g & 1)));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = (int)spread8((half >> (8 * k)) & 0xFFu);
+    }
+    out[e] = v;
+}
+
 __global__ __launch_bounds__(kThreads) void ke_scan_tiles(const ScanArgs a) {
-    __shared__ __attribute__((aligned(16))) uint64_t s_cols[kCols];
-    const int tid = threadIdx.x;
+    __shared__ ke_v4i s_b[2][kChunk / 16 * 64];      // two chunks of 16 operand tiles
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int64_t t = a.first_tile + (int64_t)blockIdx.x * a.tile_step;
     if (t >= a.n_tiles) return;
     // Tiles of the upper triangle, row-major: row block rb owns column chunks kCPR*rb .. ncc-1, so
@@ -91,46 +129,73 @@ __global__ __launch_bounds__(kThreads) void ke_scan_tiles(const ScanArgs a) {
     while (rb + 1 < a.nb && (rb + 1) * a.ncc - kCPR * (rb + 1) * rb / 2 <= t) ++rb;
     const int64_t cc = kCPR * rb + (t - (rb * a.ncc - kCPR * rb * (rb - 1) / 2));
     const int64_t row0 = rb * kTile, col0 = cc * kCols;
+    const int64_t wrow0 = row0 + (int64_t)wv * (kRT * 16);          // this wave's 128 rows
 
-    uint32_t xlo[kRI], xhi[kRI];
+    // row operands: registers for the whole tile (only dwords 0..3 of an fp4 operand are read)
+    ke_v8i ra[kRT];
 #pragma unroll
-    for (int r = 0; r < kRI; ++r) {
-        const int64_t gi = row0 + r * kThreads + tid;
-        const uint64_t x = gi < a.n ? a.hashes[gi] : 0ull;
-        xlo[r] = (uint32_t)x;
-        xhi[r] = (uint32_t)(x >> 32);
+    for (int r = 0; r < kRT; ++r) {
+        const ke_v4i v = a.expanded[(wrow0 / 16 + r) * 64 + lane];
+        ra[r] = ke_v8i{v[0], v[1], v[2], v[3], 0, 0, 0, 0};
     }
-    {
-        const int64_t gj = col0 + tid;
-        s_cols[tid] = gj < a.n ? a.hashes[gj] : ~0ull;
-    }
+    // The similarities are small non-negative integers held as floats, so their bit patterns order like
+    // integers: the running maximum is an integer max (a float max would first canonicalise every input).
+    const int thr_bits = __float_as_int((float)(64 - a.threshold));
+    const int nchunks = (int)((min((int64_t)kCols, a.n - col0) + kChunk - 1) / kChunk);
+    // column operands: 16 KB per chunk, two 16-byte pieces per thread, next chunk in flight during the products
+    const ke_v4i *cbase = a.expanded + (col0 / 16) * 64;
+    ke_v4i pre0 = cbase[tid], pre1 = cbase[kThreads + tid];
+    s_b[0][tid] = pre0;
+    s_b[0][kThreads + tid] = pre1;
+    // every load so far has landed from here on: without this hipcc re-waits for the row operands inside the
+    // loop with counts that also drain the column prefetch issued at the top of each iteration
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
     __syncthreads();
-
-    const int thr = a.threshold;
-    const int ncols = (int)((a.n - col0) < kCols ? (a.n - col0) : kCols);
-    for (int c0 = 0; c0 < ncols; c0 += kGroup) {
-        int best = 64;
-#pragma unroll
-        for (int c = 0; c < kGroup; c += 2) {
-            const uint4 yy = *reinterpret_cast<const uint4 *>(&s_cols[c0 + c]);  // two columns, broadcast read
-#pragma unroll
-            for (int r = 0; r < kRI; ++r) {
-                const int p0 = popc64(xlo[r] ^ yy.x, xhi[r] ^ yy.y);
-                const int p1 = popc64(xlo[r] ^ yy.z, xhi[r] ^ yy.w);
-                best = min(best, min(p0, p1));
-            }
+    for (int c = 0; c < nchunks; ++c) {
+        {   // unconditional (the last iteration re-reads its own chunk): a guarded load is waited for at once
+            const int cn = c + 1 < nchunks ? c + 1 : c;
+            pre0 = cbase[cn * (kChunk / 16 * 64) + tid];
+            pre1 = cbase[cn * (kChunk / 16 * 64) + kThreads + tid];
         }
-        if (best <= thr) {
-            for (int c = 0; c < kGroup; ++c) {
-                const uint64_t y = s_cols[c0 + c];
+        const ke_v4i *bt = s_b[c & 1];
+        for (int ct = 0; ct < kChunk / 16; ++ct) {
+            const ke_v4i bv = bt[ct * 64 + lane];
+            const ke_v8i b = {bv[0], bv[1], bv[2], bv[3], 0, 0, 0, 0};
+            ke_v4f acc[kRT];
 #pragma unroll
-                for (int r = 0; r < kRI; ++r) {
-                    const uint64_t x = ((uint64_t)xhi[r] << 32) | xlo[r];
-                    const int pc = __popcll(x ^ y);
-                    if (pc <= thr) consider_pair(a, row0 + r * kThreads + tid, col0 + c0 + c, x, y, pc);
+            for (int r = 0; r < kRT; ++r)
+                acc[r] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(ra[r], b, ke_v4f{0, 0, 0, 0}, 4, 4, 0, 0, 0, 0);
+            int m = 0;
+#pragma unroll
+            for (int r = 0; r < kRT; ++r) {
+                m = max(max(m, __float_as_int(acc[r][0])), __float_as_int(acc[r][1]));
+                m = max(max(m, __float_as_int(acc[r][2])), __float_as_int(acc[r][3]));
+            }
+            if (__ballot(m >= thr_bits) != 0ull) {
+                // Rare: collect which of this lane's 32 results qualify into a bit mask, then walk the mask with the
+                // original hashes (result map: lane l holds rows 4(l>>4) + i of row tile r, column l & 15).
+                uint32_t hits = 0;
+#pragma unroll
+                for (int r = 0; r < kRT; ++r)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) hits |= __float_as_int(acc[r][i]) >= thr_bits ? 1u << (4 * r + i) : 0u;
+                const int64_t gj = col0 + (int64_t)c * kChunk + ct * 16 + (lane & 15);
+                if (gj >= a.n) hits = 0;
+                const uint64_t y = hits ? a.hashes[gj] : 0ull;
+                while (hits) {
+                    const int k = __ffs(hits) - 1;
+                    hits &= hits - 1;
+                    const int64_t gi = wrow0 + (k >> 2) * 16 + 4 * (lane >> 4) + (k & 3);
+                    if (gi < gj) {
+                        const uint64_t x = a.hashes[gi];
+                        consider_pair(a, gi, gj, x, y, __popcll(x ^ y));
+                    }
                 }
             }
         }
+        s_b[(c + 1) & 1][tid] = pre0;
+        s_b[(c + 1) & 1][kThreads + tid] = pre1;
+        __syncthreads();
     }
 }
 
@@ -173,8 +238,14 @@ int ke_launch_scan(ke_ctx *ctx, const uint64_t *d_hashes, const int64_t *d_ids, 
         a.hist = (const uint32_t *)h;
     }
     const int64_t my_tiles = a.n_tiles > part_index ? (a.n_tiles - part_index + part_count - 1) / part_count : 0;
+    const int64_t n_pad = (int64_t)a.nb * kTile;     // the kernel reads whole tiles: operands beyond n are zero
+    void *exp;
+    KE_TRY(ke_reserve(ctx, KE_BUF_SCAN_EXP, (size_t)n_pad * 64, &exp));
+    a.expanded = (const ke_v4i *)exp;
     ke_time_begin(ctx, KE_T_SCAN);
     if (my_tiles > 0) {
+        hipLaunchKernelGGL(ke_scan_expand, dim3((unsigned)((n_pad * 4 + 255) / 256)), dim3(256), 0, ctx->stream, d_hashes, n, n_pad,
+                           (ke_v4i *)exp);
         if (my_tiles > 0x7fffffffLL) return ke_fail(ctx, KE_EUNSUPPORTED, "too many tiles for one launch");
         hipLaunchKernelGGL(ke_scan_tiles, dim3((unsigned)my_tiles), dim3(kThreads), 0, ctx->stream, a);
         KE_HIP(ctx, hipGetLastError());

@@ -67,26 +67,48 @@ def gather_edges(edges: np.ndarray, *, group=None, dst: Optional[int] = None) ->
     return np.concatenate(parts) if parts else edges
 
 
+_edge_slots_hint: dict = {}     # per process group: edge records every rank sends along with its count
+
+
 def allgather_edge_buffers(edges_u8, count: int, *, group=None):
-    """Device-side merge of the per-rank edge lists: all-gather of the counts, then of the edge
-    buffers cut to the largest count.  ``edges_u8``: this rank's uint8 tensor holding ``count``
-    24-byte ke_edge records at its start.  Returns (host ndarray of all edges as raw bytes viewed
-    per record by the caller, per-rank counts)."""
+    """Device-side merge of the per-rank edge lists, normally ONE collective: every rank sends a fixed-width
+    record ``[count:int64 | first K edges]`` and the counts are read from the gathered headers.  K follows the
+    largest count seen so far (x1.25, rounded up to a power of two); only when some rank holds more than K edges
+    is a second all-gather of the full buffers needed.  ``edges_u8``: this rank's uint8 tensor holding ``count``
+    24-byte ke_edge records at its start.  Returns (host ndarray of all edges as raw bytes viewed per record by
+    the caller, per-rank counts)."""
     import torch
     import torch.distributed as dist
 
     world = dist.get_world_size(group)
-    mine = torch.tensor([int(count)], dtype=torch.int64, device=edges_u8.device)
-    counts_t = torch.empty(world, dtype=torch.int64, device=edges_u8.device)
-    dist.all_gather_into_tensor(counts_t, mine, group=group)
-    counts = counts_t.cpu().tolist()
-    width = max(max(counts), 1) * 24
-    if edges_u8.numel() < width:           # a rank with a short buffer pads up to the common width
-        padded = torch.zeros(width, dtype=torch.uint8, device=edges_u8.device)
-        padded[: edges_u8.numel()] = edges_u8
-        edges_u8 = padded
-    gathered = torch.empty(world * width, dtype=torch.uint8, device=edges_u8.device)
-    dist.all_gather_into_tensor(gathered, edges_u8[:width].contiguous(), group=group)
+    dev = edges_u8.device
+    key = id(group) if group is not None else 0
+    slots = _edge_slots_hint.get(key, 1024)
+    width = 8 + slots * 24
+    send = torch.zeros(width, dtype=torch.uint8, device=dev)
+    send[:8] = torch.tensor([int(count)], dtype=torch.int64).view(torch.uint8).to(dev)
+    head = min(int(count), slots) * 24
+    if head:
+        send[8:8 + head] = edges_u8[:head]
+    gathered = torch.empty(world * width, dtype=torch.uint8, device=dev)
+    dist.all_gather_into_tensor(gathered, send, group=group)
     host = gathered.cpu().numpy().reshape(world, width)
-    merged = np.concatenate([host[r, : counts[r] * 24] for r in range(world)])
+    counts = [int(v) for v in np.ascontiguousarray(host[:, :8]).view(np.int64)[:, 0]]
+    top = max(max(counts), 1)
+    if top > slots:                         # rare: some list did not fit the record -> gather the full buffers
+        full = top * 24
+        if edges_u8.numel() < full:         # a rank with a short buffer pads up to the common width
+            padded = torch.zeros(full, dtype=torch.uint8, device=dev)
+            padded[: edges_u8.numel()] = edges_u8
+            edges_u8 = padded
+        gathered = torch.empty(world * full, dtype=torch.uint8, device=dev)
+        dist.all_gather_into_tensor(gathered, edges_u8[:full].contiguous(), group=group)
+        body = gathered.cpu().numpy().reshape(world, full)
+    else:
+        body = host[:, 8:]
+    want = 1024
+    while want < top * 5 // 4:
+        want *= 2
+    _edge_slots_hint[key] = max(slots, want)
+    merged = np.concatenate([body[r, : counts[r] * 24] for r in range(world)])
     return merged, counts

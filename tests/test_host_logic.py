@@ -196,6 +196,16 @@ buf = torch.zeros(24 * 8, dtype=torch.uint8); buf[: edges.nbytes] = torch.from_n
 raw, counts = allgather_edge_buffers(buf, len(edges))
 m2 = raw.view(_native.EDGE_DTYPE)
 assert counts == [3, 4] and m2["a"].tolist() == [0, 0, 0, 1, 1, 1, 1] and m2["b"].tolist() == [10, 11, 12, 10, 11, 12, 13]
+# one rank holds more edges than the fixed-width record carries: the second (full-width) all-gather, then the
+# record grows and the next merge is a single collective again
+big = np.zeros(1500 if rank == 1 else 2, _native.EDGE_DTYPE); big["a"] = rank; big["b"] = np.arange(len(big))
+bbuf = torch.from_numpy(big.view(np.uint8).copy())
+for _ in range(2):
+    raw, counts = allgather_edge_buffers(bbuf, len(big))
+    m3 = raw.view(_native.EDGE_DTYPE)
+    assert counts == [2, 1500] and m3["a"].tolist() == [0, 0] + [1] * 1500 and m3["b"].tolist() == [0, 1] + list(range(1500))
+raw, counts = allgather_edge_buffers(torch.zeros(0, dtype=torch.uint8), 0)
+assert counts == [0, 0] and len(raw) == 0
 parts = [table[owned_indices(n, r, world)] for r in range(world)]
 assert np.array_equal(interleave_gathered(parts, n), table)
 dist.barrier(); dist.destroy_process_group()

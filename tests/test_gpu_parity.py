@@ -161,6 +161,27 @@ def test_scan_edges_match_oracle(ctx, n, t, bb, bc):
     assert key(np.concatenate(parts)) == key(exp)
 
 
+def test_scan_counts_every_bit_position_once(ctx):
+    """The scan forms 64 - popc(x ^ y) as a 128-term product of one-bit operands on the matrix cores: every bit
+    position must contribute exactly once, for both polarities.  Hashes: a base, base ^ (1 << k) for every k, their
+    complements, and two-bit flips across the 32-bit halves; all-pairs truth from NumPy."""
+    base = 0x0123456789ABCDEF
+    vals = [base] + [base ^ (1 << k) for k in range(64)] + [base ^ 0xFFFFFFFFFFFFFFFF] + \
+           [base ^ 0xFFFFFFFFFFFFFFFF ^ (1 << k) for k in range(0, 64, 7)] + [base ^ (1 << k) ^ (1 << (63 - k)) for k in range(32)]
+    h = np.array(vals, dtype=np.uint64)
+    n = len(h)
+    x = h[:, None] ^ h[None, :]
+    pc = np.array([[bin(int(v)).count("1") for v in row] for row in x])
+    # 64 one-bit band lanes: every pair closer than 64 bits shares a lane, so the band test is out of the way
+    exp = O.scan_bruteforce(h, threshold=3, band_bits=1, band_count=64)
+    got, _ = ctx.hamming_scan(h, n, threshold=3, band_bits=1, band_count=64)
+    key = lambda e: sorted(map(tuple, e[["a", "b", "h"]].tolist()))
+    assert key(got) == key(exp)
+    for a, b, hh in got[["a", "b", "h"]].tolist():
+        assert pc[a, b] == hh
+    assert len(got) == int(np.triu(pc <= 3, 1).sum())
+
+
 def test_scan_overflow_protocol_and_degenerate_corpus(ctx):
     """All-identical hashes: O(n^2) edges; a too-small buffer reports the true count and the retry succeeds."""
     n = 700

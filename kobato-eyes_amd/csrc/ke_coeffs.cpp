@@ -130,10 +130,10 @@ void ke_build_axis_coeffs(int in_size, int out_size, KeAxisCoeffs &c, int filter
 }
 
 // Byte planes of the taps as matrix-core B operands (see KeMxTable).
-void ke_build_mx(const KeAxisCoeffs &c, KeMxTable &t) {
+void ke_build_mx(const KeAxisCoeffs &c, KeMxTable &t, int min_ks) {
     t.tiles = (c.out_size + 15) / 16;
     t.base.assign((size_t)t.tiles, 0);
-    t.ks = 1;
+    t.ks = std::max(1, min_ks);
     for (int j = 0; j < t.tiles; ++j) {
         int lo = c.in_size, hi = 0;
         for (int o = 16 * j; o < std::min(16 * j + 16, c.out_size); ++o) {

@@ -217,6 +217,7 @@ struct KeFusedArgs {
     const int32_t *h_bias;
     const int32_t *v_packed, *v_start, *v_bias;          // vertical axis: 32 outputs, ndwv window dwords
     int ndwv;
+    int qw, qw_inv, lp;   // GEN instantiations: quads per row (W / 4), ceil(2^32 / qw), LDS pitch of a luma row
     int lt_half;    // LDS bytes of ONE luma tile buffer (two are allocated; the tail reuses them as scratch)
     int lt_bytes;   // = 2 * lt_half
     int hp;         // pitch of one HT column (bytes, multiple of 8)
@@ -357,13 +358,15 @@ typedef int ke_v4i __attribute__((ext_vector_type(4)));
 // (wave jt = 0: columns [0, W/2), jt = 1: [W/2, W) = its steps SD.. with SD = (W/2 - base1)/64); the jt = 1
 // wave hands its plane-combined partial sums to its partner through a 1 KB LDS slot, and the partner adds,
 // clips and writes the transposed dHash column one tile later (after the tile's barrier).
-template <int W64, int KS, bool DH>
+// GEN: the row length is a run-time value, any multiple of 4 in (64*(W64-1), 64*W64]; W64 and KS are then upper
+// bounds (operand steps past an output tile's window hold zero taps; what they read of the next row is ignored).
+template <int W64, int KS, bool DH, bool GEN>
 __global__ __launch_bounds__(256, 2) void ke_phash_fused_mx(const KeFusedArgs a) {
     constexpr int W = 64 * W64;
-    constexpr int QW = W / 4;                    // 12-byte quads per row
-    constexpr int QPT = kRTM * QW / 256;         // quads per thread per 32-row tile
-    constexpr int QUADS_PER_TILE = kRTM * QW;
-    constexpr int LP = W + 16;
+    constexpr int QPT = kRTM * (W / 4) / 256;    // (upper bound of the) quads per thread per 32-row tile
+    const int QW = GEN ? a.qw : W / 4;           // 12-byte quads per row
+    const int QUADS_PER_TILE = kRTM * QW;
+    const int LP = GEN ? a.lp : W + 16;
     constexpr int KD = W64 / 2;                  // dHash steps per wave
     constexpr int SD1 = KS - KD;                 // first dHash step of the jt = 1 wave (checked on the host)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -425,7 +428,13 @@ __global__ __launch_bounds__(256, 2) void ke_phash_fused_mx(const KeFusedArgs a)
 #pragma unroll
         for (int q = 0; q < QPT; ++q) {
             const int i = q * 256 + tid;
-            *reinterpret_cast<uint32_t *>(dst + (i / QW) * LP + (i % QW) * 4) = luma4_biased(raw[q][0], raw[q][1], raw[q][2]);
+            if (GEN) {
+                const int row = (int)__umulhi((uint32_t)i, (uint32_t)a.qw_inv);      // i / QW, exact for i < 2^16
+                if (i < QUADS_PER_TILE)
+                    *reinterpret_cast<uint32_t *>(dst + row * LP + (i - row * QW) * 4) = luma4_biased(raw[q][0], raw[q][1], raw[q][2]);
+            } else {
+                *reinterpret_cast<uint32_t *>(dst + (i / (W / 4)) * LP + (i % (W / 4)) * 4) = luma4_biased(raw[q][0], raw[q][1], raw[q][2]);
+            }
         }
     };
     auto pack_rows = [](const ke_v4i &v0, const ke_v4i &v1, const ke_v4i &v2, int bias) {
@@ -498,11 +507,13 @@ __global__ __launch_bounds__(256, 2) void ke_phash_fused_mx(const KeFusedArgs a)
     fused_tail<(DH ? 1 : 0)>(a, Lt, HT, HTd, tid, img);
 }
 
-template <int W64, int KS, bool DH>
+template <int W64, int KS, bool DH, bool GEN = false>
 int launch_fused_mx(ke_ctx *ctx, const KeHashGroup &g, const KeAxisCoeffs *ch, const KeAxisCoeffs *cv, uint64_t *d_phash,
                     uint8_t *d_tile32, uint64_t *d_dhash, uint8_t *d_tile98) {
-    constexpr int W = 64 * W64;
-    const KeMxTable *mx = ke_get_mx(ctx, ch);
+    static_assert(!(DH && GEN), "the dHash leg needs the exact operand alignment of W = 64 * W64");
+    const int W = g.w;
+    if (GEN ? (W > 64 * W64 || W <= 64 * (W64 - 1) || W % 4) : W != 64 * W64) return KE_EUNSUPPORTED;
+    const KeMxTable *mx = ke_get_mx(ctx, ch, KS);     // at least KS steps per tile (zero-padded)
     if (!mx) return ke_fail(ctx, KE_EHIP, "coefficient upload failed");
     if (mx->tiles != 2 || mx->ks != KS) return KE_EUNSUPPORTED;
     KeFusedArgs a;
@@ -515,7 +526,11 @@ int launch_fused_mx(ke_ctx *ctx, const KeHashGroup &g, const KeAxisCoeffs *ch, c
     const int rows_padded = ((g.h + kRTM - 1) / kRTM) * kRTM;
     // one tile buffer: 32 padded rows + the part of the last row's operand window that overhangs the row
     const int overhang = std::max(0, std::max(mx->base[0], mx->base[1]) + 64 * KS - W);
-    a.lt_half = (kRTM * (W + 16) + overhang + 15) & ~15;
+    a.qw = W / 4;
+    a.qw_inv = (int)(uint32_t)((0x100000000ull + (uint64_t)a.qw - 1) / (uint64_t)a.qw);
+    // row pitch: an odd number of 16-byte units, so the 16 rows of an operand land in distinct bank groups
+    a.lp = GEN ? (((W + 15) / 16 + 1) | 1) * 16 : W + 16;
+    a.lt_half = (kRTM * a.lp + overhang + 15) & ~15;
     a.lt_bytes = 2 * a.lt_half;
     a.hp = ((std::max(cv->span, rows_padded) + 7) & ~7) + 8;
     a.hpd = 8;
@@ -545,9 +560,9 @@ int launch_fused_mx(ke_ctx *ctx, const KeHashGroup &g, const KeAxisCoeffs *ch, c
     // two workgroups per CU either way (registers), so a workgroup may take up to half of the 160 KB
     if (lds > 80 * 1024) return KE_EUNSUPPORTED;
     if (lds > 64 * 1024)
-        KE_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&ke_phash_fused_mx<W64, KS, DH>),
+        KE_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&ke_phash_fused_mx<W64, KS, DH, GEN>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((ke_phash_fused_mx<W64, KS, DH>), dim3((unsigned)g.n), dim3(256), lds, ctx->stream, a);
+    hipLaunchKernelGGL((ke_phash_fused_mx<W64, KS, DH, GEN>), dim3((unsigned)g.n), dim3(256), lds, ctx->stream, a);
     KE_HIP(ctx, hipGetLastError());
     return KE_OK;
 }
@@ -938,14 +953,14 @@ int ke_launch_hash_group(ke_ctx *ctx, const KeHashGroup &g, uint64_t *d_phash, u
     KE_TRY(upload_dct_tables(ctx));
     const bool want_p = d_phash || d_tile32_out, want_d = d_dhash || d_tile98_out;
     bool p_done = false, d_done = false;
-    // ---- fused fast path: packed RGB, 4-byte aligned rows, width 256/384/512, both axes resampled
-    if (want_p && g.channels == 3 && g.w % 64 == 0 && g.h != 32 && g.h >= 16 && g.h <= 1536 &&
+    // ---- fused fast path: packed RGB, rows of a multiple of 4 pixels up to 768, both axes resampled
+    if (want_p && g.channels == 3 && g.w % 4 == 0 && g.w > 64 && g.w <= 768 && g.h != 32 && g.h >= 16 && g.h <= 1536 &&
         !((int64_t)g.h > (int64_t)g.w * 100) && ((uintptr_t)g.pixels % 4 == 0) && (g.offsets || g.stride % 4 == 0)) {
         const KeAxisCoeffs *ch = ke_get_coeffs(ctx, g.w, 32);
         const KeAxisCoeffs *cv = ke_get_coeffs(ctx, g.h, 32);
         if (!ch || !cv) return ke_fail(ctx, KE_EHIP, "coefficient upload failed");
         int rc = KE_EUNSUPPORTED;
-        // offsets (ragged groups) are only 4-byte aligned when every image size is; w % 64 == 0 makes it so
+        // offsets (ragged groups) are only 4-byte aligned when every image size is; w % 4 == 0 makes it so
         if (want_d && g.h != 8) {   // pHash + dHash in one pass over the pixels
             if (g.w == 256) rc = launch_fused_mx<4, 3, true>(ctx, g, ch, cv, d_phash, d_tile32_out, d_dhash, d_tile98_out);
             else if (g.w == 384) rc = launch_fused_mx<6, 4, true>(ctx, g, ch, cv, d_phash, d_tile32_out, d_dhash, d_tile98_out);
@@ -953,11 +968,29 @@ int ke_launch_hash_group(ke_ctx *ctx, const KeHashGroup &g, uint64_t *d_phash, u
             if (rc == KE_OK) p_done = d_done = true;
             else if (rc != KE_EUNSUPPORTED) return rc;
         }
-        if (!p_done) {              // pHash alone (or the image is too tall for both columns sets to fit in LDS)
+        if (!p_done) {              // pHash alone (or the image is too tall for both column sets to fit in LDS)
             rc = KE_EUNSUPPORTED;
-            if (g.w == 256) rc = launch_fused_mx<4, 3, false>(ctx, g, ch, cv, d_phash, d_tile32_out, nullptr, nullptr);
-            else if (g.w == 384) rc = launch_fused_mx<6, 4, false>(ctx, g, ch, cv, d_phash, d_tile32_out, nullptr, nullptr);
-            else if (g.w == 512) rc = launch_fused_mx<8, 5, false>(ctx, g, ch, cv, d_phash, d_tile32_out, nullptr, nullptr);
+            switch (g.w) {          // widths with their own instantiation: compile-time row length
+                case 256: rc = launch_fused_mx<4, 3, false>(ctx, g, ch, cv, d_phash, d_tile32_out, nullptr, nullptr); break;
+                case 384: rc = launch_fused_mx<6, 4, false>(ctx, g, ch, cv, d_phash, d_tile32_out, nullptr, nullptr); break;
+                case 512: rc = launch_fused_mx<8, 5, false>(ctx, g, ch, cv, d_phash, d_tile32_out, nullptr, nullptr); break;
+                case 640: rc = launch_fused_mx<10, 6, false>(ctx, g, ch, cv, d_phash, d_tile32_out, nullptr, nullptr); break;
+                case 768: rc = launch_fused_mx<12, 7, false>(ctx, g, ch, cv, d_phash, d_tile32_out, nullptr, nullptr); break;
+                default:
+                    switch ((g.w + 63) / 64) {   // any other multiple of 4: run-time row length, operand steps of the bucket
+                        case 2: rc = launch_fused_mx<2, 2, false, true>(ctx, g, ch, cv, d_phash, d_tile32_out, nullptr, nullptr); break;
+                        case 3: rc = launch_fused_mx<3, 2, false, true>(ctx, g, ch, cv, d_phash, d_tile32_out, nullptr, nullptr); break;
+                        case 4: rc = launch_fused_mx<4, 3, false, true>(ctx, g, ch, cv, d_phash, d_tile32_out, nullptr, nullptr); break;
+                        case 5: rc = launch_fused_mx<5, 3, false, true>(ctx, g, ch, cv, d_phash, d_tile32_out, nullptr, nullptr); break;
+                        case 6: rc = launch_fused_mx<6, 4, false, true>(ctx, g, ch, cv, d_phash, d_tile32_out, nullptr, nullptr); break;
+                        case 7: rc = launch_fused_mx<7, 5, false, true>(ctx, g, ch, cv, d_phash, d_tile32_out, nullptr, nullptr); break;
+                        case 8: rc = launch_fused_mx<8, 5, false, true>(ctx, g, ch, cv, d_phash, d_tile32_out, nullptr, nullptr); break;
+                        case 9: rc = launch_fused_mx<9, 6, false, true>(ctx, g, ch, cv, d_phash, d_tile32_out, nullptr, nullptr); break;
+                        case 10: rc = launch_fused_mx<10, 6, false, true>(ctx, g, ch, cv, d_phash, d_tile32_out, nullptr, nullptr); break;
+                        case 11: rc = launch_fused_mx<11, 7, false, true>(ctx, g, ch, cv, d_phash, d_tile32_out, nullptr, nullptr); break;
+                        default: break;          // 708..764: 8 operand steps do not fit the register file beside the pixel loads
+                    }
+            }
             if (rc == KE_OK) p_done = true;
             else if (rc != KE_EUNSUPPORTED) return rc;
         }

@@ -79,6 +79,24 @@ def test_phash_only_matrix_core_path(ctx, w):
             assert int(got_p[k]) == ep, (w, h, k)
 
 
+def test_phash_any_width_up_to_768_matrix_core_path(ctx):
+    """Rows of any multiple of 4 pixels in (64, 704] (and 768) take the same single-pass kernel with a run-time row
+    length: every such width once (heights rotate through tile-boundary cases), against the oracle's tile and bits."""
+    rng = np.random.default_rng(4)
+    heights = [16, 33, 64, 97, 200, 31 + 32 * 7, 480]
+    for k, w in enumerate(list(range(68, 705, 4)) + [768]):
+        h = heights[k % len(heights)]
+        n = 3
+        px = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
+        px[1] = (rng.integers(0, 2, (h, w, 3)) * 255).astype(np.uint8)
+        got_p, _ = ctx.hash_uniform(px, n, w, h, 3, want_dhash=False)
+        t32, _ = ctx.luma_tiles_uniform(px, n, w, h, 3, want98=False)
+        for j in range(n):
+            ep, _, e32, _, _ = O.hash_image(px[j], want_tiles=True)
+            assert np.array_equal(t32[j], e32), (w, h, j, "tile32")
+            assert int(got_p[j]) == ep, (w, h, j)
+
+
 def test_extreme_pixels_fused(ctx):
     """Saturated inputs exercise the clip after each pass and the signed-byte bias."""
     rng = np.random.default_rng(0)

@@ -200,6 +200,19 @@ __device__ __forceinline__ uint32_t luma4_biased(uint32_t d0, uint32_t d1, uint3
     return lo | hi;
 }
 
+// Four consecutive pixels of one row -> four signed luma bytes.  d: the 4*C source bytes.
+template <int C>
+__device__ __forceinline__ uint32_t luma4_generic(const uint32_t *d) {
+    if (C == 3) return luma4_biased(d[0], d[1], d[2]);
+    if (C == 1) return d[0] ^ 0x80808080u;
+    constexpr uint32_t CHI = 0x001D964Cu, CLO = 0x002F468Bu, START = 0x8000u - 0x800000u;
+    uint32_t s[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)   // RGBX: byte 3 meets a zero weight, as Pillow's rgb2l ignores it
+        s[k] = (__builtin_amdgcn_udot4(d[k], CHI, 0u, false) << 8) + __builtin_amdgcn_udot4(d[k], CLO, START, false);
+    return __builtin_amdgcn_perm(s[1], s[0], 0x0C0C0602u) | __builtin_amdgcn_perm(s[3], s[2], 0x06020C0Cu);   // byte 2 of each sum
+}
+
 __device__ __forceinline__ int combine_planes(int d0, int d1, int d2, int bias) {
     return (int)((uint32_t)d0 + ((uint32_t)d1 << 8) + ((uint32_t)d2 << 16) + (uint32_t)bias);
 }
@@ -360,8 +373,10 @@ typedef int ke_v4i __attribute__((ext_vector_type(4)));
 // clips and writes the transposed dHash column one tile later (after the tile's barrier).
 // GEN: the row length is a run-time value, any multiple of 4 in (64*(W64-1), 64*W64]; W64 and KS are then upper
 // bounds (operand steps past an output tile's window hold zero taps; what they read of the next row is ignored).
-template <int W64, int KS, bool DH, bool GEN>
+// C: bytes per pixel, 3 (RGB) or 4 (RGBX/RGBA: the fourth byte is ignored, as convert("L") ignores it).
+template <int W64, int KS, bool DH, bool GEN, int C>
 __global__ __launch_bounds__(256, 2) void ke_phash_fused_mx(const KeFusedArgs a) {
+    constexpr uint32_t QB = 4u * C;              // bytes of a 4-pixel quad
     constexpr int W = 64 * W64;
     constexpr int QPT = kRTM * (W / 4) / 256;    // (upper bound of the) quads per thread per 32-row tile
     const int QW = GEN ? a.qw : W / 4;           // 12-byte quads per row
@@ -379,7 +394,7 @@ __global__ __launch_bounds__(256, 2) void ke_phash_fused_mx(const KeFusedArgs a)
     const int64_t img = blockIdx.x;
     const uint8_t *src = a.pixels + (a.offsets ? a.offsets[img] : (uint64_t)img * a.stride);
     const int h = a.h;
-    const uint32_t image_bytes = (uint32_t)h * (uint32_t)QW * 12u;
+    const uint32_t image_bytes = (uint32_t)h * (uint32_t)QW * QB;
 
     // this wave's slice of the product: rows 16*mt.., outputs 16*jt..
     const int mt = wv >> 1, jt = wv & 1;
@@ -407,21 +422,20 @@ __global__ __launch_bounds__(256, 2) void ke_phash_fused_mx(const KeFusedArgs a)
     uint8_t *htd_dst = HTd + (size_t)(lane & 15) * a.hpd + 16 * mt + 4 * (lane >> 4);
     ke_v4i *x_slot = reinterpret_cast<ke_v4i *>(X + mt * 1024 + lane * 16);     // + 2048 for odd tiles
 
-    uint32_t raw[QPT][3];
+    uint32_t raw[QPT][C];
     auto load_tile = [&](int t) {
-        const uint32_t tile_off = (uint32_t)t * (uint32_t)(QUADS_PER_TILE * 12);
+        const uint32_t tile_off = (uint32_t)t * ((uint32_t)QUADS_PER_TILE * QB);
         const uint8_t *tile_ptr = src + tile_off;                 // wave-uniform
-        const uint32_t lim = image_bytes - 12u - tile_off;        // last loadable quad, relative to the tile
+        const uint32_t lim = image_bytes - QB - tile_off;         // last loadable quad, relative to the tile
 #pragma unroll
         for (int q = 0; q < QPT; ++q) {
             // Unconditional loads (a guarded load makes hipcc wait vmcnt(0) after each one): quads past the image
             // end re-read the last quad; those rows only ever meet zero tap weights.  Streamed once: non-temporal.
-            const uint32_t vo = (uint32_t)(q * 256 + tid) * 12u;
+            const uint32_t vo = (uint32_t)(q * 256 + tid) * QB;
             const uint32_t off = vo < lim ? vo : lim;
             const uint32_t *p = reinterpret_cast<const uint32_t *>(tile_ptr + off);
-            raw[q][0] = __builtin_nontemporal_load(p);
-            raw[q][1] = __builtin_nontemporal_load(p + 1);
-            raw[q][2] = __builtin_nontemporal_load(p + 2);
+#pragma unroll
+            for (int k = 0; k < C; ++k) raw[q][k] = __builtin_nontemporal_load(p + k);
         }
     };
     auto store_luma = [&](uint8_t *dst) {
@@ -431,9 +445,9 @@ __global__ __launch_bounds__(256, 2) void ke_phash_fused_mx(const KeFusedArgs a)
             if (GEN) {
                 const int row = (int)__umulhi((uint32_t)i, (uint32_t)a.qw_inv);      // i / QW, exact for i < 2^16
                 if (i < QUADS_PER_TILE)
-                    *reinterpret_cast<uint32_t *>(dst + row * LP + (i - row * QW) * 4) = luma4_biased(raw[q][0], raw[q][1], raw[q][2]);
+                    *reinterpret_cast<uint32_t *>(dst + row * LP + (i - row * QW) * 4) = luma4_generic<C>(raw[q]);
             } else {
-                *reinterpret_cast<uint32_t *>(dst + (i / (W / 4)) * LP + (i % (W / 4)) * 4) = luma4_biased(raw[q][0], raw[q][1], raw[q][2]);
+                *reinterpret_cast<uint32_t *>(dst + (i / (W / 4)) * LP + (i % (W / 4)) * 4) = luma4_generic<C>(raw[q]);
             }
         }
     };
@@ -507,7 +521,7 @@ __global__ __launch_bounds__(256, 2) void ke_phash_fused_mx(const KeFusedArgs a)
     fused_tail<(DH ? 1 : 0)>(a, Lt, HT, HTd, tid, img);
 }
 
-template <int W64, int KS, bool DH, bool GEN = false>
+template <int W64, int KS, bool DH, bool GEN = false, int C = 3>
 int launch_fused_mx(ke_ctx *ctx, const KeHashGroup &g, const KeAxisCoeffs *ch, const KeAxisCoeffs *cv, uint64_t *d_phash,
                     uint8_t *d_tile32, uint64_t *d_dhash, uint8_t *d_tile98) {
     static_assert(!(DH && GEN), "the dHash leg needs the exact operand alignment of W = 64 * W64");
@@ -560,9 +574,9 @@ int launch_fused_mx(ke_ctx *ctx, const KeHashGroup &g, const KeAxisCoeffs *ch, c
     // two workgroups per CU either way (registers), so a workgroup may take up to half of the 160 KB
     if (lds > 80 * 1024) return KE_EUNSUPPORTED;
     if (lds > 64 * 1024)
-        KE_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&ke_phash_fused_mx<W64, KS, DH, GEN>),
+        KE_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&ke_phash_fused_mx<W64, KS, DH, GEN, C>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((ke_phash_fused_mx<W64, KS, DH, GEN>), dim3((unsigned)g.n), dim3(256), lds, ctx->stream, a);
+    hipLaunchKernelGGL((ke_phash_fused_mx<W64, KS, DH, GEN, C>), dim3((unsigned)g.n), dim3(256), lds, ctx->stream, a);
     KE_HIP(ctx, hipGetLastError());
     return KE_OK;
 }
@@ -596,19 +610,6 @@ struct KeBandArgs {
     uint8_t *hs;       // [img][nout][hp]
     int hp;
 };
-
-// Four consecutive pixels of one row -> four signed luma bytes.  d: the 4*C source bytes.
-template <int C>
-__device__ __forceinline__ uint32_t luma4_generic(const uint32_t *d) {
-    if (C == 3) return luma4_biased(d[0], d[1], d[2]);
-    if (C == 1) return d[0] ^ 0x80808080u;
-    constexpr uint32_t CHI = 0x001D964Cu, CLO = 0x002F468Bu, START = 0x8000u - 0x800000u;
-    uint32_t s[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k)   // RGBX: byte 3 meets a zero weight, as Pillow's rgb2l ignores it
-        s[k] = (__builtin_amdgcn_udot4(d[k], CHI, 0u, false) << 8) + __builtin_amdgcn_udot4(d[k], CLO, START, false);
-    return ((s[0] >> 16) & 0xFFu) | ((s[1] >> 8) & 0xFF00u) | (s[2] & 0xFF0000u) | ((s[3] << 8) & 0xFF000000u);
-}
 
 template <int NDWC, int C, bool ALIGNED>
 __global__ __launch_bounds__(256, 3) void ke_hband(const KeBandArgs a) {
@@ -954,21 +955,21 @@ int ke_launch_hash_group(ke_ctx *ctx, const KeHashGroup &g, uint64_t *d_phash, u
     const bool want_p = d_phash || d_tile32_out, want_d = d_dhash || d_tile98_out;
     bool p_done = false, d_done = false;
     // ---- fused fast path: packed RGB, rows of a multiple of 4 pixels up to 768, both axes resampled
-    if (want_p && g.channels == 3 && g.w % 4 == 0 && g.w > 64 && g.w <= 768 && g.h != 32 && g.h >= 16 && g.h <= 1536 &&
+    if (want_p && (g.channels == 3 || g.channels == 4) && g.w % 4 == 0 && g.w > 64 && g.w <= 768 && g.h != 32 && g.h >= 16 && g.h <= 1536 &&
         !((int64_t)g.h > (int64_t)g.w * 100) && ((uintptr_t)g.pixels % 4 == 0) && (g.offsets || g.stride % 4 == 0)) {
         const KeAxisCoeffs *ch = ke_get_coeffs(ctx, g.w, 32);
         const KeAxisCoeffs *cv = ke_get_coeffs(ctx, g.h, 32);
         if (!ch || !cv) return ke_fail(ctx, KE_EHIP, "coefficient upload failed");
         int rc = KE_EUNSUPPORTED;
         // offsets (ragged groups) are only 4-byte aligned when every image size is; w % 4 == 0 makes it so
-        if (want_d && g.h != 8) {   // pHash + dHash in one pass over the pixels
+        if (want_d && g.h != 8 && g.channels == 3) {   // pHash + dHash in one pass over the pixels
             if (g.w == 256) rc = launch_fused_mx<4, 3, true>(ctx, g, ch, cv, d_phash, d_tile32_out, d_dhash, d_tile98_out);
             else if (g.w == 384) rc = launch_fused_mx<6, 4, true>(ctx, g, ch, cv, d_phash, d_tile32_out, d_dhash, d_tile98_out);
             else if (g.w == 512) rc = launch_fused_mx<8, 5, true>(ctx, g, ch, cv, d_phash, d_tile32_out, d_dhash, d_tile98_out);
             if (rc == KE_OK) p_done = d_done = true;
             else if (rc != KE_EUNSUPPORTED) return rc;
         }
-        if (!p_done) {              // pHash alone (or the image is too tall for both column sets to fit in LDS)
+        if (!p_done && g.channels == 3) {   // pHash alone (or the image is too tall for both column sets to fit in LDS)
             rc = KE_EUNSUPPORTED;
             switch (g.w) {          // widths with their own instantiation: compile-time row length
                 case 256: rc = launch_fused_mx<4, 3, false>(ctx, g, ch, cv, d_phash, d_tile32_out, nullptr, nullptr); break;
@@ -991,6 +992,18 @@ int ke_launch_hash_group(ke_ctx *ctx, const KeHashGroup &g, uint64_t *d_phash, u
                         default: break;          // 708..764: 8 operand steps do not fit the register file beside the pixel loads
                     }
             }
+            if (rc == KE_OK) p_done = true;
+            else if (rc != KE_EUNSUPPORTED) return rc;
+        }
+        if (!p_done && g.channels == 4) {   // RGBX / RGBA rows: run-time row length per 64-pixel bucket
+            rc = KE_EUNSUPPORTED;
+#define KE_GEN4(B, K) case B: rc = launch_fused_mx<B, K, false, true, 4>(ctx, g, ch, cv, d_phash, d_tile32_out, nullptr, nullptr); break
+            switch ((g.w + 63) / 64) {
+                KE_GEN4(2, 2); KE_GEN4(3, 2); KE_GEN4(4, 3); KE_GEN4(5, 3); KE_GEN4(6, 4); KE_GEN4(7, 5); KE_GEN4(8, 5); KE_GEN4(9, 6);
+                KE_GEN4(10, 6);
+                default: break;
+            }
+#undef KE_GEN4
             if (rc == KE_OK) p_done = true;
             else if (rc != KE_EUNSUPPORTED) return rc;
         }

@@ -95,6 +95,10 @@ def test_phash_any_width_up_to_768_matrix_core_path(ctx):
             ep, _, e32, _, _ = O.hash_image(px[j], want_tiles=True)
             assert np.array_equal(t32[j], e32), (w, h, j, "tile32")
             assert int(got_p[j]) == ep, (w, h, j)
+        if w <= 640 and k % 3 == 0:                      # RGBA / RGBX rows: the fourth byte is ignored, as convert("L") does
+            px4 = np.concatenate([px, rng.integers(0, 256, (n, h, w, 1), dtype=np.uint8)], axis=3)
+            got4, _ = ctx.hash_uniform(px4, n, w, h, 4, want_dhash=False)
+            assert np.array_equal(got4, got_p), (w, h, "rgba")
 
 
 def test_extreme_pixels_fused(ctx):

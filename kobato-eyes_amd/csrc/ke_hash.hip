@@ -366,11 +366,11 @@ int upload_dct_tables(ke_ctx *ctx) {
 constexpr int kRTM = 32;
 typedef int ke_v4i __attribute__((ext_vector_type(4)));
 
-// dHash leg (DH): the 9-output axis is one more 16-column operand tile whose taps span the whole row, W/64
-// steps.  Each wave runs the half of those steps whose A operands it already holds for its pHash outputs
-// (wave jt = 0: columns [0, W/2), jt = 1: [W/2, W) = its steps SD.. with SD = (W/2 - base1)/64); the jt = 1
-// wave hands its plane-combined partial sums to its partner through a 1 KB LDS slot, and the partner adds,
-// clips and writes the transposed dHash column one tile later (after the tile's barrier).
+// dHash leg (DH): the 9-output axis is one more 16-column operand tile whose taps span the whole row,
+// ceil(W/64) steps.  The two waves of a row block take one half of those steps each (KD per wave, columns
+// [0, 64 KD) and [64 KD, 128 KD)); the jt = 1 wave hands its plane-combined partial sums to its partner
+// through a 1 KB LDS slot, and the partner adds, clips and writes the transposed dHash column one tile
+// later (after the tile's barrier).
 // GEN: the row length is a run-time value, any multiple of 4 in (64*(W64-1), 64*W64]; W64 and KS are then upper
 // bounds (operand steps past an output tile's window hold zero taps; what they read of the next row is ignored).
 // C: bytes per pixel, 3 (RGB) or 4 (RGBX/RGBA: the fourth byte is ignored, as convert("L") ignores it).
@@ -382,8 +382,7 @@ __global__ __launch_bounds__(256, 2) void ke_phash_fused_mx(const KeFusedArgs a)
     const int QW = GEN ? a.qw : W / 4;           // 12-byte quads per row
     const int QUADS_PER_TILE = kRTM * QW;
     const int LP = GEN ? a.lp : W + 16;
-    constexpr int KD = W64 / 2;                  // dHash steps per wave
-    constexpr int SD1 = KS - KD;                 // first dHash step of the jt = 1 wave (checked on the host)
+    constexpr int KD = (W64 + 1) / 2;            // dHash steps per wave
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *Lt = smem;
     uint8_t *HT = smem + a.lt_bytes;
@@ -418,6 +417,7 @@ __global__ __launch_bounds__(256, 2) void ke_phash_fused_mx(const KeFusedArgs a)
     const int ocol = 16 * jt + (lane & 15);
     const int hbias = a.h_bias[ocol];
     const int a_off = (16 * mt + (lane & 15)) * LP + (jt ? a.mx_base1 : a.mx_base0) + 16 * (lane >> 4);
+    const int d_off = (16 * mt + (lane & 15)) * LP + 64 * KD * jt + 16 * (lane >> 4);
     uint8_t *ht_dst = HT + (size_t)ocol * a.hp + 16 * mt + 4 * (lane >> 4);
     uint8_t *htd_dst = HTd + (size_t)(lane & 15) * a.hpd + 16 * mt + 4 * (lane >> 4);
     ke_v4i *x_slot = reinterpret_cast<ke_v4i *>(X + mt * 1024 + lane * 16);     // + 2048 for odd tiles
@@ -458,8 +458,7 @@ __global__ __launch_bounds__(256, 2) void ke_phash_fused_mx(const KeFusedArgs a)
         return packed ^ 0x80808080u;    // signed bytes for the vertical pass
     };
     // products of one tile; returns this wave's dHash partial (plane-combined, no bias)
-    auto products = [&](int t, const uint8_t *cur, auto sd_tag) -> ke_v4i {
-        constexpr int SD = decltype(sd_tag)::value;
+    auto products = [&](int t, const uint8_t *cur) -> ke_v4i {
         ke_v4i acc[3], dacc[3];
 #pragma unroll
         for (int p = 0; p < 3; ++p) acc[p] = dacc[p] = ke_v4i{0, 0, 0, 0};
@@ -469,10 +468,14 @@ __global__ __launch_bounds__(256, 2) void ke_phash_fused_mx(const KeFusedArgs a)
             const ke_v4i av = *reinterpret_cast<const ke_v4i *>(__builtin_assume_aligned(ap + 64 * s, 16));
 #pragma unroll
             for (int p = 0; p < 3; ++p) acc[p] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, bf[s][p], acc[p], 0, 0, 0);
-            if (DH && s >= SD && s < SD + KD) {
+        }
+        if (DH) {
+            const uint8_t *dp = cur + d_off;
 #pragma unroll
-                for (int p = 0; p < 3; ++p)
-                    dacc[p] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, bd[(s - SD) % KDR][p], dacc[p], 0, 0, 0);
+            for (int d = 0; d < KDR; ++d) {
+                const ke_v4i av = *reinterpret_cast<const ke_v4i *>(__builtin_assume_aligned(dp + 64 * d, 16));
+#pragma unroll
+                for (int p = 0; p < 3; ++p) dacc[p] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, bd[d][p], dacc[p], 0, 0, 0);
             }
         }
         *reinterpret_cast<uint32_t *>(ht_dst + t * kRTM) = pack_rows(acc[0], acc[1], acc[2], hbias);
@@ -491,12 +494,12 @@ __global__ __launch_bounds__(256, 2) void ke_phash_fused_mx(const KeFusedArgs a)
     };
     auto hpass = [&](int t, const uint8_t *cur) {
         if (!DH) {
-            products(t, cur, std::integral_constant<int, 0>{});
+            products(t, cur);
         } else if (jt) {
-            x_slot[(t & 1) * 128] = products(t, cur, std::integral_constant<int, SD1>{});
+            x_slot[(t & 1) * 128] = products(t, cur);
         } else {
             if (t > 0) finish_dhash(t - 1);
-            carry = products(t, cur, std::integral_constant<int, 0>{});
+            carry = products(t, cur);
         }
     };
 
@@ -524,7 +527,6 @@ __global__ __launch_bounds__(256, 2) void ke_phash_fused_mx(const KeFusedArgs a)
 template <int W64, int KS, bool DH, bool GEN = false, int C = 3>
 int launch_fused_mx(ke_ctx *ctx, const KeHashGroup &g, const KeAxisCoeffs *ch, const KeAxisCoeffs *cv, uint64_t *d_phash,
                     uint8_t *d_tile32, uint64_t *d_dhash, uint8_t *d_tile98) {
-    static_assert(!(DH && GEN), "the dHash leg needs the exact operand alignment of W = 64 * W64");
     const int W = g.w;
     if (GEN ? (W > 64 * W64 || W <= 64 * (W64 - 1) || W % 4) : W != 64 * W64) return KE_EUNSUPPORTED;
     const KeMxTable *mx = ke_get_mx(ctx, ch, KS);     // at least KS steps per tile (zero-padded)
@@ -539,7 +541,8 @@ int launch_fused_mx(ke_ctx *ctx, const KeHashGroup &g, const KeAxisCoeffs *ch, c
     a.mx_frag = mx->d_frag; a.mx_base0 = mx->base[0]; a.mx_base1 = mx->base[1];
     const int rows_padded = ((g.h + kRTM - 1) / kRTM) * kRTM;
     // one tile buffer: 32 padded rows + the part of the last row's operand window that overhangs the row
-    const int overhang = std::max(0, std::max(mx->base[0], mx->base[1]) + 64 * KS - W);
+    constexpr int KD = (W64 + 1) / 2;
+    const int overhang = std::max(0, std::max(std::max(mx->base[0], mx->base[1]) + 64 * KS, DH ? 128 * KD : 0) - W);
     a.qw = W / 4;
     a.qw_inv = (int)(uint32_t)((0x100000000ull + (uint64_t)a.qw - 1) / (uint64_t)a.qw);
     // row pitch: an odd number of 16-byte units, so the 16 rows of an operand land in distinct bank groups
@@ -553,13 +556,10 @@ int launch_fused_mx(ke_ctx *ctx, const KeHashGroup &g, const KeAxisCoeffs *ch, c
     if (DH) {
         const KeAxisCoeffs *chd = ke_get_coeffs(ctx, g.w, 9), *cvd = ke_get_coeffs(ctx, g.h, 8);
         if (!chd || !cvd) return ke_fail(ctx, KE_EHIP, "coefficient upload failed");
-        const KeMxTable *mxd = ke_get_mx(ctx, chd);
+        const KeMxTable *mxd = ke_get_mx(ctx, chd, 2 * KD);     // the whole row in two halves of KD steps
         const KeChunkTable *tv = ke_get_chunks(ctx, cvd, 3);
         if (!mxd || !tv) return ke_fail(ctx, KE_EHIP, "coefficient upload failed");
-        // the two halves of the dHash steps must be the A operands the waves already read for pHash
-        if (mxd->tiles != 1 || mxd->base[0] != 0 || mxd->ks != W64 || mx->base[0] != 0 ||
-            mx->base[1] + 64 * (KS - W64 / 2) != W / 2)
-            return KE_EUNSUPPORTED;
+        if (mxd->tiles != 1 || mxd->base[0] != 0 || mxd->ks != 2 * KD) return KE_EUNSUPPORTED;
         a.mxd_frag = mxd->d_frag;
         a.hd_bias = chd->d_bias;
         a.vd_cpacked = tv->d_cpacked; a.vd_cstart = tv->d_cstart; a.vd_bias = cvd->d_bias;
@@ -962,10 +962,19 @@ int ke_launch_hash_group(ke_ctx *ctx, const KeHashGroup &g, uint64_t *d_phash, u
         if (!ch || !cv) return ke_fail(ctx, KE_EHIP, "coefficient upload failed");
         int rc = KE_EUNSUPPORTED;
         // offsets (ragged groups) are only 4-byte aligned when every image size is; w % 4 == 0 makes it so
-        if (want_d && g.h != 8 && g.channels == 3) {   // pHash + dHash in one pass over the pixels
-            if (g.w == 256) rc = launch_fused_mx<4, 3, true>(ctx, g, ch, cv, d_phash, d_tile32_out, d_dhash, d_tile98_out);
-            else if (g.w == 384) rc = launch_fused_mx<6, 4, true>(ctx, g, ch, cv, d_phash, d_tile32_out, d_dhash, d_tile98_out);
-            else if (g.w == 512) rc = launch_fused_mx<8, 5, true>(ctx, g, ch, cv, d_phash, d_tile32_out, d_dhash, d_tile98_out);
+        if (want_d && g.h != 8 && g.channels == 3) {   // pHash + dHash in one pass over the pixels (rows up to 512)
+#define KE_GEND(B, K) case B: rc = launch_fused_mx<B, K, true, true>(ctx, g, ch, cv, d_phash, d_tile32_out, d_dhash, d_tile98_out); break
+            switch (g.w) {
+                case 256: rc = launch_fused_mx<4, 3, true>(ctx, g, ch, cv, d_phash, d_tile32_out, d_dhash, d_tile98_out); break;
+                case 384: rc = launch_fused_mx<6, 4, true>(ctx, g, ch, cv, d_phash, d_tile32_out, d_dhash, d_tile98_out); break;
+                case 512: rc = launch_fused_mx<8, 5, true>(ctx, g, ch, cv, d_phash, d_tile32_out, d_dhash, d_tile98_out); break;
+                default:
+                    switch ((g.w + 63) / 64) {
+                        KE_GEND(2, 2); KE_GEND(3, 2); KE_GEND(4, 3); KE_GEND(5, 3); KE_GEND(6, 4); KE_GEND(7, 5); KE_GEND(8, 5);
+                        default: break;
+                    }
+            }
+#undef KE_GEND
             if (rc == KE_OK) p_done = d_done = true;
             else if (rc != KE_EUNSUPPORTED) return rc;
         }

@@ -95,6 +95,14 @@ def test_phash_any_width_up_to_768_matrix_core_path(ctx):
             ep, _, e32, _, _ = O.hash_image(px[j], want_tiles=True)
             assert np.array_equal(t32[j], e32), (w, h, j, "tile32")
             assert int(got_p[j]) == ep, (w, h, j)
+        if w <= 512:                                     # both hashes from one pass over the pixels (dHash leg)
+            both_p, both_d = ctx.hash_uniform(px, n, w, h, 3)
+            _, t98 = ctx.luma_tiles_uniform(px, n, w, h, 3)
+            assert np.array_equal(both_p, got_p), (w, h, "phash with dhash")
+            for j in range(n):
+                _, ed, _, e98, _ = O.hash_image(px[j], want_tiles=True)
+                assert np.array_equal(t98[j], e98), (w, h, j, "tile98")
+                assert int(both_d[j]) == ed, (w, h, j, "dhash")
         if w <= 640 and k % 3 == 0:                      # RGBA / RGBX rows: the fourth byte is ignored, as convert("L") does
             px4 = np.concatenate([px, rng.integers(0, 256, (n, h, w, 1), dtype=np.uint8)], axis=3)
             got4, _ = ctx.hash_uniform(px4, n, w, h, 4, want_dhash=False)

@@ -426,7 +426,9 @@ __global__ __launch_bounds__(256, 2) void ke_phash_fused_mx(const KeFusedArgs a)
     auto load_tile = [&](int t) {
         const uint32_t tile_off = (uint32_t)t * ((uint32_t)QUADS_PER_TILE * QB);
         const uint8_t *tile_ptr = src + tile_off;                 // wave-uniform
-        const uint32_t lim = image_bytes - QB - tile_off;         // last loadable quad, relative to the tile
+        // last loadable quad, relative to the tile; slots past the tile's own quads (run-time row lengths leave some)
+        // re-read its last quad instead of pulling the next tile's bytes a second time
+        const uint32_t lim = min(image_bytes - QB - tile_off, (uint32_t)(QUADS_PER_TILE - 1) * QB);
 #pragma unroll
         for (int q = 0; q < QPT; ++q) {
             // Unconditional loads (a guarded load makes hipcc wait vmcnt(0) after each one): quads past the image
@@ -577,6 +579,160 @@ int launch_fused_mx(ke_ctx *ctx, const KeHashGroup &g, const KeAxisCoeffs *ch, c
         KE_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&ke_phash_fused_mx<W64, KS, DH, GEN, C>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((ke_phash_fused_mx<W64, KS, DH, GEN, C>), dim3((unsigned)g.n), dim3(256), lds, ctx->stream, a);
+    KE_HIP(ctx, hipGetLastError());
+    return KE_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// Wide rows (up to 2048 pixels): the same chain with the work cut differently.  A 32-row tile of such a row
+// no longer fits LDS twice and one wave cannot hold the operands of a whole output tile, so: 16-row tiles,
+// 512 threads, wave = (output tile jt, quarter kh of that tile's operand steps).  Each wave multiplies its KSH
+// steps; the quarters kh = 1..3 hand their plane-combined partial sums (int32, wrap-around arithmetic, so the
+// order of the additions does not matter) to the kh = 0 wave through LDS, which adds the bias, clips and writes
+// the transposed column one tile later -- the exchange of the dHash leg above, four ways.  pHash only.
+// ---------------------------------------------------------------------------------------
+constexpr int kRTW = 16;
+
+template <int KSH, int QPT>
+__global__ __launch_bounds__(512, 1) void ke_phash_fused_wide(const KeFusedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t *Lt = smem;
+    uint8_t *HT = smem + a.lt_bytes;
+    uint8_t *X = smem + a.x_off;                 // [tile parity][jt][kh - 1][lane] x 16 B
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int jt = wv & 1, kh = wv >> 1;
+    const int64_t img = blockIdx.x;
+    const uint8_t *src = a.pixels + (a.offsets ? a.offsets[img] : (uint64_t)img * a.stride);
+    const int h = a.h, QW = a.qw, LP = a.lp;
+    const int quads_per_tile = kRTW * QW;
+    const uint32_t image_bytes = (uint32_t)h * (uint32_t)QW * 12u;
+
+    ke_v4i bf[KSH][3];
+#pragma unroll
+    for (int s = 0; s < KSH; ++s)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+            bf[s][p] = reinterpret_cast<const ke_v4i *>(a.mx_frag)[((jt * 4 * KSH + kh * KSH + s) * 3 + p) * 64 + lane];
+    const int ocol = 16 * jt + (lane & 15);
+    const int hbias = a.h_bias[ocol];
+    const int a_off = (lane & 15) * LP + (jt ? a.mx_base1 : a.mx_base0) + 64 * KSH * kh + 16 * (lane >> 4);
+    uint8_t *ht_dst = HT + (size_t)ocol * a.hp + 4 * (lane >> 4);
+    ke_v4i *x_slot = reinterpret_cast<ke_v4i *>(X) + jt * 192 + lane;     // + 64 per quarter, + 384 for odd tiles
+
+    uint32_t raw[QPT][3];
+    auto load_tile = [&](int t) {
+        const uint32_t tile_off = (uint32_t)t * ((uint32_t)quads_per_tile * 12u);
+        const uint8_t *tile_ptr = src + tile_off;
+        const uint32_t lim = min(image_bytes - 12u - tile_off, (uint32_t)(quads_per_tile - 1) * 12u);
+#pragma unroll
+        for (int q = 0; q < QPT; ++q) {           // unconditional, clamped, non-temporal (see ke_phash_fused_mx)
+            const uint32_t vo = (uint32_t)(q * 512 + tid) * 12u;
+            const uint32_t off = vo < lim ? vo : lim;
+            const uint32_t *p = reinterpret_cast<const uint32_t *>(tile_ptr + off);
+            raw[q][0] = __builtin_nontemporal_load(p);
+            raw[q][1] = __builtin_nontemporal_load(p + 1);
+            raw[q][2] = __builtin_nontemporal_load(p + 2);
+        }
+    };
+    auto store_luma = [&](uint8_t *dst) {
+#pragma unroll
+        for (int q = 0; q < QPT; ++q) {
+            const int i = q * 512 + tid;
+            const int row = (int)__umulhi((uint32_t)i, (uint32_t)a.qw_inv);          // i / QW, exact for i < 2^16
+            if (i < quads_per_tile)
+                *reinterpret_cast<uint32_t *>(dst + row * LP + (i - row * QW) * 4) = luma4_biased(raw[q][0], raw[q][1], raw[q][2]);
+        }
+    };
+    auto products = [&](const uint8_t *cur) -> ke_v4i {
+        ke_v4i acc[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) acc[p] = ke_v4i{0, 0, 0, 0};
+        const uint8_t *ap = cur + a_off;
+#pragma unroll
+        for (int s = 0; s < KSH; ++s) {
+            const ke_v4i av = *reinterpret_cast<const ke_v4i *>(__builtin_assume_aligned(ap + 64 * s, 16));
+#pragma unroll
+            for (int p = 0; p < 3; ++p) acc[p] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, bf[s][p], acc[p], 0, 0, 0);
+        }
+        ke_v4i part;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) part[i] = combine_planes(acc[0][i], acc[1][i], acc[2][i], 0);
+        return part;
+    };
+    ke_v4i carry = {0, 0, 0, 0};
+    auto finish = [&](int t) {                    // kh = 0 waves: tile t's column bytes from the four quarters
+        const ke_v4i *xs = x_slot + (t & 1) * 384;
+        const ke_v4i sum = carry + xs[0] + xs[64] + xs[128];
+        uint32_t packed = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) packed |= (uint32_t)clip8_fixed((int)((uint32_t)sum[i] + (uint32_t)hbias)) << (8 * i);
+        *reinterpret_cast<uint32_t *>(ht_dst + t * kRTW) = packed ^ 0x80808080u;
+    };
+    auto hpass = [&](int t, const uint8_t *cur) {
+        if (kh) {
+            x_slot[(t & 1) * 384 + (kh - 1) * 64] = products(cur);
+        } else {
+            if (t > 0) finish(t - 1);
+            carry = products(cur);
+        }
+    };
+
+    const int ntiles = (h + kRTW - 1) / kRTW;
+    load_tile(0);
+    store_luma(Lt);
+    __syncthreads();
+    for (int t = 0; t + 1 < ntiles; ++t) {
+        load_tile(t + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        hpass(t, Lt + (t & 1) * a.lt_half);
+        __builtin_amdgcn_sched_barrier(0);
+        store_luma(Lt + ((t + 1) & 1) * a.lt_half);
+        __syncthreads();
+    }
+    hpass(ntiles - 1, Lt + ((ntiles - 1) & 1) * a.lt_half);
+    __syncthreads();
+    if (!kh) finish(ntiles - 1);
+    __syncthreads();
+    // the tail is written for 256 threads; the other four waves are done (ended waves leave the barrier count)
+    if (tid >= 256) return;
+    fused_tail<0>(a, Lt, HT, nullptr, tid, img);
+}
+
+template <int KSH, int QPT>
+int launch_fused_wide(ke_ctx *ctx, const KeHashGroup &g, const KeAxisCoeffs *ch, const KeAxisCoeffs *cv, uint64_t *d_phash,
+                      uint8_t *d_tile32) {
+    const int W = g.w;
+    if (W % 4 || kRTW * (W / 4) > 512 * QPT) return KE_EUNSUPPORTED;
+    const KeMxTable *mx = ke_get_mx(ctx, ch, 4 * KSH);
+    if (!mx) return ke_fail(ctx, KE_EHIP, "coefficient upload failed");
+    if (mx->tiles != 2 || mx->ks != 4 * KSH) return KE_EUNSUPPORTED;
+    KeFusedArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.pixels = g.pixels; a.offsets = g.offsets; a.stride = g.stride; a.out_idx = g.out_idx; a.h = g.h;
+    a.h_bias = ch->d_bias;
+    a.v_packed = cv->d_packed; a.v_start = cv->d_start; a.v_bias = cv->d_bias;
+    a.ndwv = cv->ndw;
+    a.mx_frag = mx->d_frag; a.mx_base0 = mx->base[0]; a.mx_base1 = mx->base[1];
+    const int rows_padded = ((g.h + kRTW - 1) / kRTW) * kRTW;
+    const int overhang = std::max(0, std::max(mx->base[0], mx->base[1]) + 64 * 4 * KSH - W);
+    a.qw = W / 4;
+    a.qw_inv = (int)(uint32_t)((0x100000000ull + (uint64_t)a.qw - 1) / (uint64_t)a.qw);
+    a.lp = (((W + 15) / 16 + 1) | 1) * 16;
+    a.lt_half = (kRTW * a.lp + overhang + 15) & ~15;
+    a.lt_bytes = 2 * a.lt_half;
+    a.hp = ((std::max(cv->span, rows_padded) + 7) & ~7) + 8;
+    a.hpd = 8;
+    a.phash = d_phash; a.tile32_out = d_tile32;
+    size_t lds = (size_t)a.lt_bytes + (size_t)32 * a.hp;
+    lds = (lds + 15) & ~(size_t)15;
+    a.x_off = (int)lds;
+    lds += 2 * 2 * 3 * 1024;
+    if (lds > 150 * 1024) return KE_EUNSUPPORTED;     // one workgroup per CU
+    if (lds > 64 * 1024)
+        KE_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&ke_phash_fused_wide<KSH, QPT>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((ke_phash_fused_wide<KSH, QPT>), dim3((unsigned)g.n), dim3(512), lds, ctx->stream, a);
     KE_HIP(ctx, hipGetLastError());
     return KE_OK;
 }
@@ -954,8 +1110,17 @@ int ke_launch_hash_group(ke_ctx *ctx, const KeHashGroup &g, uint64_t *d_phash, u
     KE_TRY(upload_dct_tables(ctx));
     const bool want_p = d_phash || d_tile32_out, want_d = d_dhash || d_tile98_out;
     bool p_done = false, d_done = false;
+    // The single-pass kernels give one workgroup a whole image, so a small group of large images cannot fill the chip
+    // with them; it takes the banded path, which cuts every image into bands (a single image is spread over the whole
+    // GPU).  Measured crossover on MI355X: about 100 images at 512x512, 130-250 at 1024^2 and 2048^2, none below
+    // ~400 KB per image.  KE_FUSED_MIN_IMAGES overrides the threshold (tests set it to 1 to reach these kernels
+    // with a few images).
+    const int64_t image_bytes = (int64_t)g.w * g.h * g.channels;
+    int64_t fused_min = image_bytes < 400 * 1024 ? 1 : std::min<int64_t>(192, image_bytes / 8192);
+    if (const char *e = getenv("KE_FUSED_MIN_IMAGES")) fused_min = atoll(e);
+    const bool fused_ok = g.n >= fused_min;
     // ---- fused fast path: packed RGB, rows of a multiple of 4 pixels up to 768, both axes resampled
-    if (want_p && (g.channels == 3 || g.channels == 4) && g.w % 4 == 0 && g.w > 64 && g.w <= 768 && g.h != 32 && g.h >= 16 && g.h <= 1536 &&
+    if (fused_ok && want_p && (g.channels == 3 || g.channels == 4) && g.w % 4 == 0 && g.w > 64 && g.w <= 768 && g.h != 32 && g.h >= 16 && g.h <= 1536 &&
         !((int64_t)g.h > (int64_t)g.w * 100) && ((uintptr_t)g.pixels % 4 == 0) && (g.offsets || g.stride % 4 == 0)) {
         const KeAxisCoeffs *ch = ke_get_coeffs(ctx, g.w, 32);
         const KeAxisCoeffs *cv = ke_get_coeffs(ctx, g.h, 32);
@@ -1016,6 +1181,19 @@ int ke_launch_hash_group(ke_ctx *ctx, const KeHashGroup &g, uint64_t *d_phash, u
             if (rc == KE_OK) p_done = true;
             else if (rc != KE_EUNSUPPORTED) return rc;
         }
+    }
+    // ---- wide rows: packed RGB, 704 < W <= 2048 (and the 708..764 gap of the kernel above)
+    if (fused_ok && want_p && !p_done && g.channels == 3 && g.w % 4 == 0 && g.w > 704 && g.w <= 2048 && g.h != 32 && g.h >= 16 && g.h <= 4096 &&
+        !((int64_t)g.h > (int64_t)g.w * 100) && ((uintptr_t)g.pixels % 4 == 0) && (g.offsets || g.stride % 4 == 0)) {
+        const KeAxisCoeffs *ch = ke_get_coeffs(ctx, g.w, 32);
+        const KeAxisCoeffs *cv = ke_get_coeffs(ctx, g.h, 32);
+        if (!ch || !cv) return ke_fail(ctx, KE_EHIP, "coefficient upload failed");
+        int rc;
+        if (g.w <= 1024) rc = launch_fused_wide<3, 8>(ctx, g, ch, cv, d_phash, d_tile32_out);
+        else if (g.w <= 1536) rc = launch_fused_wide<4, 12>(ctx, g, ch, cv, d_phash, d_tile32_out);
+        else rc = launch_fused_wide<5, 16>(ctx, g, ch, cv, d_phash, d_tile32_out);
+        if (rc == KE_OK) p_done = true;
+        else if (rc != KE_EUNSUPPORTED) return rc;
     }
     // ---- generic path, chunked so the first-pass scratch stays bounded
     if ((want_p && !p_done) || (want_d && !d_done)) {

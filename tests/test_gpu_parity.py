@@ -109,6 +109,51 @@ def test_phash_any_width_up_to_768_matrix_core_path(ctx):
             assert np.array_equal(got4, got_p), (w, h, "rgba")
 
 
+def test_phash_wide_rows_matrix_core_path(ctx):
+    """RGB rows of 708..2048 pixels take the 512-thread variant (16-row tiles, each output tile's operand steps split
+    over four waves that meet through LDS): widths across its three instantiations, heights around the tile size,
+    tall images (LDS-limited), full-range noise; tile and bits against the oracle."""
+    rng = np.random.default_rng(12)
+    shapes = [(708, 100), (720, 480), (800, 600), (832, 33), (960, 540), (1024, 768), (1028, 64), (1152, 864), (1280, 720),
+              (1440, 900), (1536, 1000), (1540, 17), (1600, 1200), (1920, 1080), (2048, 1100), (2048, 16), (2000, 3000), (1024, 4096)]
+    shapes += [(w, 16 + (w // 4) % 70) for w in range(712, 2049, 92)]
+    for (w, h) in shapes:
+        n = 2
+        px = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
+        px[1] = (rng.integers(0, 2, (h, w, 3)) * 255).astype(np.uint8)
+        got_p, _ = ctx.hash_uniform(px, n, w, h, 3, want_dhash=False)
+        t32, _ = ctx.luma_tiles_uniform(px, n, w, h, 3, want98=False)
+        for j in range(n):
+            ep, _, e32, _, _ = O.hash_image(px[j], want_tiles=True)
+            assert np.array_equal(t32[j], e32), (w, h, j, "tile32")
+            assert int(got_p[j]) == ep, (w, h, j)
+    # both hashes requested: pHash from this kernel, dHash from the banded pass
+    px = rng.integers(0, 256, (2, 300, 1000, 3), dtype=np.uint8)
+    got_p, got_d = ctx.hash_uniform(px, 2, 1000, 300, 3)
+    for j in range(2):
+        ep, ed = O.hash_image(px[j])[:2]
+        assert (int(got_p[j]), int(got_d[j])) == (ep, ed)
+
+
+def test_small_groups_choose_a_path_and_all_paths_agree(ctx, monkeypatch):
+    """Default dispatch (small groups of large images -> banded path, large groups -> one workgroup per image), the
+    single-pass kernels forced and the banded path forced: identical hashes for the same pixels."""
+    rng = np.random.default_rng(77)
+    for (w, h, n) in [(512, 512, 8), (512, 512, 300), (1024, 768, 6), (1920, 1080, 3), (640, 480, 200), (256, 256, 5)]:
+        px = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
+        results = []
+        for mode in (None, "1", "1000000000"):
+            if mode is None:
+                monkeypatch.delenv("KE_FUSED_MIN_IMAGES", raising=False)
+            else:
+                monkeypatch.setenv("KE_FUSED_MIN_IMAGES", mode)
+            results.append(ctx.hash_uniform(px, n, w, h, 3))
+        for p, d in results[1:]:
+            assert np.array_equal(p, results[0][0]) and np.array_equal(d, results[0][1]), (w, h, n)
+        ep, ed = O.hash_image(px[0])[:2]
+        assert (int(results[0][0][0]), int(results[0][1][0])) == (ep, ed)
+
+
 def test_extreme_pixels_fused(ctx):
     """Saturated inputs exercise the clip after each pass and the signed-byte bias."""
     rng = np.random.default_rng(0)

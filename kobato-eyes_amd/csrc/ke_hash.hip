@@ -589,16 +589,18 @@ int launch_fused_mx(ke_ctx *ctx, const KeHashGroup &g, const KeAxisCoeffs *ch, c
 // 512 threads, wave = (output tile jt, quarter kh of that tile's operand steps).  Each wave multiplies its KSH
 // steps; the quarters kh = 1..3 hand their plane-combined partial sums (int32, wrap-around arithmetic, so the
 // order of the additions does not matter) to the kh = 0 wave through LDS, which adds the bias, clips and writes
-// the transposed column one tile later -- the exchange of the dHash leg above, four ways.  pHash only.
+// the transposed column one tile later -- the exchange of the dHash leg above, four ways.  With DH the eight waves
+// also take an eighth each of the dHash axis' operand steps (KDW per wave) and meet in wave 0 the same way.
 // ---------------------------------------------------------------------------------------
 constexpr int kRTW = 16;
 
-template <int KSH, int QPT>
+template <int KSH, int QPT, bool DH, int KDW>
 __global__ __launch_bounds__(512, 1) void ke_phash_fused_wide(const KeFusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *Lt = smem;
     uint8_t *HT = smem + a.lt_bytes;
-    uint8_t *X = smem + a.x_off;                 // [tile parity][jt][kh - 1][lane] x 16 B
+    uint8_t *HTd = HT + 32 * a.hp;
+    uint8_t *X = smem + a.x_off;                 // [tile parity][jt][kh - 1][lane] x 16 B, then [parity][wave - 1][lane] for dHash
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
     const int jt = wv & 1, kh = wv >> 1;
@@ -619,6 +621,20 @@ __global__ __launch_bounds__(512, 1) void ke_phash_fused_wide(const KeFusedArgs 
     const int a_off = (lane & 15) * LP + (jt ? a.mx_base1 : a.mx_base0) + 64 * KSH * kh + 16 * (lane >> 4);
     uint8_t *ht_dst = HT + (size_t)ocol * a.hp + 4 * (lane >> 4);
     ke_v4i *x_slot = reinterpret_cast<ke_v4i *>(X) + jt * 192 + lane;     // + 64 per quarter, + 384 for odd tiles
+    constexpr int KDR = DH ? KDW : 1;
+    ke_v4i bd[KDR][3];
+    int dbias = 0;
+    if (DH) {
+#pragma unroll
+        for (int d = 0; d < KDR; ++d)
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                bd[d][p] = reinterpret_cast<const ke_v4i *>(a.mxd_frag)[((wv * KDW + d) * 3 + p) * 64 + lane];
+        dbias = a.hd_bias[(lane & 15) < 9 ? (lane & 15) : 8];
+    }
+    const int d_off = (lane & 15) * LP + 64 * KDW * wv + 16 * (lane >> 4);
+    uint8_t *htd_dst = HTd + (size_t)(lane & 15) * a.hpd + 4 * (lane >> 4);
+    ke_v4i *xd_slot = reinterpret_cast<ke_v4i *>(X) + 768 + lane;          // + 64 per wave, + 448 for odd tiles
 
     uint32_t raw[QPT][3];
     auto load_tile = [&](int t) {
@@ -660,7 +676,33 @@ __global__ __launch_bounds__(512, 1) void ke_phash_fused_wide(const KeFusedArgs 
         for (int i = 0; i < 4; ++i) part[i] = combine_planes(acc[0][i], acc[1][i], acc[2][i], 0);
         return part;
     };
-    ke_v4i carry = {0, 0, 0, 0};
+    auto dproducts = [&](const uint8_t *cur) -> ke_v4i {
+        ke_v4i dacc[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) dacc[p] = ke_v4i{0, 0, 0, 0};
+        const uint8_t *dp = cur + d_off;
+#pragma unroll
+        for (int d = 0; d < KDR; ++d) {
+            const ke_v4i av = *reinterpret_cast<const ke_v4i *>(__builtin_assume_aligned(dp + 64 * d, 16));
+#pragma unroll
+            for (int p = 0; p < 3; ++p) dacc[p] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, bd[d][p], dacc[p], 0, 0, 0);
+        }
+        ke_v4i part;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) part[i] = combine_planes(dacc[0][i], dacc[1][i], dacc[2][i], 0);
+        return part;
+    };
+    ke_v4i carry = {0, 0, 0, 0}, dcarry = {0, 0, 0, 0};
+    auto dfinish = [&](int t) {                   // wave 0: tile t's dHash column bytes from the eight parts
+        const ke_v4i *xs = xd_slot + (t & 1) * 448;
+        ke_v4i sum = dcarry;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) sum += xs[64 * k];
+        uint32_t packed = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) packed |= (uint32_t)clip8_fixed((int)((uint32_t)sum[i] + (uint32_t)dbias)) << (8 * i);
+        if ((lane & 15) < 9) *reinterpret_cast<uint32_t *>(htd_dst + t * kRTW) = packed ^ 0x80808080u;
+    };
     auto finish = [&](int t) {                    // kh = 0 waves: tile t's column bytes from the four quarters
         const ke_v4i *xs = x_slot + (t & 1) * 384;
         const ke_v4i sum = carry + xs[0] + xs[64] + xs[128];
@@ -675,6 +717,14 @@ __global__ __launch_bounds__(512, 1) void ke_phash_fused_wide(const KeFusedArgs 
         } else {
             if (t > 0) finish(t - 1);
             carry = products(cur);
+        }
+        if (DH) {
+            if (wv) {
+                xd_slot[(t & 1) * 448 + (wv - 1) * 64] = dproducts(cur);
+            } else {
+                if (t > 0) dfinish(t - 1);
+                dcarry = dproducts(cur);
+            }
         }
     };
 
@@ -693,15 +743,16 @@ __global__ __launch_bounds__(512, 1) void ke_phash_fused_wide(const KeFusedArgs 
     hpass(ntiles - 1, Lt + ((ntiles - 1) & 1) * a.lt_half);
     __syncthreads();
     if (!kh) finish(ntiles - 1);
+    if (DH && !wv) dfinish(ntiles - 1);
     __syncthreads();
     // the tail is written for 256 threads; the other four waves are done (ended waves leave the barrier count)
     if (tid >= 256) return;
-    fused_tail<0>(a, Lt, HT, nullptr, tid, img);
+    fused_tail<(DH ? 1 : 0)>(a, Lt, HT, HTd, tid, img);
 }
 
-template <int KSH, int QPT>
+template <int KSH, int QPT, bool DH, int KDW>
 int launch_fused_wide(ke_ctx *ctx, const KeHashGroup &g, const KeAxisCoeffs *ch, const KeAxisCoeffs *cv, uint64_t *d_phash,
-                      uint8_t *d_tile32) {
+                      uint8_t *d_tile32, uint64_t *d_dhash, uint8_t *d_tile98) {
     const int W = g.w;
     if (W % 4 || kRTW * (W / 4) > 512 * QPT) return KE_EUNSUPPORTED;
     const KeMxTable *mx = ke_get_mx(ctx, ch, 4 * KSH);
@@ -715,7 +766,7 @@ int launch_fused_wide(ke_ctx *ctx, const KeHashGroup &g, const KeAxisCoeffs *ch,
     a.ndwv = cv->ndw;
     a.mx_frag = mx->d_frag; a.mx_base0 = mx->base[0]; a.mx_base1 = mx->base[1];
     const int rows_padded = ((g.h + kRTW - 1) / kRTW) * kRTW;
-    const int overhang = std::max(0, std::max(mx->base[0], mx->base[1]) + 64 * 4 * KSH - W);
+    const int overhang = std::max(0, std::max(std::max(mx->base[0], mx->base[1]) + 64 * 4 * KSH, DH ? 512 * KDW : 0) - W);
     a.qw = W / 4;
     a.qw_inv = (int)(uint32_t)((0x100000000ull + (uint64_t)a.qw - 1) / (uint64_t)a.qw);
     a.lp = (((W + 15) / 16 + 1) | 1) * 16;
@@ -725,14 +776,29 @@ int launch_fused_wide(ke_ctx *ctx, const KeHashGroup &g, const KeAxisCoeffs *ch,
     a.hpd = 8;
     a.phash = d_phash; a.tile32_out = d_tile32;
     size_t lds = (size_t)a.lt_bytes + (size_t)32 * a.hp;
+    if (DH) {
+        const KeAxisCoeffs *chd = ke_get_coeffs(ctx, g.w, 9), *cvd = ke_get_coeffs(ctx, g.h, 8);
+        if (!chd || !cvd) return ke_fail(ctx, KE_EHIP, "coefficient upload failed");
+        const KeMxTable *mxd = ke_get_mx(ctx, chd, 8 * KDW);    // the whole row in eight parts of KDW steps
+        const KeChunkTable *tv = ke_get_chunks(ctx, cvd, 3);
+        if (!mxd || !tv) return ke_fail(ctx, KE_EHIP, "coefficient upload failed");
+        if (mxd->tiles != 1 || mxd->base[0] != 0 || mxd->ks != 8 * KDW) return KE_EUNSUPPORTED;
+        a.mxd_frag = mxd->d_frag;
+        a.hd_bias = chd->d_bias;
+        a.vd_cpacked = tv->d_cpacked; a.vd_cstart = tv->d_cstart; a.vd_bias = cvd->d_bias;
+        a.ndwcv = tv->ndwc;
+        a.hpd = ((std::max(tv->cspan, rows_padded) + 7) & ~7) + 8;
+        a.dhash = d_dhash; a.tile98_out = d_tile98;
+        lds += (size_t)9 * a.hpd;
+    }
     lds = (lds + 15) & ~(size_t)15;
     a.x_off = (int)lds;
-    lds += 2 * 2 * 3 * 1024;
+    lds += 2 * 2 * 3 * 1024 + (DH ? 2 * 7 * 1024 : 0);
     if (lds > 150 * 1024) return KE_EUNSUPPORTED;     // one workgroup per CU
     if (lds > 64 * 1024)
-        KE_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&ke_phash_fused_wide<KSH, QPT>),
+        KE_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&ke_phash_fused_wide<KSH, QPT, DH, KDW>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((ke_phash_fused_wide<KSH, QPT>), dim3((unsigned)g.n), dim3(512), lds, ctx->stream, a);
+    hipLaunchKernelGGL((ke_phash_fused_wide<KSH, QPT, DH, KDW>), dim3((unsigned)g.n), dim3(512), lds, ctx->stream, a);
     KE_HIP(ctx, hipGetLastError());
     return KE_OK;
 }
@@ -1188,12 +1254,21 @@ int ke_launch_hash_group(ke_ctx *ctx, const KeHashGroup &g, uint64_t *d_phash, u
         const KeAxisCoeffs *ch = ke_get_coeffs(ctx, g.w, 32);
         const KeAxisCoeffs *cv = ke_get_coeffs(ctx, g.h, 32);
         if (!ch || !cv) return ke_fail(ctx, KE_EHIP, "coefficient upload failed");
-        int rc;
-        if (g.w <= 1024) rc = launch_fused_wide<3, 8>(ctx, g, ch, cv, d_phash, d_tile32_out);
-        else if (g.w <= 1536) rc = launch_fused_wide<4, 12>(ctx, g, ch, cv, d_phash, d_tile32_out);
-        else rc = launch_fused_wide<5, 16>(ctx, g, ch, cv, d_phash, d_tile32_out);
-        if (rc == KE_OK) p_done = true;
-        else if (rc != KE_EUNSUPPORTED) return rc;
+        int rc = KE_EUNSUPPORTED;
+        if (want_d && g.h != 8) {    // both hashes in one pass
+            if (g.w <= 1024) rc = launch_fused_wide<3, 8, true, 2>(ctx, g, ch, cv, d_phash, d_tile32_out, d_dhash, d_tile98_out);
+            else if (g.w <= 1536) rc = launch_fused_wide<4, 12, true, 3>(ctx, g, ch, cv, d_phash, d_tile32_out, d_dhash, d_tile98_out);
+            else rc = launch_fused_wide<5, 16, true, 4>(ctx, g, ch, cv, d_phash, d_tile32_out, d_dhash, d_tile98_out);
+            if (rc == KE_OK) p_done = d_done = true;
+            else if (rc != KE_EUNSUPPORTED) return rc;
+        }
+        if (!p_done) {
+            if (g.w <= 1024) rc = launch_fused_wide<3, 8, false, 1>(ctx, g, ch, cv, d_phash, d_tile32_out, nullptr, nullptr);
+            else if (g.w <= 1536) rc = launch_fused_wide<4, 12, false, 1>(ctx, g, ch, cv, d_phash, d_tile32_out, nullptr, nullptr);
+            else rc = launch_fused_wide<5, 16, false, 1>(ctx, g, ch, cv, d_phash, d_tile32_out, nullptr, nullptr);
+            if (rc == KE_OK) p_done = true;
+            else if (rc != KE_EUNSUPPORTED) return rc;
+        }
     }
     // ---- generic path, chunked so the first-pass scratch stays bounded
     if ((want_p && !p_done) || (want_d && !d_done)) {

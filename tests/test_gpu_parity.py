@@ -127,12 +127,17 @@ def test_phash_wide_rows_matrix_core_path(ctx):
             ep, _, e32, _, _ = O.hash_image(px[j], want_tiles=True)
             assert np.array_equal(t32[j], e32), (w, h, j, "tile32")
             assert int(got_p[j]) == ep, (w, h, j)
-    # both hashes requested: pHash from this kernel, dHash from the banded pass
-    px = rng.integers(0, 256, (2, 300, 1000, 3), dtype=np.uint8)
-    got_p, got_d = ctx.hash_uniform(px, 2, 1000, 300, 3)
-    for j in range(2):
-        ep, ed = O.hash_image(px[j])[:2]
-        assert (int(got_p[j]), int(got_d[j])) == (ep, ed)
+    # both hashes from the same pass (the eight waves share the dHash axis' operand steps)
+    for (w, h) in [(708, 100), (800, 600), (1000, 300), (1024, 768), (1028, 47), (1280, 720), (1536, 16), (1600, 1200), (1920, 1080),
+                   (2048, 900), (2044, 33)]:
+        px = rng.integers(0, 256, (2, h, w, 3), dtype=np.uint8)
+        px[1, :, ::3] = 255
+        got_p, got_d = ctx.hash_uniform(px, 2, w, h, 3)
+        t32, t98 = ctx.luma_tiles_uniform(px, 2, w, h, 3)
+        for j in range(2):
+            ep, ed, e32, e98, _ = O.hash_image(px[j], want_tiles=True)
+            assert np.array_equal(t32[j], e32) and np.array_equal(t98[j], e98), (w, h, j)
+            assert (int(got_p[j]), int(got_d[j])) == (ep, ed), (w, h, j)
 
 
 def test_small_groups_choose_a_path_and_all_paths_agree(ctx, monkeypatch):

@@ -9,14 +9,19 @@
 //       NumPy's pairwise order, 64 compare bits MSB first
 //   K3  dHash from the 9x8 tile
 //
-// Two paths, same arithmetic:
-//   * ke_phash_fused_mx<W64,KS,DH>: one workgroup per image, the whole chain in one launch; the
-//     image is streamed once from HBM (12 B/lane coalesced loads), luma goes to LDS as
-//     signed bytes, the 22-bit tap weights are split into three signed byte planes; the
-//     horizontal taps run on v_mfma_i32_16x16x64_i8, the (32x smaller) vertical taps on
-//     v_dot4_i32_i8.  HBM-bound by design: 3*W*H bytes in, 8 (16 with dHash) out.
-//   * generic passes (ke_resample_pass) for every other shape, channel count and for dHash.
-#include <type_traits>
+// Paths, same arithmetic in all of them:
+//   * single-pass kernels, one workgroup per image, the whole chain in one launch: the image is
+//     streamed once from HBM (12 or 16 B/lane coalesced loads), luma goes to LDS as signed bytes,
+//     the 22-bit tap weights are split into three signed byte planes; the horizontal taps run on
+//     v_mfma_i32_16x16x64_i8 (exact int32), the (32x smaller) vertical taps on v_dot4_i32_i8.
+//     HBM-bound by design: C*W*H bytes in, 8 (16 with dHash) out.
+//       ke_phash_fused_mx    RGB / RGBX rows up to 768 pixels, 32-row tiles, 256 threads
+//       ke_phash_fused_wide  RGB rows of 708..2048 pixels, 16-row tiles, 512 threads
+//   * banded path (ke_hband + ke_vtile + ke_tiles_to_hashes): every other shape, odd widths,
+//     1-byte pixels, and small groups of large images (an image is cut into bands of rows so that a
+//     few images still fill the GPU); also the resize behind ke_resize_luma_uniform / ke_fit_luma_uniform
+//   * generic passes (ke_resample_pass): last resort (Pillow's vertical-first rule, tiny images).
+#include <cstdlib>
 
 #include "ke_internal.h"
 #include "dct_table.h"

@@ -44,7 +44,7 @@ def parse_args():
     ap.add_argument("--threshold", type=int, default=8)
     ap.add_argument("--dhash", action="store_true", help="also compute dHash in the hash step")
     ap.add_argument("--ssim-threshold", type=float, default=None,
-                    help="BASELINE configs[3] flavour (single GPU): re-check every candidate edge with the SSIM kernel inside the step")
+                    help="BASELINE configs[3] flavour: re-check every candidate edge with the SSIM kernel inside the step (pairs sharded over the ranks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--phase-timing", action="store_true", help="after the timed run, time each phase of a step with syncs in between (stderr)")
     ap.add_argument("--cpu-sample", type=int, default=16000, help="images hashed by the CPU oracle for the baseline")
@@ -98,7 +98,7 @@ def main():
     import torch.distributed as dist
 
     from kobato_eyes_amd import _native
-    from kobato_eyes_amd.distributed import allgather_edge_buffers, allgather_hashes
+    from kobato_eyes_amd.distributed import allgather_edge_buffers, allgather_hashes, ssim_refine_sharded
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -159,16 +159,23 @@ def main():
             all_edges = merged.view(_native.EDGE_DTYPE)
         else:
             all_edges = edges_dev[: edges * 24].cpu().numpy().view(_native.EDGE_DTYPE)
-        # 4b. optional SSIM refine of the candidate edges (both images are resident on one GPU)
-        if args.ssim_threshold is not None:
-            if world != 1:
-                raise SystemExit("--ssim-threshold is a single-GPU mode (the pair's images must be resident)")
-            if len(all_edges):
+        # 4b. optional SSIM refine of the candidate edges.  One GPU: every image is resident.  Several: the pairs are
+        #     dealt round-robin and a rank regenerates the images of its pairs from (seed, position).
+        if args.ssim_threshold is not None and len(all_edges):
+            if world == 1:
                 ssim = ctx.ssim_pairs_uniform(pixels.data_ptr(), n_total, side, side, 3, all_edges["a"], all_edges["b"])
-                state["ssim_ms"] = ctx.last_kernel_ms(2)
-                state["ssim_pairs"] = len(all_edges)
-                state["ssim_quartiles"] = [float(q) for q in np.quantile(ssim, [0.0, 0.25, 0.5, 0.75, 1.0])]
-                all_edges = all_edges[ssim >= args.ssim_threshold]
+            else:
+                def fetch(ids):
+                    need = len(ids) * img_bytes
+                    if state.get("pair_px") is None or state["pair_px"].numel() < need:
+                        state["pair_px"] = torch.empty(need, dtype=torch.uint8, device=dev)
+                    ctx.synth_rgb_indexed(SEED, ids, side, side, state["pair_px"].data_ptr())
+                    return state["pair_px"].data_ptr()
+                ssim = ssim_refine_sharded(ctx, all_edges, fetch, side, side, 3)
+            state["ssim_ms"] = ctx.last_kernel_ms(2)
+            state["ssim_pairs"] = len(all_edges)
+            state["ssim_quartiles"] = [float(q) for q in np.quantile(ssim, [0.0, 0.25, 0.5, 0.75, 1.0])]
+            all_edges = all_edges[ssim >= args.ssim_threshold]
         # 5. cluster membership on the host
         labels = _native.cluster_labels(all_edges, n_total)
         state.update(table=table, edges=all_edges, labels=labels, pairs=int(counters[0]))

@@ -161,6 +161,11 @@ int ke_sad_pairs(ke_ctx *ctx, const uint8_t *thumbs, int64_t n_thumbs, int64_t p
  * device or host memory; ke_synth_hashes writes the scan-only hash table. */
 int ke_synth_rgb(ke_ctx *ctx, uint64_t seed, int64_t first_index, int64_t n, int32_t width, int32_t height,
                  uint8_t *rgb_out);
+/* The same generator for an arbitrary list of corpus positions (host or device array): image k of the output is
+ * corpus image indices[k].  A rank that has to evaluate a pair whose images live on another rank regenerates them
+ * this way (SSIM stage); rgb_out must be device memory. */
+int ke_synth_rgb_indexed(ke_ctx *ctx, uint64_t seed, const int64_t *indices, int64_t n, int32_t width, int32_t height,
+                         uint8_t *rgb_out);
 int ke_synth_hashes(ke_ctx *ctx, uint64_t seed, int64_t n, uint64_t *hashes_out);
 
 /* ---- timing hook for bench.py: wall time of the kernels enqueued by the LAST call of the

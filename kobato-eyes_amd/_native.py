@@ -27,6 +27,7 @@ EXPORTS = (
     "ke_get_stream", "ke_synchronize", "ke_device_info", "ke_malloc", "ke_free", "ke_memcpy",
     "ke_hash_images", "ke_hash_uniform", "ke_luma_tiles_uniform", "ke_hamming_scan", "ke_cluster_labels",
     "ke_ssim_pairs_uniform", "ke_resize_luma_uniform", "ke_fit_luma_uniform", "ke_tile_ahash", "ke_sad_pairs", "ke_synth_rgb",
+    "ke_synth_rgb_indexed",
     "ke_synth_hashes", "ke_last_kernel_ms",
 )
 
@@ -82,13 +83,14 @@ def load_library() -> C.CDLL:
         lib.ke_tile_ahash.argtypes = [vp, vp, i64, i32, i32, vp]
         lib.ke_sad_pairs.argtypes = [vp, vp, i64, i64, vp, vp, i64, vp]
         lib.ke_synth_rgb.argtypes = [vp, u64, i64, i64, i32, i32, vp]
+        lib.ke_synth_rgb_indexed.argtypes = [vp, u64, vp, i64, i32, i32, vp]
         lib.ke_synth_hashes.argtypes = [vp, u64, i64, vp]
         lib.ke_last_kernel_ms.argtypes = [vp, i32]
         lib.ke_last_kernel_ms.restype = dbl
         for name in ("ke_set_stream", "ke_synchronize", "ke_device_info", "ke_malloc", "ke_free", "ke_memcpy",
                      "ke_hash_images", "ke_hash_uniform", "ke_luma_tiles_uniform", "ke_hamming_scan",
                      "ke_cluster_labels", "ke_ssim_pairs_uniform", "ke_resize_luma_uniform", "ke_fit_luma_uniform", "ke_tile_ahash",
-                     "ke_sad_pairs", "ke_synth_rgb", "ke_synth_hashes"):
+                     "ke_sad_pairs", "ke_synth_rgb", "ke_synth_rgb_indexed", "ke_synth_hashes"):
             getattr(lib, name).restype = C.c_int
         _lib = lib
         return lib
@@ -314,6 +316,12 @@ class Context:
         with self._lock:
             self._check(self._lib.ke_synth_rgb(self._h, seed, first, n, width, height, _addr(out)), "ke_synth_rgb")
         return out
+
+    def synth_rgb_indexed(self, seed: int, indices, width: int, height: int, out: int) -> None:
+        """Corpus images indices[k] -> device memory at ``out`` (k-th image at out + k*w*h*3)."""
+        idx = np.ascontiguousarray(indices, dtype=np.int64)
+        with self._lock:
+            self._check(self._lib.ke_synth_rgb_indexed(self._h, seed, _addr(idx), len(idx), width, height, out), "ke_synth_rgb_indexed")
 
     def synth_hashes(self, seed: int, n: int, out=None):
         if out is None:

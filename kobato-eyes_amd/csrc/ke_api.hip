@@ -706,7 +706,7 @@ KE_API int ke_synth_rgb(ke_ctx *ctx, uint64_t seed, int64_t first_index, int64_t
     const size_t img_bytes = (size_t)width * height * 3;
     if (ke_is_device_ptr(rgb_out)) {
         ke_time_begin(ctx, KE_T_SYNTH);
-        KE_TRY(ke_launch_synth_rgb(ctx, seed, first_index, n, width, height, rgb_out));
+        KE_TRY(ke_launch_synth_rgb(ctx, seed, first_index, nullptr, n, width, height, rgb_out));
         ke_time_end(ctx, KE_T_SYNTH);
         return KE_OK;
     }
@@ -715,10 +715,25 @@ KE_API int ke_synth_rgb(ke_ctx *ctx, uint64_t seed, int64_t first_index, int64_t
         const int64_t m = std::min(chunk, n - f);
         void *d;
         KE_TRY(ke_reserve(ctx, KE_BUF_PIXELS, (size_t)m * img_bytes, &d));
-        KE_TRY(ke_launch_synth_rgb(ctx, seed, first_index + f, m, width, height, (uint8_t *)d));
+        KE_TRY(ke_launch_synth_rgb(ctx, seed, first_index + f, nullptr, m, width, height, (uint8_t *)d));
         KE_HIP(ctx, hipMemcpyAsync(rgb_out + (size_t)f * img_bytes, d, (size_t)m * img_bytes, hipMemcpyDeviceToHost, ctx->stream));
         KE_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
+    return KE_OK;
+}
+
+KE_API int ke_synth_rgb_indexed(ke_ctx *ctx, uint64_t seed, const int64_t *indices, int64_t n, int32_t width, int32_t height,
+                                uint8_t *rgb_out) {
+    if (!ctx) return KE_EINVAL;
+    if (n < 0 || width <= 0 || height <= 0 || (n > 0 && (!rgb_out || !indices))) return ke_fail(ctx, KE_EINVAL, "bad synth arguments");
+    if (n == 0) return KE_OK;
+    if (!ke_is_device_ptr(rgb_out)) return ke_fail(ctx, KE_EINVAL, "ke_synth_rgb_indexed writes device memory only");
+    KE_HIP(ctx, hipSetDevice(ctx->device));
+    const void *d_idx;
+    KE_TRY(ke_to_device(ctx, indices, (size_t)n * 8, KE_BUF_META, &d_idx));
+    ke_time_begin(ctx, KE_T_SYNTH);
+    KE_TRY(ke_launch_synth_rgb(ctx, seed, 0, (const int64_t *)d_idx, n, width, height, rgb_out));
+    ke_time_end(ctx, KE_T_SYNTH);
     return KE_OK;
 }
 

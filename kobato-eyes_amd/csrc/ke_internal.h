@@ -163,5 +163,6 @@ int ke_launch_scan(ke_ctx *ctx, const uint64_t *d_hashes, const int64_t *d_ids, 
                    unsigned long long *pairs_evaluated);
 int ke_launch_ssim(ke_ctx *ctx, const uint8_t *d_images, int w, int h, int channels, const int64_t *d_pa,
                    const int64_t *d_pb, int64_t n_pairs, double *d_out);
-int ke_launch_synth_rgb(ke_ctx *ctx, uint64_t seed, int64_t first, int64_t n, int w, int h, uint8_t *d_out);
+int ke_launch_synth_rgb(ke_ctx *ctx, uint64_t seed, int64_t first, const int64_t *d_indices, int64_t n, int w, int h,
+                        uint8_t *d_out);
 int ke_launch_synth_hashes(ke_ctx *ctx, uint64_t seed, int64_t n, uint64_t *d_out);

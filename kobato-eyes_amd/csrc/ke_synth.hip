@@ -15,11 +15,12 @@ __device__ __host__ inline uint64_t splitmix64(uint64_t z) {
 }
 constexpr uint64_t P1 = 0xD6E8FEB86659FD93ull, P2 = 0xCA5A826395121157ull, P3 = 0x9E6C63D0676A9A99ull;
 
-__global__ __launch_bounds__(256) void ke_synth_rgb_kernel(uint64_t seed, int64_t first, int w, int h,
-                                                            uint8_t *__restrict__ out, int blocks_per_image) {
+// indices: nullable list of corpus positions to generate (then image k of the launch is indices[k]), else first + k
+__global__ __launch_bounds__(256) void ke_synth_rgb_kernel(uint64_t seed, int64_t first, const int64_t *__restrict__ indices,
+                                                            int w, int h, uint8_t *__restrict__ out, int blocks_per_image) {
     const int64_t k = blockIdx.x / blocks_per_image;
     const int blk = blockIdx.x % blocks_per_image;
-    const int64_t index = first + k;
+    const int64_t index = indices ? indices[k] : first + k;
     const uint64_t r = splitmix64(seed ^ (0x51ED270B0E3A6F5Dull + (uint64_t)index * P1));
     const bool variant = index >= 10 && index % 10 == 9;
     int64_t base = index;
@@ -72,7 +73,7 @@ __global__ void ke_synth_hashes_kernel(uint64_t seed, int64_t n, uint64_t *__res
 
 }  // namespace
 
-int ke_launch_synth_rgb(ke_ctx *ctx, uint64_t seed, int64_t first, int64_t n, int w, int h, uint8_t *d_out) {
+int ke_launch_synth_rgb(ke_ctx *ctx, uint64_t seed, int64_t first, const int64_t *d_indices, int64_t n, int w, int h, uint8_t *d_out) {
     const int64_t npix = (int64_t)w * h;
     int bpi = (int)std::min<int64_t>((npix + 1023) / 1024, 64);
     if (bpi < 1) bpi = 1;
@@ -80,8 +81,8 @@ int ke_launch_synth_rgb(ke_ctx *ctx, uint64_t seed, int64_t first, int64_t n, in
     const int64_t per_launch = 0x7fffffffLL / bpi;
     for (int64_t f = 0; f < n; f += per_launch) {
         const int64_t m = std::min(per_launch, n - f);
-        hipLaunchKernelGGL(ke_synth_rgb_kernel, dim3((unsigned)(m * bpi)), dim3(256), 0, ctx->stream, seed, first + f, w, h,
-                           d_out + (size_t)f * npix * 3, bpi);
+        hipLaunchKernelGGL(ke_synth_rgb_kernel, dim3((unsigned)(m * bpi)), dim3(256), 0, ctx->stream, seed, first + f,
+                           d_indices ? d_indices + f : nullptr, w, h, d_out + (size_t)f * npix * 3, bpi);
         KE_HIP(ctx, hipGetLastError());
     }
     return KE_OK;

@@ -5,7 +5,8 @@ Images are hash-partitioned over ranks (image i belongs to rank i mod world); af
 hashing ONE all-gather shares the 64-bit hash table; the tile triangle of the
 pair scan is then dealt round-robin to ranks (ke_hamming_scan part_index/part_count), each
 rank returns its edges to the host, and rank 0 (or every rank) merges them for clustering.
-No other collective exists on the path.
+With the SSIM refine stage on, the merged candidate pairs are dealt round-robin to the ranks and one more
+small all-gather returns the scores (``ssim_refine_sharded``).
 """
 from __future__ import annotations
 
@@ -112,3 +113,35 @@ def allgather_edge_buffers(edges_u8, count: int, *, group=None):
     _edge_slots_hint[key] = max(slots, want)
     merged = np.concatenate([body[r, : counts[r] * 24] for r in range(world)])
     return merged, counts
+
+
+def ssim_refine_sharded(ctx, edges: np.ndarray, fetch_images, width: int, height: int, channels: int = 3, *, group=None):
+    """SSIM of every candidate pair, the pairs dealt round-robin over the ranks (SSIM stage).
+
+    ``edges``: the merged edge records, identical on every rank (fields a, b = corpus positions).
+    ``fetch_images(ids) -> int``: device pointer to the images of the sorted unique positions ``ids``, packed back to
+    back -- the evaluating rank must hold both images of a pair; for the synthetic corpus they are regenerated from
+    (seed, position), for real files this is a fetch.  Returns float64 SSIM per edge, the same array on every rank.
+    """
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    n = len(edges)
+    mine = np.arange(rank, n, world)
+    per = (n + world - 1) // world
+    local = np.full(per, np.nan)
+    if len(mine):
+        a, b = edges["a"][mine].astype(np.int64), edges["b"][mine].astype(np.int64)
+        ids = np.unique(np.concatenate([a, b]))
+        pixels = fetch_images(ids)
+        local[: len(mine)] = ctx.ssim_pairs_uniform(pixels, len(ids), width, height, channels, np.searchsorted(ids, a),
+                                                    np.searchsorted(ids, b))
+    if world == 1:
+        return local[:n]
+    dev = torch.device("cuda", ctx.device) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    gathered = torch.empty(world * per, dtype=torch.float64, device=dev)
+    dist.all_gather_into_tensor(gathered, torch.from_numpy(local).to(dev), group=group)
+    # gathered[r*per + k] is edge r + k*world
+    return gathered.cpu().numpy().reshape(world, per).T.reshape(-1)[:n]

@@ -11,7 +11,7 @@ import torch
 import torch.distributed as dist
 
 from kobato_eyes_amd import _native
-from kobato_eyes_amd.distributed import allgather_edge_buffers, allgather_hashes, owned_indices
+from kobato_eyes_amd.distributed import allgather_edge_buffers, allgather_hashes, owned_indices, ssim_refine_sharded
 
 dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
 ctx = _native.Context(0)
@@ -43,6 +43,20 @@ pairs = torch.tensor([int(counters[0])], dtype=torch.int64)
 dist.all_reduce(pairs)
 assert int(pairs.item()) == n * (n - 1) // 2, "shards do not tile the pair space exactly once"
 assert np.array_equal(labels, _native.cluster_labels(ref_edges, n))
+# SSIM stage: the merged pairs dealt round-robin, each rank regenerating the images of its pairs from (seed, position)
+scratch = {"ptr": 0}
+def fetch(ids):
+    if scratch["ptr"]:
+        ctx.free(scratch["ptr"])
+    scratch["ptr"] = ctx.malloc(len(ids) * img_bytes)
+    ctx.synth_rgb_indexed(seed, ids, side, side, scratch["ptr"])
+    return scratch["ptr"]
+ssim = ssim_refine_sharded(ctx, all_edges, fetch, side, side, 3)
+ref_ssim = ctx.ssim_pairs_uniform(full_px, n, side, side, 3, all_edges["a"], all_edges["b"])
+assert len(ssim) == len(all_edges) and np.array_equal(ssim, ref_ssim), "sharded SSIM differs from the single-process scores"
+assert np.array_equal(_native.cluster_labels(all_edges[ssim >= 0.9], n), _native.cluster_labels(all_edges[ref_ssim >= 0.9], n))
+if scratch["ptr"]:
+    ctx.free(scratch["ptr"])
 ctx.free(px); ctx.free(full_px)
 dist.barrier()
 dist.destroy_process_group()

@@ -21,8 +21,7 @@ namespace {
 // images live in registers, the five vertical window sums are updated incrementally (+ new row, - oldest
 // row; sums of seven float32 values are exact in fp64, so the order cannot matter), rounded to float32
 // (scipy's axis-0 pass), then the horizontal windows are gathered from the two neighbouring lanes with
-// wave shuffles (axis-1 pass), again summed exactly in fp64.  division by 7: one Newton step on q = s*(1/7),
-// which is the correctly rounded quotient.  x = L/255 is formed arithmetically (exact).
+// wave shuffles (axis-1 pass), again summed exactly in fp64.  division by 7: see mean7.  x = L/255 is formed arithmetically (exact).
 // ---------------------------------------------------------------------------------------
 constexpr int kBandRows = 64;     // interior rows per wave
 
@@ -35,10 +34,16 @@ struct SsimArgs {
     double *partial;   // [pair][items_per_pair]
 };
 
-__device__ __forceinline__ double div7(double s) {
-    const double r = 0x1.2492492492492p-3;           // RN(1/7)
-    const double q = s * r;
-    return fma(fma(-7.0, q, s), r, q);
+// float32(s / 7) for a window sum s, as scipy stores it (double quotient, then the cast): one multiply by RN(1/7).
+// Why that is the same value for every s that occurs here: s is an exact multiple of 2^-42 below 8 (sums of seven
+// float32 values that are 0 or at least 2^-19 -- x >= 1/255, products >= 1/65025, column means of those >= 1/7 of
+// that), so the true quotient K/7 * 2^-42 is either exactly a float32 rounding midpoint or at least 2^-42/7 away
+// from every one of them.  RN(s * r) is within one double ulp (<= 2^-50) of the true quotient, hence on the same
+// side of every midpoint as the correctly rounded double quotient; and when the quotient IS a midpoint (K = 7M),
+// s * r = Q (1 - 2^-54.2) rounds back to Q itself (Q has 25 significant bits), so the tie breaks identically.
+__device__ __forceinline__ float mean7(double s) {
+    const double r = 0x1.2492492492492p-3;           // RN(1/7) = (1/7)(1 - 2^-54.2)
+    return (float)(s * r);
 }
 
 // Four consecutive pixels of one row starting at byte address `ad` (any alignment) -> four luma bytes.
@@ -75,13 +80,13 @@ __device__ __forceinline__ uint32_t load_luma4(uintptr_t ad, uintptr_t last_dwor
     return out;
 }
 
-// x = L/255 in float32, correctly rounded for every L in 0..255 (checked exhaustively against a true
-// division): q0 = L*r, one fma residual, one fma correction.
+// x = L/255 in float32, correctly rounded for every L in 0..255 (checked for all 256 values in exact rational
+// arithmetic): 1/255 = r_hi + r_lo to 48 bits, L * r_lo rounded, then one fma -- L/255 is never close to a float32
+// rounding boundary (255 is odd), so the 2^-24 ulp this loses cannot change the result.
 __device__ __forceinline__ float unit_of(uint32_t L) {
-    const float r = 0x1.010102p-8f;                         // RN(1/255)
+    const float r_hi = 0x1.010102p-8f, r_lo = -0x1.fdfdfep-33f;
     const float l = (float)L;
-    const float q0 = l * r;
-    return fmaf(fmaf(-255.0f, q0, l), r, q0);
+    return fmaf(l, r_hi, l * r_lo);
 }
 
 // PX pixels per lane (4 or 8): a wave covers 64*PX halo columns, 64*PX - 6 interior ones.
@@ -151,11 +156,11 @@ __global__ __launch_bounds__(256, 2) void ke_ssim_waves(const SsimArgs a) {
         float m[5][PX + 6];                                 // [quantity][left 3 | own PX | right 3]
 #pragma unroll
         for (int k = 0; k < PX; ++k) {
-            m[0][3 + k] = (float)div7(sx[k]);
-            m[1][3 + k] = (float)div7(sy[k]);
-            m[2][3 + k] = (float)div7(sxx[k]);
-            m[3][3 + k] = (float)div7(syy[k]);
-            m[4][3 + k] = (float)div7(sxy[k]);
+            m[0][3 + k] = mean7(sx[k]);
+            m[1][3 + k] = mean7(sy[k]);
+            m[2][3 + k] = mean7(sxx[k]);
+            m[3][3 + k] = mean7(syy[k]);
+            m[4][3 + k] = mean7(sxy[k]);
         }
 #pragma unroll
         for (int q = 0; q < 5; ++q) {
@@ -181,8 +186,8 @@ __global__ __launch_bounds__(256, 2) void ke_ssim_waves(const SsimArgs a) {
             }
             const int bc = PX * lane + k;                  // column inside the block
             const bool inside = (bc >= 3) && (bc < 3 + block_cols) && (x0 + bc < a.w - 3);
-            const float ux = (float)div7(hs[0]), uy = (float)div7(hs[1]);
-            const float uxx = (float)div7(hs[2]), uyy = (float)div7(hs[3]), uxy = (float)div7(hs[4]);
+            const float ux = mean7(hs[0]), uy = mean7(hs[1]);
+            const float uxx = mean7(hs[2]), uyy = mean7(hs[3]), uxy = mean7(hs[4]);
             const float mxx = ux * ux, myy = uy * uy, mxy = ux * uy;
             const float vx = cov_norm * (uxx - mxx);
             const float vy = cov_norm * (uyy - myy);

@@ -129,8 +129,7 @@ def main():
     if world == 1:
         ctx.synth_rgb(SEED, 0, n_local, side, side, out=pixels.data_ptr())
     else:
-        for k, i in enumerate(mine.tolist()):   # strided indices: one small launch per image
-            ctx.synth_rgb(SEED, i, 1, side, side, out=pixels.data_ptr() + k * img_bytes)
+        ctx.synth_rgb_indexed(SEED, mine, side, side, pixels.data_ptr())   # this rank's strided positions, one launch
     local_hash = torch.zeros(per, dtype=torch.int64, device=dev)
     local_dhash = torch.zeros(per, dtype=torch.int64, device=dev) if args.dhash else None
     cap = max(1 << 16, n_total)

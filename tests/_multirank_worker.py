@@ -19,8 +19,7 @@ seed = 20260604
 mine = owned_indices(n, rank, world)
 img_bytes = side * side * 3
 px = ctx.malloc(len(mine) * img_bytes)
-for k, i in enumerate(mine.tolist()):
-    ctx.synth_rgb(seed, i, 1, side, side, out=px + k * img_bytes)
+ctx.synth_rgb_indexed(seed, mine, side, side, px)
 local = np.zeros((n + world - 1) // world, np.uint64)
 ph, _ = ctx.hash_uniform(px, len(mine), side, side, 3, want_dhash=False)
 local[: len(mine)] = ph

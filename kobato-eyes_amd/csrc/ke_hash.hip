@@ -599,8 +599,9 @@ int launch_fused_mx(ke_ctx *ctx, const KeHashGroup &g, const KeAxisCoeffs *ch, c
 // ---------------------------------------------------------------------------------------
 constexpr int kRTW = 16;
 
-template <int KSH, int QPT, bool DH, int KDW>
+template <int KSH, int QPT, bool DH, int KDW, int C>
 __global__ __launch_bounds__(512, 1) void ke_phash_fused_wide(const KeFusedArgs a) {
+    constexpr uint32_t QB = 4u * C;              // bytes of a 4-pixel quad (RGB or RGBX)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *Lt = smem;
     uint8_t *HT = smem + a.lt_bytes;
@@ -613,7 +614,7 @@ __global__ __launch_bounds__(512, 1) void ke_phash_fused_wide(const KeFusedArgs 
     const uint8_t *src = a.pixels + (a.offsets ? a.offsets[img] : (uint64_t)img * a.stride);
     const int h = a.h, QW = a.qw, LP = a.lp;
     const int quads_per_tile = kRTW * QW;
-    const uint32_t image_bytes = (uint32_t)h * (uint32_t)QW * 12u;
+    const uint32_t image_bytes = (uint32_t)h * (uint32_t)QW * QB;
 
     ke_v4i bf[KSH][3];
 #pragma unroll
@@ -641,19 +642,18 @@ __global__ __launch_bounds__(512, 1) void ke_phash_fused_wide(const KeFusedArgs 
     uint8_t *htd_dst = HTd + (size_t)(lane & 15) * a.hpd + 4 * (lane >> 4);
     ke_v4i *xd_slot = reinterpret_cast<ke_v4i *>(X) + 768 + lane;          // + 64 per wave, + 448 for odd tiles
 
-    uint32_t raw[QPT][3];
+    uint32_t raw[QPT][C];
     auto load_tile = [&](int t) {
-        const uint32_t tile_off = (uint32_t)t * ((uint32_t)quads_per_tile * 12u);
+        const uint32_t tile_off = (uint32_t)t * ((uint32_t)quads_per_tile * QB);
         const uint8_t *tile_ptr = src + tile_off;
-        const uint32_t lim = min(image_bytes - 12u - tile_off, (uint32_t)(quads_per_tile - 1) * 12u);
+        const uint32_t lim = min(image_bytes - QB - tile_off, (uint32_t)(quads_per_tile - 1) * QB);
 #pragma unroll
         for (int q = 0; q < QPT; ++q) {           // unconditional, clamped, non-temporal (see ke_phash_fused_mx)
-            const uint32_t vo = (uint32_t)(q * 512 + tid) * 12u;
+            const uint32_t vo = (uint32_t)(q * 512 + tid) * QB;
             const uint32_t off = vo < lim ? vo : lim;
             const uint32_t *p = reinterpret_cast<const uint32_t *>(tile_ptr + off);
-            raw[q][0] = __builtin_nontemporal_load(p);
-            raw[q][1] = __builtin_nontemporal_load(p + 1);
-            raw[q][2] = __builtin_nontemporal_load(p + 2);
+#pragma unroll
+            for (int c = 0; c < C; ++c) raw[q][c] = __builtin_nontemporal_load(p + c);
         }
     };
     auto store_luma = [&](uint8_t *dst) {
@@ -662,7 +662,7 @@ __global__ __launch_bounds__(512, 1) void ke_phash_fused_wide(const KeFusedArgs 
             const int i = q * 512 + tid;
             const int row = (int)__umulhi((uint32_t)i, (uint32_t)a.qw_inv);          // i / QW, exact for i < 2^16
             if (i < quads_per_tile)
-                *reinterpret_cast<uint32_t *>(dst + row * LP + (i - row * QW) * 4) = luma4_biased(raw[q][0], raw[q][1], raw[q][2]);
+                *reinterpret_cast<uint32_t *>(dst + row * LP + (i - row * QW) * 4) = luma4_generic<C>(raw[q]);
         }
     };
     auto products = [&](const uint8_t *cur) -> ke_v4i {
@@ -755,7 +755,7 @@ __global__ __launch_bounds__(512, 1) void ke_phash_fused_wide(const KeFusedArgs 
     fused_tail<(DH ? 1 : 0)>(a, Lt, HT, HTd, tid, img);
 }
 
-template <int KSH, int QPT, bool DH, int KDW>
+template <int KSH, int QPT, bool DH, int KDW, int C = 3>
 int launch_fused_wide(ke_ctx *ctx, const KeHashGroup &g, const KeAxisCoeffs *ch, const KeAxisCoeffs *cv, uint64_t *d_phash,
                       uint8_t *d_tile32, uint64_t *d_dhash, uint8_t *d_tile98) {
     const int W = g.w;
@@ -801,9 +801,9 @@ int launch_fused_wide(ke_ctx *ctx, const KeHashGroup &g, const KeAxisCoeffs *ch,
     lds += 2 * 2 * 3 * 1024 + (DH ? 2 * 7 * 1024 : 0);
     if (lds > 150 * 1024) return KE_EUNSUPPORTED;     // one workgroup per CU
     if (lds > 64 * 1024)
-        KE_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&ke_phash_fused_wide<KSH, QPT, DH, KDW>),
+        KE_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&ke_phash_fused_wide<KSH, QPT, DH, KDW, C>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((ke_phash_fused_wide<KSH, QPT, DH, KDW>), dim3((unsigned)g.n), dim3(512), lds, ctx->stream, a);
+    hipLaunchKernelGGL((ke_phash_fused_wide<KSH, QPT, DH, KDW, C>), dim3((unsigned)g.n), dim3(512), lds, ctx->stream, a);
     KE_HIP(ctx, hipGetLastError());
     return KE_OK;
 }
@@ -1254,20 +1254,28 @@ int ke_launch_hash_group(ke_ctx *ctx, const KeHashGroup &g, uint64_t *d_phash, u
         }
     }
     // ---- wide rows: packed RGB, 704 < W <= 2048 (and the 708..764 gap of the kernel above)
-    if (fused_ok && want_p && !p_done && g.channels == 3 && g.w % 4 == 0 && g.w > 704 && g.w <= 2048 && g.h != 32 && g.h >= 16 && g.h <= 4096 &&
+    if (fused_ok && want_p && !p_done && (g.channels == 3 || g.channels == 4) && g.w % 4 == 0 && g.w > (g.channels == 3 ? 704 : 640) &&
+        g.w <= 2048 && g.h != 32 && g.h >= 16 && g.h <= 4096 &&
         !((int64_t)g.h > (int64_t)g.w * 100) && ((uintptr_t)g.pixels % 4 == 0) && (g.offsets || g.stride % 4 == 0)) {
         const KeAxisCoeffs *ch = ke_get_coeffs(ctx, g.w, 32);
         const KeAxisCoeffs *cv = ke_get_coeffs(ctx, g.h, 32);
         if (!ch || !cv) return ke_fail(ctx, KE_EHIP, "coefficient upload failed");
         int rc = KE_EUNSUPPORTED;
-        if (want_d && g.h != 8) {    // both hashes in one pass
+        if (want_d && g.h != 8 && g.channels == 3) {    // both hashes in one pass
             if (g.w <= 1024) rc = launch_fused_wide<3, 8, true, 2>(ctx, g, ch, cv, d_phash, d_tile32_out, d_dhash, d_tile98_out);
             else if (g.w <= 1536) rc = launch_fused_wide<4, 12, true, 3>(ctx, g, ch, cv, d_phash, d_tile32_out, d_dhash, d_tile98_out);
             else rc = launch_fused_wide<5, 16, true, 4>(ctx, g, ch, cv, d_phash, d_tile32_out, d_dhash, d_tile98_out);
             if (rc == KE_OK) p_done = d_done = true;
             else if (rc != KE_EUNSUPPORTED) return rc;
         }
-        if (!p_done) {
+        if (!p_done && g.channels == 4) {
+            if (g.w <= 1024) rc = launch_fused_wide<3, 8, false, 1, 4>(ctx, g, ch, cv, d_phash, d_tile32_out, nullptr, nullptr);
+            else if (g.w <= 1536) rc = launch_fused_wide<4, 12, false, 1, 4>(ctx, g, ch, cv, d_phash, d_tile32_out, nullptr, nullptr);
+            else rc = launch_fused_wide<5, 16, false, 1, 4>(ctx, g, ch, cv, d_phash, d_tile32_out, nullptr, nullptr);
+            if (rc == KE_OK) p_done = true;
+            else if (rc != KE_EUNSUPPORTED) return rc;
+        }
+        if (!p_done && g.channels == 3) {
             if (g.w <= 1024) rc = launch_fused_wide<3, 8, false, 1>(ctx, g, ch, cv, d_phash, d_tile32_out, nullptr, nullptr);
             else if (g.w <= 1536) rc = launch_fused_wide<4, 12, false, 1>(ctx, g, ch, cv, d_phash, d_tile32_out, nullptr, nullptr);
             else rc = launch_fused_wide<5, 16, false, 1>(ctx, g, ch, cv, d_phash, d_tile32_out, nullptr, nullptr);

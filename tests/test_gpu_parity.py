@@ -127,6 +127,14 @@ def test_phash_wide_rows_matrix_core_path(ctx):
             ep, _, e32, _, _ = O.hash_image(px[j], want_tiles=True)
             assert np.array_equal(t32[j], e32), (w, h, j, "tile32")
             assert int(got_p[j]) == ep, (w, h, j)
+    # RGBA / RGBX rows (644..2048): the fourth byte is ignored, as convert("L") ignores it
+    for (w, h) in [(644, 40), (800, 600), (1024, 64), (1284, 100), (1920, 1080), (2048, 31)]:
+        px = rng.integers(0, 256, (2, h, w, 4), dtype=np.uint8)
+        got4, _ = ctx.hash_uniform(px, 2, w, h, 4, want_dhash=False)
+        both_p, both_d = ctx.hash_uniform(px, 2, w, h, 4)
+        for j in range(2):
+            ep, ed = O.hash_image(px[j])[:2]
+            assert int(got4[j]) == ep and (int(both_p[j]), int(both_d[j])) == (ep, ed), (w, h, j, "rgba")
     # both hashes from the same pass (the eight waves share the dHash axis' operand steps)
     for (w, h) in [(708, 100), (800, 600), (1000, 300), (1024, 768), (1028, 47), (1280, 720), (1536, 16), (1600, 1200), (1920, 1080),
                    (2048, 900), (2044, 33)]:

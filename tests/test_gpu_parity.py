@@ -65,7 +65,7 @@ def test_phash_only_matrix_core_path(ctx, w):
     16-output tiles): heights around the tile size, ragged ends, full-range noise (clip on both sides) and the
     heights where the launch falls back to the dot-product kernel (LDS) all give the oracle's tile and bits."""
     rng = np.random.default_rng(w)
-    for h in (16, 17, 31, 33, 47, 64, 65, 100, 333, 512, 700, 900, 1000, 1536):
+    for h in (16, 17, 31, 33, 47, 64, 65, 100, 333, 512, 700, 900, 1000, 1536, 2048, 3000, 4096):
         n = 5
         px = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
         px[1] = (rng.integers(0, 2, (h, w, 3)) * 255).astype(np.uint8)

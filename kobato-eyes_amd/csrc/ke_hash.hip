@@ -1215,7 +1215,9 @@ int ke_launch_hash_group(ke_ctx *ctx, const KeHashGroup &g, uint64_t *d_phash, u
             if (rc == KE_OK) p_done = d_done = true;
             else if (rc != KE_EUNSUPPORTED) return rc;
         }
-        if (!p_done && g.channels == 3) {   // pHash alone (or the image is too tall for both column sets to fit in LDS)
+        // both hashes of RGB rows of 516..768 pixels: the wide-row kernel below has a dHash leg for them, this one does not
+        const bool wide_both = want_d && g.h != 8 && g.channels == 3 && g.w > 512;
+        if (!p_done && g.channels == 3 && !wide_both) {   // pHash alone (or the image is too tall for both column sets to fit in LDS)
             rc = KE_EUNSUPPORTED;
             switch (g.w) {          // widths with their own instantiation: compile-time row length
                 case 256: rc = launch_fused_mx<4, 3, false>(ctx, g, ch, cv, d_phash, d_tile32_out, nullptr, nullptr); break;
@@ -1255,7 +1257,8 @@ int ke_launch_hash_group(ke_ctx *ctx, const KeHashGroup &g, uint64_t *d_phash, u
         }
     }
     // ---- wide rows: packed RGB, 704 < W <= 2048 (and the 708..764 gap of the kernel above)
-    if (fused_ok && want_p && !p_done && (g.channels == 3 || g.channels == 4) && g.w % 4 == 0 && g.w > (g.channels == 3 ? 704 : 640) &&
+    if (fused_ok && want_p && !p_done && (g.channels == 3 || g.channels == 4) && g.w % 4 == 0 &&
+        g.w > (g.channels == 4 ? 640 : (want_d && g.h != 8) ? 512 : 704) &&
         g.w <= 2048 && g.h != 32 && g.h >= 16 && g.h <= 4096 &&
         !((int64_t)g.h > (int64_t)g.w * 100) && ((uintptr_t)g.pixels % 4 == 0) && (g.offsets || g.stride % 4 == 0)) {
         const KeAxisCoeffs *ch = ke_get_coeffs(ctx, g.w, 32);

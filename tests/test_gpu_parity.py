@@ -136,8 +136,8 @@ def test_phash_wide_rows_matrix_core_path(ctx):
             ep, ed = O.hash_image(px[j])[:2]
             assert int(got4[j]) == ep and (int(both_p[j]), int(both_d[j])) == (ep, ed), (w, h, j, "rgba")
     # both hashes from the same pass (the eight waves share the dHash axis' operand steps)
-    for (w, h) in [(708, 100), (800, 600), (1000, 300), (1024, 768), (1028, 47), (1280, 720), (1536, 16), (1600, 1200), (1920, 1080),
-                   (2048, 900), (2044, 33)]:
+    for (w, h) in [(516, 64), (640, 480), (704, 99), (768, 768), (708, 100), (800, 600), (1000, 300), (1024, 768), (1028, 47), (1280, 720),
+                   (1536, 16), (1600, 1200), (1920, 1080), (2048, 900), (2044, 33)]:
         px = rng.integers(0, 256, (2, h, w, 3), dtype=np.uint8)
         px[1, :, ::3] = 255
         got_p, got_d = ctx.hash_uniform(px, 2, w, h, 3)

@@ -145,11 +145,11 @@ const KeChunkTable *ke_get_chunks(ke_ctx *ctx, const KeAxisCoeffs *cc, int cpo, 
     return t;
 }
 
-const KeMxTable *ke_get_mx(ke_ctx *ctx, const KeAxisCoeffs *cc, int min_ks) {
+const KeMxTable *ke_get_mx(ke_ctx *ctx, const KeAxisCoeffs *cc, int min_ks, bool align64) {
     auto *c = const_cast<KeAxisCoeffs *>(cc);
     if (c->mx) return c->mx;
     auto *t = new KeMxTable();
-    ke_build_mx(*c, *t, min_ks);
+    ke_build_mx(*c, *t, min_ks, align64);
     if (upload_i32(ctx, t->frag, &t->d_frag)) {
         delete t;
         return nullptr;

@@ -130,7 +130,7 @@ void ke_build_axis_coeffs(int in_size, int out_size, KeAxisCoeffs &c, int filter
 }
 
 // Byte planes of the taps as matrix-core B operands (see KeMxTable).
-void ke_build_mx(const KeAxisCoeffs &c, KeMxTable &t, int min_ks) {
+void ke_build_mx(const KeAxisCoeffs &c, KeMxTable &t, int min_ks, bool align64) {
     t.tiles = (c.out_size + 15) / 16;
     t.base.assign((size_t)t.tiles, 0);
     t.ks = std::max(1, min_ks);
@@ -142,8 +142,8 @@ void ke_build_mx(const KeAxisCoeffs &c, KeMxTable &t, int min_ks) {
         }
         // 64-aligned when that costs no extra step (the kernel's dHash leg shares A operands between axes then)
         const int ks16 = (hi - (lo & ~15) + 63) / 64, ks64 = (hi - (lo & ~63) + 63) / 64;
-        t.base[j] = ks64 == ks16 ? (lo & ~63) : (lo & ~15);
-        t.ks = std::max(t.ks, ks16);
+        t.base[j] = (align64 || ks64 == ks16) ? (lo & ~63) : (lo & ~15);
+        t.ks = std::max(t.ks, align64 ? ks64 : ks16);
     }
     t.frag.assign((size_t)t.tiles * t.ks * 3 * 64 * 4, 0);
     for (int j = 0; j < t.tiles; ++j)

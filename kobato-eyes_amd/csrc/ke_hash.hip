@@ -1050,6 +1050,8 @@ int launch_hband_ndwc(ke_ctx *ctx, const KeBandArgs &a, int64_t n, size_t lds, i
     }
 }
 
+int launch_vtile(ke_ctx *ctx, const uint8_t *hs, int hp, int64_t n, int ow, int oh, const KeAxisCoeffs *cvt, uint8_t *d_tiles);
+
 // Banded target: src images -> (oh x ow) u8 tiles.  Returns KE_EUNSUPPORTED for shapes it does not take
 // (Pillow's vertical-first rule, images under 4 pixels, windows beyond 8 chunks of 32 dwords).
 int resample_banded(ke_ctx *ctx, const KeHashGroup &g, int ow, int oh, uint8_t *d_tiles, int filter = KE_FILTER_LANCZOS,
@@ -1123,15 +1125,238 @@ int resample_banded(ke_ctx *ctx, const KeHashGroup &g, int ow, int oh, uint8_t *
         else rc = aligned ? launch_hband_ndwc<4, true>(ctx, a, g.n, lds, tc->ndwc) : launch_hband_ndwc<4, false>(ctx, a, g.n, lds, tc->ndwc);
         if (rc != KE_OK) return rc;
     }
+    return launch_vtile(ctx, a.hs, a.hp, g.n, ow, oh, cvt, d_tiles);
+}
+
+// vertical taps of the banded paths: hs[img][ow][hp] signed bytes -> (oh x ow) u8 tiles
+int launch_vtile(ke_ctx *ctx, const uint8_t *hs, int hp, int64_t n, int ow, int oh, const KeAxisCoeffs *cvt, uint8_t *d_tiles) {
     KeVtileArgs v;
-    v.hs = a.hs; v.hp = a.hp; v.ow = ow; v.oh = oh;
+    v.hs = hs; v.hp = hp; v.ow = ow; v.oh = oh;
     v.packed = cvt->d_packed; v.start = cvt->d_start; v.bias = cvt->d_bias; v.ndw = cvt->ndw;
-    v.cg = std::max(1, std::min(ow, (48 * 1024) / a.hp));
+    v.cg = std::max(1, std::min(ow, (48 * 1024) / hp));
     v.tiles = d_tiles;
-    if ((size_t)v.cg * a.hp > 64 * 1024) return KE_EUNSUPPORTED;
-    hipLaunchKernelGGL(ke_vtile, dim3((unsigned)g.n), dim3(256), (size_t)v.cg * a.hp, ctx->stream, v);
+    if ((size_t)v.cg * hp > 64 * 1024) return KE_EUNSUPPORTED;
+    hipLaunchKernelGGL(ke_vtile, dim3((unsigned)n), dim3(256), (size_t)v.cg * hp, ctx->stream, v);
     KE_HIP(ctx, hipGetLastError());
     return KE_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// Rows wider than 2048 pixels (photographs): the horizontal pass of the banded path on the matrix cores.
+// A workgroup owns a band of rows of one image and walks it in 16-row tiles; a tile is taken in strips of
+// 2048 pixels (16 rows x 2048 luma bytes = one LDS buffer, two buffers), and the int32 accumulators of an
+// output tile live across the strips of a tile.  1024 threads: wave = (output tile jt, eighth kh of that
+// tile's operand steps); a step belongs to exactly one strip (tile bases and strip edges are multiples of
+// 64), so a wave multiplies in a strip the steps of its eighth that fall into it.  After the last strip the
+// eighths meet in the kh = 0 wave through LDS (one tile later, as in ke_phash_fused_wide), which clips and
+// stages the band's transposed bytes; they leave for the global scratch at the end of the band and
+// ke_vtile / ke_tiles_to_hashes finish as for every banded image.
+// ---------------------------------------------------------------------------------------
+struct KeStripArgs {
+    const uint8_t *pixels;
+    const uint64_t *offsets;
+    uint64_t stride;
+    int w, h;
+    int nstrips;            // ceil(w / 2048)
+    int band_rows, bands;   // rows per workgroup (multiple of 16), workgroups per image
+    const int32_t *mx_frag; // KeMxTable::frag, 8 * KSH steps per tile, bases multiples of 64
+    int base0, base1;
+    const int32_t *bias;
+    int bp;                 // pitch of one output column of the band staging area (bytes, multiple of 4)
+    int x_off, hb_off;      // LDS offsets of the exchange slots and of the staging area
+    uint8_t *hs;            // [img][32][hp]
+    int hp;
+};
+
+constexpr int kSW = 2048;                 // strip width in pixels: 16 rows of it are one LDS buffer
+constexpr int kSLP = kSW + 16;            // LDS pitch of a strip row (129 x 16 B: conflict-free operand rows)
+
+// The strip geometry is compile-time on purpose: a run-time strip width (equal strips, no nearly empty last one)
+// costs row/column registers per load slot, spills at 1024 threads x 128 registers and ran 25 % slower.
+template <int KSH>
+__global__ __launch_bounds__(1024) void ke_hstrips(const KeStripArgs a) {
+    constexpr int QPT = 16 * (kSW / 4) / 1024;     // 8 quads per thread per strip
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t *Lt = smem;
+    ke_v4i *X = reinterpret_cast<ke_v4i *>(smem + a.x_off);      // [parity][jt][kh - 1][lane]
+    uint8_t *HB = smem + a.hb_off;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int jt = wv & 1, kh = wv >> 1;
+    const int64_t img = blockIdx.x / a.bands;
+    const int band = blockIdx.x % a.bands;
+    const uint8_t *src = a.pixels + (a.offsets ? a.offsets[img] : (uint64_t)img * a.stride);
+    const int y_begin = band * a.band_rows;
+    const int y_end = min(a.h, y_begin + a.band_rows);
+    const int ntiles = (y_end - y_begin + 15) / 16;
+    const int S = a.nstrips, nit = ntiles * S;
+
+    ke_v4i bf[KSH][3];
+#pragma unroll
+    for (int i = 0; i < KSH; ++i)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+            bf[i][p] = reinterpret_cast<const ke_v4i *>(a.mx_frag)[((jt * 8 * KSH + kh * KSH + i) * 3 + p) * 64 + lane];
+    const int x_first = (jt ? a.base1 : a.base0) + 64 * KSH * kh;     // first tap column of this wave's steps (wave-uniform)
+    const int ocol = 16 * jt + (lane & 15);
+    const int obias = a.bias[ocol];
+    const int a_row = (lane & 15) * kSLP + 16 * (lane >> 4);
+    ke_v4i *x_slot = X + jt * 448 + lane;                       // + 64 per eighth, + 896 for odd tiles
+    uint8_t *hb_dst = HB + (size_t)ocol * a.bp + 4 * (lane >> 4);
+
+    // pixel quads of a strip: item = q*1024 + tid -> (row = item / 512, quad = item % 512)
+    const uint32_t row_bytes = (uint32_t)a.w * 3u;
+    uint32_t raw[QPT][3];
+    auto load_it = [&](int it) {
+        const int t = it / S, s = it - t * S;
+        const int x0 = s * kSW;
+        const int qmax = (min(kSW, a.w - x0) >> 2) - 1;             // last quad of this strip's row segment
+#pragma unroll
+        for (int q = 0; q < QPT; ++q) {
+            const int item = q * 1024 + tid;
+            const int y = min(y_begin + 16 * t + (item >> 9), a.h - 1);
+            const int c = min(item & 511, qmax);
+            const uint32_t *p = reinterpret_cast<const uint32_t *>(src + (uint32_t)y * row_bytes + (uint32_t)(x0 + 4 * c) * 3u);
+            raw[q][0] = __builtin_nontemporal_load(p);
+            raw[q][1] = __builtin_nontemporal_load(p + 1);
+            raw[q][2] = __builtin_nontemporal_load(p + 2);
+        }
+    };
+    auto store_luma = [&](uint8_t *dst) {
+#pragma unroll
+        for (int q = 0; q < QPT; ++q) {
+            const int item = q * 1024 + tid;
+            *reinterpret_cast<uint32_t *>(dst + (item >> 9) * kSLP + 4 * (item & 511)) = luma4_biased(raw[q][0], raw[q][1], raw[q][2]);
+        }
+    };
+    ke_v4i acc[3], carry = {0, 0, 0, 0};
+#pragma unroll
+    for (int p = 0; p < 3; ++p) acc[p] = ke_v4i{0, 0, 0, 0};
+    auto finish = [&](int t) {                     // kh = 0 waves: tile t's column bytes from the eight parts
+        const ke_v4i *xs = x_slot + (t & 1) * 896;
+        ke_v4i sum = carry;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) sum += xs[64 * k];
+        uint32_t packed = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) packed |= (uint32_t)clip8_fixed((int)((uint32_t)sum[i] + (uint32_t)obias)) << (8 * i);
+        *reinterpret_cast<uint32_t *>(hb_dst + 16 * t) = packed ^ 0x80808080u;
+    };
+    auto compute = [&](int it, const uint8_t *cur) {
+        const int t = it / S, s = it - t * S;
+        const uint8_t *ap = cur + a_row;
+#pragma unroll
+        for (int i = 0; i < KSH; ++i) {
+            const int x = x_first + 64 * i;
+            if ((x >> 11) == s) {                  // wave-uniform: this step's 64 columns lie in the strip
+                const ke_v4i av = *reinterpret_cast<const ke_v4i *>(__builtin_assume_aligned(ap + (x & (kSW - 1)), 16));
+#pragma unroll
+                for (int p = 0; p < 3; ++p) acc[p] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, bf[i][p], acc[p], 0, 0, 0);
+            }
+        }
+        if (s == S - 1) {                          // the tile is complete
+            ke_v4i part;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) part[i] = combine_planes(acc[0][i], acc[1][i], acc[2][i], 0);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) acc[p] = ke_v4i{0, 0, 0, 0};
+            if (kh) {
+                x_slot[(t & 1) * 896 + (kh - 1) * 64] = part;
+            } else {
+                if (t > 0) finish(t - 1);
+                carry = part;
+            }
+        }
+    };
+
+    load_it(0);
+    store_luma(Lt);
+    __syncthreads();
+    for (int it = 0; it + 1 < nit; ++it) {
+        load_it(it + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(it, Lt + (it & 1) * (16 * kSLP));
+        __builtin_amdgcn_sched_barrier(0);
+        store_luma(Lt + ((it + 1) & 1) * (16 * kSLP));
+        __syncthreads();
+    }
+    compute(nit - 1, Lt + ((nit - 1) & 1) * (16 * kSLP));
+    __syncthreads();
+    if (!kh) finish(ntiles - 1);
+    __syncthreads();
+    // write the band out: whole dwords along y (y_begin and bp are multiples of 4; hs rows are padded)
+    {
+        const int wpc = (y_end - y_begin + 3) / 4;
+        uint8_t *dst = a.hs + (size_t)img * 32 * a.hp + y_begin;
+        for (int e = tid; e < 32 * wpc; e += 1024) {
+            const int col = e / wpc, k = e % wpc;
+            *reinterpret_cast<uint32_t *>(dst + (size_t)col * a.hp + 4 * k) = *reinterpret_cast<const uint32_t *>(HB + col * a.bp + 4 * k);
+        }
+    }
+}
+
+int launch_vtile(ke_ctx *ctx, const uint8_t *hs, int hp, int64_t n, int ow, int oh, const KeAxisCoeffs *cvt, uint8_t *d_tiles);
+
+// pHash tile (32 x 32) of packed RGB images 2052..5300 pixels wide, large groups only
+int resample_strips(ke_ctx *ctx, const KeHashGroup &g, uint8_t *d_tiles) {
+    if (g.channels != 3 || g.w % 4 || g.w <= 2048 || (int64_t)g.h > (int64_t)g.w * 100) return KE_EUNSUPPORTED;
+    if ((int64_t)g.w * g.h * 3 >= (1LL << 31) || (uintptr_t)g.pixels % 4 || !(g.offsets || g.stride % 4 == 0)) return KE_EUNSUPPORTED;
+    const KeAxisCoeffs *chz = ke_get_coeffs(ctx, g.w, 32);
+    const KeAxisCoeffs *cvt = ke_get_coeffs(ctx, g.h, 32);
+    if (!chz || !cvt) return ke_fail(ctx, KE_EHIP, "coefficient upload failed");
+    // natural step count with 64-aligned bases decides the instantiation
+    int ks = 0;
+    for (int j = 0; j < 2; ++j) {
+        int lo = g.w, hi = 0;
+        for (int o = 16 * j; o < 16 * j + 16; ++o) { lo = std::min(lo, chz->bounds[2 * o]); hi = std::max(hi, chz->bounds[2 * o] + chz->bounds[2 * o + 1]); }
+        ks = std::max(ks, (hi - (lo & ~63) + 63) / 64);
+    }
+    const int ksh = (ks + 7) / 8;
+    if (ksh > 6) return KE_EUNSUPPORTED;
+    const KeMxTable *mx = ke_get_mx(ctx, chz, 8 * std::max(ksh, 3), true);
+    if (!mx) return ke_fail(ctx, KE_EHIP, "coefficient upload failed");
+    if (mx->tiles != 2 || mx->ks != 8 * std::max(ksh, 3) || mx->base[0] % 64 || mx->base[1] % 64) return KE_EUNSUPPORTED;
+    KeStripArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.pixels = g.pixels; a.offsets = g.offsets; a.stride = g.stride; a.w = g.w; a.h = g.h;
+    a.nstrips = (g.w + kSW - 1) / kSW;
+    // a nearly empty last strip costs a full strip of load slots: rows that leave less than 3/8 of one stay banded
+    if (g.w - (a.nstrips - 1) * kSW < 768) return KE_EUNSUPPORTED;
+    // bands of up to 256 rows, equal, multiples of 16; only worth it when the bands fill the chip
+    const int64_t want_bands = (g.h + 255) / 256;
+    a.band_rows = (int)((((g.h + want_bands - 1) / want_bands) + 15) / 16 * 16);
+    a.bands = (g.h + a.band_rows - 1) / a.band_rows;
+    // few workgroups cannot fill the chip: such groups keep the banded kernel (smaller bands, up to 3072 workgroups);
+    // KE_FUSED_MIN_IMAGES, when set, decides instead (as for the single-pass kernels)
+    if (const char *e = getenv("KE_FUSED_MIN_IMAGES")) {
+        if (g.n < atoll(e)) return KE_EUNSUPPORTED;
+    } else if (g.n * a.bands < 2 * (int64_t)ctx->cu_count) {
+        return KE_EUNSUPPORTED;
+    }
+    a.mx_frag = mx->d_frag; a.base0 = mx->base[0]; a.base1 = mx->base[1];
+    a.bias = chz->d_bias;
+    a.bp = a.band_rows + 4;
+    size_t lds = 2 * (size_t)16 * kSLP;
+    a.x_off = (int)lds; lds += 2 * 2 * 7 * 1024;
+    a.hb_off = (int)lds; lds += (size_t)32 * a.bp;
+    a.hp = ((std::max(cvt->span, g.h + 4) + 7) & ~7) + 8;
+    void *hs;
+    KE_TRY(ke_reserve(ctx, KE_BUF_TMP, (size_t)g.n * 32 * a.hp, &hs));
+    a.hs = (uint8_t *)hs;
+    if ((int64_t)g.n * a.bands > 0x7fffffffLL) return ke_fail(ctx, KE_EUNSUPPORTED, "group too large for one launch");
+    const dim3 grid((unsigned)(g.n * a.bands)), blk(1024);
+#define KE_STRIPS(K) do { \
+        KE_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&ke_hstrips<K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL(ke_hstrips<K>, grid, blk, lds, ctx->stream, a); } while (0)
+    switch (std::max(ksh, 3)) {
+        case 3: KE_STRIPS(3); break;
+        case 4: KE_STRIPS(4); break;
+        case 5: KE_STRIPS(5); break;
+        default: KE_STRIPS(6); break;
+    }
+#undef KE_STRIPS
+    KE_HIP(ctx, hipGetLastError());
+    return launch_vtile(ctx, a.hs, a.hp, g.n, 32, 32, cvt, d_tiles);
 }
 
 // Generic target: src images -> (oh x ow) u8 tiles, two single-axis passes in Pillow's order.
@@ -1307,7 +1532,8 @@ int ke_launch_hash_group(ke_ctx *ctx, const KeHashGroup &g, uint64_t *d_phash, u
             if (want_p && !p_done) {
                 if (d_tile32_out) t32 = d_tile32_out + (size_t)f * 1024;
                 else KE_TRY(ke_reserve(ctx, KE_BUF_TILE32, (size_t)s.n * 1024, &t32));
-                int rb = resample_banded(ctx, s, 32, 32, (uint8_t *)t32);
+                int rb = resample_strips(ctx, s, (uint8_t *)t32);
+                if (rb == KE_EUNSUPPORTED) rb = resample_banded(ctx, s, 32, 32, (uint8_t *)t32);
                 if (rb == KE_EUNSUPPORTED) rb = resample_generic(ctx, s, 32, 32, (uint8_t *)t32);
                 KE_TRY(rb);
             }

@@ -69,7 +69,7 @@ struct KeChunkTable {
 
 void ke_build_axis_coeffs(int in_size, int out_size, KeAxisCoeffs &out, int filter, float in0, float in1);
 void ke_build_chunked(const KeAxisCoeffs &c, int cpo, KeChunkTable &out, int ndwc_multiple = 4);
-void ke_build_mx(const KeAxisCoeffs &c, KeMxTable &out, int min_ks = 0);
+void ke_build_mx(const KeAxisCoeffs &c, KeMxTable &out, int min_ks = 0, bool align64 = false);
 
 struct KeDevBuf {
     void *ptr = nullptr;
@@ -135,7 +135,8 @@ const KeAxisCoeffs *ke_get_coeffs(ke_ctx *ctx, int in_size, int out_size, int fi
                                   float in1 = -1.0f);
 const KeChunkTable *ke_get_chunks(ke_ctx *ctx, const KeAxisCoeffs *c, int cpo, int ndwc_multiple = 4);
 // min_ks: build with at least this many steps per tile (zero operands past the window); a cached table keeps its own
-const KeMxTable *ke_get_mx(ke_ctx *ctx, const KeAxisCoeffs *c, int min_ks = 0);
+// align64: every tile's first tap column is a multiple of 64 (the strip kernel cuts rows at multiples of 64)
+const KeMxTable *ke_get_mx(ke_ctx *ctx, const KeAxisCoeffs *c, int min_ks = 0, bool align64 = false);
 void ke_time_begin(ke_ctx *ctx, int kind);
 void ke_time_end(ke_ctx *ctx, int kind);
 

@@ -167,6 +167,25 @@ def test_small_groups_choose_a_path_and_all_paths_agree(ctx, monkeypatch):
         assert (int(results[0][0][0]), int(results[0][1][0])) == (ep, ed)
 
 
+def test_phash_strip_kernel_for_rows_wider_than_2048(ctx):
+    """Photograph-sized rows (2816..5300 pixels) take the banded horizontal pass on the matrix cores (16-row tiles in
+    strips of 2048 pixels, accumulators carried across the strips, eight waves per output tile): widths across its four
+    instantiations, 2 and 3 strips, bands that end inside a tile, a full 12-megapixel frame; both hashes (dHash of these
+    shapes comes from the banded kernel) and the 32x32 tile against the oracle."""
+    rng = np.random.default_rng(21)
+    for (w, h) in [(2816, 64), (3000, 33), (3072, 300), (3264, 17), (4000, 3000), (4032, 64), (4096, 500), (4608, 80), (5184, 48),
+                   (5296, 16), (2560, 100), (5400, 16)]:          # the last two fall outside it (nearly empty strip / too many steps)
+        n = 2
+        px = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
+        px[1] = (rng.integers(0, 2, (h, w, 3)) * 255).astype(np.uint8)
+        got_p, got_d = ctx.hash_uniform(px, n, w, h, 3)
+        t32, _ = ctx.luma_tiles_uniform(px, n, w, h, 3, want98=False)
+        for j in range(n):
+            ep, ed, e32, _, _ = O.hash_image(px[j], want_tiles=True)
+            assert np.array_equal(t32[j], e32), (w, h, j, "tile32")
+            assert (int(got_p[j]), int(got_d[j])) == (ep, ed), (w, h, j)
+
+
 def test_extreme_pixels_fused(ctx):
     """Saturated inputs exercise the clip after each pass and the signed-byte bias."""
     rng = np.random.default_rng(0)

@@ -94,9 +94,9 @@ static void free_coeff_cache(ke_ctx *ctx) {
             if (ck.second->d_cxor) (void)hipFree(ck.second->d_cxor);
             delete ck.second;
         }
-        if (c->mx) {
-            if (c->mx->d_frag) (void)hipFree(c->mx->d_frag);
-            delete c->mx;
+        for (auto &mk : c->mx) {
+            if (mk.second->d_frag) (void)hipFree(mk.second->d_frag);
+            delete mk.second;
         }
         delete c;
     }
@@ -147,14 +147,16 @@ const KeChunkTable *ke_get_chunks(ke_ctx *ctx, const KeAxisCoeffs *cc, int cpo, 
 
 const KeMxTable *ke_get_mx(ke_ctx *ctx, const KeAxisCoeffs *cc, int min_ks, bool align64) {
     auto *c = const_cast<KeAxisCoeffs *>(cc);
-    if (c->mx) return c->mx;
+    const int key = min_ks * 2 + (align64 ? 1 : 0);
+    auto it = c->mx.find(key);
+    if (it != c->mx.end()) return it->second;
     auto *t = new KeMxTable();
     ke_build_mx(*c, *t, min_ks, align64);
     if (upload_i32(ctx, t->frag, &t->d_frag)) {
         delete t;
         return nullptr;
     }
-    c->mx = t;
+    c->mx[key] = t;
     return t;
 }
 

@@ -247,9 +247,25 @@ struct KeFusedArgs {
     int ndwcv;      // chunk dwords of the vertical dHash axis
     int hpd;        // pitch of one dHash HT column (bytes, multiple of 8)
     int x_off;      // LDS offset of the exchange buffer of the two half-row waves
+    // band mode (bands > 0): a workgroup turns rows [band * band_rows, +band_rows) of its image into transposed columns and
+    // writes them to the global scratch hs[img][32][hs_hp] (hsd[img][9][hsd_hp] for the dHash axis); ke_vtile finishes
+    int bands, band_rows;
+    uint8_t *hs, *hsd;
+    int hs_hp, hsd_hp;
     uint64_t *dhash;
     uint8_t *tile98_out;
 };
+
+// Band mode of the single-pass kernels: the band's transposed columns (LDS, pitch hp) -> global scratch, whole dwords
+// along y (band starts and pitches are multiples of 4; the scratch rows are padded).
+__device__ __forceinline__ void band_writeout(const uint8_t *HT, int hp, int ncols, int rows, uint8_t *dst, int dst_hp, int tid,
+                                              int nthreads) {
+    const int wpc = (rows + 3) / 4;
+    for (int e = tid; e < ncols * wpc; e += nthreads) {
+        const int col = e / wpc, k = e % wpc;
+        *reinterpret_cast<uint32_t *>(dst + (size_t)col * dst_hp + 4 * k) = *reinterpret_cast<const uint32_t *>(HT + col * hp + 4 * k);
+    }
+}
 
 // K1' (vertical taps out of the transposed horizontal results HT), K2 (DCT corner, mean, bits) and, for the
 // NDWD > 0 instantiations, the dHash vertical taps + K3: the part of the fused kernels behind the row loop.
@@ -395,10 +411,11 @@ __global__ __launch_bounds__(256, 2) void ke_phash_fused_mx(const KeFusedArgs a)
     uint8_t *X = smem + a.x_off;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
-    const int64_t img = blockIdx.x;
-    const uint8_t *src = a.pixels + (a.offsets ? a.offsets[img] : (uint64_t)img * a.stride);
-    const int h = a.h;
-    const uint32_t image_bytes = (uint32_t)h * (uint32_t)QW * QB;
+    const int64_t img = a.bands ? blockIdx.x / a.bands : blockIdx.x;
+    const int y_begin = a.bands ? (int)(blockIdx.x % a.bands) * a.band_rows : 0;
+    const uint8_t *src = a.pixels + (a.offsets ? a.offsets[img] : (uint64_t)img * a.stride) + (size_t)y_begin * QW * QB;
+    const int h = a.bands ? min(a.band_rows, a.h - y_begin) : a.h;          // rows this workgroup turns into columns
+    const uint32_t image_bytes = (uint32_t)(a.h - y_begin) * (uint32_t)QW * QB;   // bytes from src to the end of the image
 
     // this wave's slice of the product: rows 16*mt.., outputs 16*jt..
     const int mt = wv >> 1, jt = wv & 1;
@@ -528,12 +545,24 @@ __global__ __launch_bounds__(256, 2) void ke_phash_fused_mx(const KeFusedArgs a)
         if (!jt) finish_dhash(ntiles - 1);
         __syncthreads();
     }
+    if (a.bands) {
+        band_writeout(HT, a.hp, 32, h, a.hs + (size_t)img * 32 * a.hs_hp + y_begin, a.hs_hp, tid, 256);
+        if (DH) band_writeout(HTd, a.hpd, 9, h, a.hsd + (size_t)img * 9 * a.hsd_hp + y_begin, a.hsd_hp, tid, 256);
+        return;
+    }
     fused_tail<(DH ? 1 : 0)>(a, Lt, HT, HTd, tid, img);
 }
 
+// Band mode of the single-pass kernels (see KeFusedArgs::bands): how a group is cut, and where the columns go.
+struct KeBandPlan {
+    int bands, band_rows;
+    uint8_t *hs, *hsd;
+    int hs_hp, hsd_hp;
+};
+
 template <int W64, int KS, bool DH, bool GEN = false, int C = 3>
 int launch_fused_mx(ke_ctx *ctx, const KeHashGroup &g, const KeAxisCoeffs *ch, const KeAxisCoeffs *cv, uint64_t *d_phash,
-                    uint8_t *d_tile32, uint64_t *d_dhash, uint8_t *d_tile98) {
+                    uint8_t *d_tile32, uint64_t *d_dhash, uint8_t *d_tile98, const KeBandPlan *plan = nullptr) {
     const int W = g.w;
     if (GEN ? (W > 64 * W64 || W <= 64 * (W64 - 1) || W % 4) : W != 64 * W64) return KE_EUNSUPPORTED;
     const KeMxTable *mx = ke_get_mx(ctx, ch, KS);     // at least KS steps per tile (zero-padded)
@@ -546,7 +575,8 @@ int launch_fused_mx(ke_ctx *ctx, const KeHashGroup &g, const KeAxisCoeffs *ch, c
     a.v_packed = cv->d_packed; a.v_start = cv->d_start; a.v_bias = cv->d_bias;
     a.ndwv = cv->ndw;
     a.mx_frag = mx->d_frag; a.mx_base0 = mx->base[0]; a.mx_base1 = mx->base[1];
-    const int rows_padded = ((g.h + kRTM - 1) / kRTM) * kRTM;
+    const int rows_padded = plan ? plan->band_rows : ((g.h + kRTM - 1) / kRTM) * kRTM;
+    if (plan) { a.bands = plan->bands; a.band_rows = plan->band_rows; a.hs = plan->hs; a.hsd = plan->hsd; a.hs_hp = plan->hs_hp; a.hsd_hp = plan->hsd_hp; }
     // one tile buffer: 32 padded rows + the part of the last row's operand window that overhangs the row
     constexpr int KD = (W64 + 1) / 2;
     const int overhang = std::max(0, std::max(std::max(mx->base[0], mx->base[1]) + 64 * KS, DH ? 128 * KD : 0) - W);
@@ -556,10 +586,10 @@ int launch_fused_mx(ke_ctx *ctx, const KeHashGroup &g, const KeAxisCoeffs *ch, c
     a.lp = GEN ? (((W + 15) / 16 + 1) | 1) * 16 : W + 16;
     a.lt_half = (kRTM * a.lp + overhang + 15) & ~15;
     a.lt_bytes = 2 * a.lt_half;
-    a.hp = ((std::max(cv->span, rows_padded) + 7) & ~7) + 8;
+    a.hp = ((std::max(plan ? 0 : cv->span, rows_padded) + 7) & ~7) + 8;
     a.hpd = 8;
     a.phash = d_phash; a.tile32_out = d_tile32;
-    size_t lds = (size_t)a.lt_bytes + (size_t)32 * a.hp;
+    size_t lds = std::max<size_t>((size_t)a.lt_bytes + (size_t)32 * a.hp, 4096);
     if (DH) {
         const KeAxisCoeffs *chd = ke_get_coeffs(ctx, g.w, 9), *cvd = ke_get_coeffs(ctx, g.h, 8);
         if (!chd || !cvd) return ke_fail(ctx, KE_EHIP, "coefficient upload failed");
@@ -571,20 +601,23 @@ int launch_fused_mx(ke_ctx *ctx, const KeHashGroup &g, const KeAxisCoeffs *ch, c
         a.hd_bias = chd->d_bias;
         a.vd_cpacked = tv->d_cpacked; a.vd_cstart = tv->d_cstart; a.vd_bias = cvd->d_bias;
         a.ndwcv = tv->ndwc;
-        a.hpd = ((std::max(tv->cspan, rows_padded) + 7) & ~7) + 8;
+        a.hpd = ((std::max(plan ? 0 : tv->cspan, rows_padded) + 7) & ~7) + 8;
         a.dhash = d_dhash; a.tile98_out = d_tile98;
         lds += (size_t)9 * a.hpd;
         lds = (lds + 15) & ~(size_t)15;
         a.x_off = (int)lds;
         lds += 4096;
     }
-    // up to 80 KB two workgroups share a CU; a tall image (its 32 x H transposed columns) may take most of the 160 KB
-    // and run one per CU, which still beats the banded path (measured 6.0 vs 3.7-4.6 TB/s)
+    // up to 80 KB two workgroups share a CU.  A tall image (its 32 x H transposed columns) would need more and run one
+    // per CU; if cutting it into bands brings the columns back under that line, decline: the caller then runs this
+    // kernel per band (measured 5.4-6.0 TB/s against 3.9-4.9 for one workgroup per CU)
     if (lds > 150 * 1024) return KE_EUNSUPPORTED;
+    if (!plan && lds > 80 * 1024 && lds - (size_t)(32 * (a.hp - 136)) - (DH ? (size_t)(9 * (a.hpd - 136)) : 0) <= 80 * 1024) return KE_EUNSUPPORTED;
     if (lds > 64 * 1024)
         KE_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&ke_phash_fused_mx<W64, KS, DH, GEN, C>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((ke_phash_fused_mx<W64, KS, DH, GEN, C>), dim3((unsigned)g.n), dim3(256), lds, ctx->stream, a);
+    if (g.n * (plan ? plan->bands : 1) > 0x7fffffffLL) return ke_fail(ctx, KE_EUNSUPPORTED, "group too large for one launch");
+    hipLaunchKernelGGL((ke_phash_fused_mx<W64, KS, DH, GEN, C>), dim3((unsigned)(g.n * (plan ? plan->bands : 1))), dim3(256), lds, ctx->stream, a);
     KE_HIP(ctx, hipGetLastError());
     return KE_OK;
 }
@@ -611,11 +644,13 @@ __global__ __launch_bounds__(512, 1) void ke_phash_fused_wide(const KeFusedArgs 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
     const int jt = wv & 1, kh = wv >> 1;
-    const int64_t img = blockIdx.x;
-    const uint8_t *src = a.pixels + (a.offsets ? a.offsets[img] : (uint64_t)img * a.stride);
-    const int h = a.h, QW = a.qw, LP = a.lp;
+    const int64_t img = a.bands ? blockIdx.x / a.bands : blockIdx.x;
+    const int y_begin = a.bands ? (int)(blockIdx.x % a.bands) * a.band_rows : 0;
+    const int QW = a.qw, LP = a.lp;
+    const uint8_t *src = a.pixels + (a.offsets ? a.offsets[img] : (uint64_t)img * a.stride) + (size_t)y_begin * QW * QB;
+    const int h = a.bands ? min(a.band_rows, a.h - y_begin) : a.h;          // rows this workgroup turns into columns
     const int quads_per_tile = kRTW * QW;
-    const uint32_t image_bytes = (uint32_t)h * (uint32_t)QW * QB;
+    const uint32_t image_bytes = (uint32_t)(a.h - y_begin) * (uint32_t)QW * QB;   // bytes from src to the end of the image
 
     ke_v4i bf[KSH][3];
 #pragma unroll
@@ -751,6 +786,11 @@ __global__ __launch_bounds__(512, 1) void ke_phash_fused_wide(const KeFusedArgs 
     if (!kh) finish(ntiles - 1);
     if (DH && !wv) dfinish(ntiles - 1);
     __syncthreads();
+    if (a.bands) {
+        band_writeout(HT, a.hp, 32, h, a.hs + (size_t)img * 32 * a.hs_hp + y_begin, a.hs_hp, tid, 512);
+        if (DH) band_writeout(HTd, a.hpd, 9, h, a.hsd + (size_t)img * 9 * a.hsd_hp + y_begin, a.hsd_hp, tid, 512);
+        return;
+    }
     // the tail is written for 256 threads; the other four waves are done (ended waves leave the barrier count)
     if (tid >= 256) return;
     fused_tail<(DH ? 1 : 0)>(a, Lt, HT, HTd, tid, img);
@@ -758,7 +798,7 @@ __global__ __launch_bounds__(512, 1) void ke_phash_fused_wide(const KeFusedArgs 
 
 template <int KSH, int QPT, bool DH, int KDW, int C = 3>
 int launch_fused_wide(ke_ctx *ctx, const KeHashGroup &g, const KeAxisCoeffs *ch, const KeAxisCoeffs *cv, uint64_t *d_phash,
-                      uint8_t *d_tile32, uint64_t *d_dhash, uint8_t *d_tile98) {
+                      uint8_t *d_tile32, uint64_t *d_dhash, uint8_t *d_tile98, const KeBandPlan *plan = nullptr) {
     const int W = g.w;
     if (W % 4 || kRTW * (W / 4) > 512 * QPT) return KE_EUNSUPPORTED;
     const KeMxTable *mx = ke_get_mx(ctx, ch, 4 * KSH);
@@ -771,14 +811,15 @@ int launch_fused_wide(ke_ctx *ctx, const KeHashGroup &g, const KeAxisCoeffs *ch,
     a.v_packed = cv->d_packed; a.v_start = cv->d_start; a.v_bias = cv->d_bias;
     a.ndwv = cv->ndw;
     a.mx_frag = mx->d_frag; a.mx_base0 = mx->base[0]; a.mx_base1 = mx->base[1];
-    const int rows_padded = ((g.h + kRTW - 1) / kRTW) * kRTW;
+    const int rows_padded = plan ? plan->band_rows : ((g.h + kRTW - 1) / kRTW) * kRTW;
+    if (plan) { a.bands = plan->bands; a.band_rows = plan->band_rows; a.hs = plan->hs; a.hsd = plan->hsd; a.hs_hp = plan->hs_hp; a.hsd_hp = plan->hsd_hp; }
     const int overhang = std::max(0, std::max(std::max(mx->base[0], mx->base[1]) + 64 * 4 * KSH, DH ? 512 * KDW : 0) - W);
     a.qw = W / 4;
     a.qw_inv = (int)(uint32_t)((0x100000000ull + (uint64_t)a.qw - 1) / (uint64_t)a.qw);
     a.lp = (((W + 15) / 16 + 1) | 1) * 16;
     a.lt_half = (kRTW * a.lp + overhang + 15) & ~15;
     a.lt_bytes = 2 * a.lt_half;
-    a.hp = ((std::max(cv->span, rows_padded) + 7) & ~7) + 8;
+    a.hp = ((std::max(plan ? 0 : cv->span, rows_padded) + 7) & ~7) + 8;
     a.hpd = 8;
     a.phash = d_phash; a.tile32_out = d_tile32;
     size_t lds = (size_t)a.lt_bytes + (size_t)32 * a.hp;
@@ -793,7 +834,7 @@ int launch_fused_wide(ke_ctx *ctx, const KeHashGroup &g, const KeAxisCoeffs *ch,
         a.hd_bias = chd->d_bias;
         a.vd_cpacked = tv->d_cpacked; a.vd_cstart = tv->d_cstart; a.vd_bias = cvd->d_bias;
         a.ndwcv = tv->ndwc;
-        a.hpd = ((std::max(tv->cspan, rows_padded) + 7) & ~7) + 8;
+        a.hpd = ((std::max(plan ? 0 : tv->cspan, rows_padded) + 7) & ~7) + 8;
         a.dhash = d_dhash; a.tile98_out = d_tile98;
         lds += (size_t)9 * a.hpd;
     }
@@ -801,10 +842,13 @@ int launch_fused_wide(ke_ctx *ctx, const KeHashGroup &g, const KeAxisCoeffs *ch,
     a.x_off = (int)lds;
     lds += 2 * 2 * 3 * 1024 + (DH ? 2 * 7 * 1024 : 0);
     if (lds > 150 * 1024) return KE_EUNSUPPORTED;     // one workgroup per CU
+    // ... unless bands of rows bring it under 80 KB (two per CU): then the caller runs this kernel per band
+    if (!plan && lds > 80 * 1024 && lds - (size_t)(32 * (a.hp - 136)) - (DH ? (size_t)(9 * (a.hpd - 136)) : 0) <= 80 * 1024) return KE_EUNSUPPORTED;
     if (lds > 64 * 1024)
         KE_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&ke_phash_fused_wide<KSH, QPT, DH, KDW, C>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((ke_phash_fused_wide<KSH, QPT, DH, KDW, C>), dim3((unsigned)g.n), dim3(512), lds, ctx->stream, a);
+    if (g.n * (plan ? plan->bands : 1) > 0x7fffffffLL) return ke_fail(ctx, KE_EUNSUPPORTED, "group too large for one launch");
+    hipLaunchKernelGGL((ke_phash_fused_wide<KSH, QPT, DH, KDW, C>), dim3((unsigned)(g.n * (plan ? plan->bands : 1))), dim3(512), lds, ctx->stream, a);
     KE_HIP(ctx, hipGetLastError());
     return KE_OK;
 }
@@ -1106,7 +1150,7 @@ int resample_banded(ke_ctx *ctx, const KeHashGroup &g, int ow, int oh, uint8_t *
     if (lds > 64 * 1024) return KE_EUNSUPPORTED;
     a.hp = ((std::max(cvt->span, g.h + 4) + 7) & ~7) + 8;
     void *hs;
-    KE_TRY(ke_reserve(ctx, KE_BUF_TMP, (size_t)g.n * ow * a.hp, &hs));
+    KE_TRY(ke_reserve(ctx, KE_BUF_TMP, (size_t)g.n * ow * a.hp + 8192, &hs));     // + slack: ke_vtile_mx reads whole steps
     a.hs = (uint8_t *)hs;
     if ((int64_t)g.n * a.bands > 0x7fffffffLL) return ke_fail(ctx, KE_EUNSUPPORTED, "group too large for one launch");
     // "aligned" = every row starts on a quad boundary of the packed stream (w % 4 == 0), so a
@@ -1128,8 +1172,68 @@ int resample_banded(ke_ctx *ctx, const KeHashGroup &g, int ow, int oh, uint8_t *
     return launch_vtile(ctx, a.hs, a.hp, g.n, ow, oh, cvt, d_tiles);
 }
 
+// Vertical taps of the banded paths on the matrix cores: T[yy][col] = sum_y k[yy][y] * hs[col][y] is the product of the tap
+// matrix (A: 16 outputs x 64 rows per step, the KeMxTable image of the vertical axis) with the transposed columns, which
+// are exactly a B operand as they lie in the scratch (lane = (column, 16 consecutive rows)).  One wave per 16 x 16 block
+// of the output tile, operands straight from global memory / L2, no LDS.  The one-thread-per-output ke_vtile it replaces
+// walked each window serially with its taps fetched from global memory and took as long as the horizontal pass on
+// 4096-row images.
+struct KeVtileMxArgs {
+    const uint8_t *hs;      // [img][ow][hp] signed bytes
+    int hp, ow, oh;
+    const int32_t *frag;    // KeMxTable::frag of the vertical axis
+    int ks, mt, nt;         // steps per output tile, output-row tiles, column tiles
+    int base[8];            // first row of each output-row tile's window (multiples of 16)
+    const int32_t *bias;
+    uint8_t *tiles;         // [img][oh][ow]
+    int64_t items;          // n * mt * nt
+};
+
+__global__ __launch_bounds__(256) void ke_vtile_mx(const KeVtileMxArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= a.items) return;
+    const int per = a.mt * a.nt;
+    const int64_t img = item / per;
+    const int r = (int)(item % per), mt = r / a.nt, nt = r % a.nt;
+    const int col = 16 * nt + (lane & 15);
+    const uint8_t *bp = a.hs + ((size_t)img * a.ow + min(col, a.ow - 1)) * a.hp + a.base[mt] + 16 * (lane >> 4);
+    const ke_v4i *fr = reinterpret_cast<const ke_v4i *>(a.frag) + (size_t)mt * a.ks * 3 * 64 + lane;
+    ke_v4i acc[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) acc[p] = ke_v4i{0, 0, 0, 0};
+    for (int s = 0; s < a.ks; ++s) {
+        ke_v4i bv;
+        __builtin_memcpy(&bv, bp + 64 * s, 16);                      // 8-byte aligned: two dwordx2 or one dwordx4
+#pragma unroll
+        for (int p = 0; p < 3; ++p) acc[p] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fr[(s * 3 + p) * 64], bv, acc[p], 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int yy = 16 * mt + 4 * (lane >> 4) + i;
+        if (yy < a.oh && col < a.ow)
+            a.tiles[((size_t)img * a.oh + yy) * a.ow + col] = (uint8_t)clip8_fixed(combine_planes(acc[0][i], acc[1][i], acc[2][i], a.bias[yy]));
+    }
+}
+
 // vertical taps of the banded paths: hs[img][ow][hp] signed bytes -> (oh x ow) u8 tiles
 int launch_vtile(ke_ctx *ctx, const uint8_t *hs, int hp, int64_t n, int ow, int oh, const KeAxisCoeffs *cvt, uint8_t *d_tiles) {
+    if (oh <= 128 && !getenv("KE_VTILE_VALU")) {
+        const KeMxTable *mx = ke_get_mx(ctx, cvt);
+        if (!mx) return ke_fail(ctx, KE_EHIP, "coefficient upload failed");
+        KeVtileMxArgs m;
+        std::memset(&m, 0, sizeof m);
+        m.hs = hs; m.hp = hp; m.ow = ow; m.oh = oh;
+        m.frag = mx->d_frag; m.ks = mx->ks; m.mt = mx->tiles; m.nt = (ow + 15) / 16;
+        for (int j = 0; j < mx->tiles; ++j) m.base[j] = mx->base[j];
+        m.bias = cvt->d_bias; m.tiles = d_tiles;
+        m.items = n * m.mt * m.nt;
+        const int64_t blocks = (m.items + 3) / 4;
+        if (blocks > 0x7fffffffLL) return ke_fail(ctx, KE_EUNSUPPORTED, "group too large for one launch");
+        hipLaunchKernelGGL(ke_vtile_mx, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, m);
+        KE_HIP(ctx, hipGetLastError());
+        return KE_OK;
+    }
     KeVtileArgs v;
     v.hs = hs; v.hp = hp; v.ow = ow; v.oh = oh;
     v.packed = cvt->d_packed; v.start = cvt->d_start; v.bias = cvt->d_bias; v.ndw = cvt->ndw;
@@ -1341,7 +1445,7 @@ int resample_strips(ke_ctx *ctx, const KeHashGroup &g, uint8_t *d_tiles) {
     a.hb_off = (int)lds; lds += (size_t)32 * a.bp;
     a.hp = ((std::max(cvt->span, g.h + 4) + 7) & ~7) + 8;
     void *hs;
-    KE_TRY(ke_reserve(ctx, KE_BUF_TMP, (size_t)g.n * 32 * a.hp, &hs));
+    KE_TRY(ke_reserve(ctx, KE_BUF_TMP, (size_t)g.n * 32 * a.hp + 8192, &hs));
     a.hs = (uint8_t *)hs;
     if ((int64_t)g.n * a.bands > 0x7fffffffLL) return ke_fail(ctx, KE_EUNSUPPORTED, "group too large for one launch");
     const dim3 grid((unsigned)(g.n * a.bands)), blk(1024);
@@ -1400,6 +1504,149 @@ int resample_generic(ke_ctx *ctx, const KeHashGroup &g, int ow, int oh, uint8_t 
     return KE_OK;
 }
 
+
+// Picks the single-pass kernel for a group (row length, bytes per pixel, one or both hashes) and launches it.
+// plan == NULL: one workgroup per image, hashes (and optional tiles) written directly.  plan != NULL: band mode, the
+// transposed columns go to plan->hs / plan->hsd and the caller finishes with ke_vtile.  *did_d: dHash was covered too.
+// Returns KE_EUNSUPPORTED when no single-pass kernel takes the shape (or its LDS needs exceed the CU).
+int dispatch_single_pass(ke_ctx *ctx, const KeHashGroup &g, bool want_d, uint64_t *d_phash, uint8_t *d_t32, uint64_t *d_dhash,
+                         uint8_t *d_t98, const KeBandPlan *plan, bool *did_d) {
+    *did_d = false;
+    if (!(g.channels == 3 || g.channels == 4) || g.w % 4 || g.w <= 64 || g.w > 2048 || g.h == 32 || g.h < 16 ||
+        (!plan && g.h > 4096) || (int64_t)g.h > (int64_t)g.w * 100 || (uintptr_t)g.pixels % 4 || !(g.offsets || g.stride % 4 == 0) ||
+        (int64_t)g.w * g.h * g.channels >= (1LL << 31))
+        return KE_EUNSUPPORTED;
+    // offsets (ragged groups) are only 4-byte aligned when every image size is; w % 4 == 0 makes it so
+    const KeAxisCoeffs *ch = ke_get_coeffs(ctx, g.w, 32);
+    const KeAxisCoeffs *cv = ke_get_coeffs(ctx, g.h, 32);
+    if (!ch || !cv) return ke_fail(ctx, KE_EHIP, "coefficient upload failed");
+    const bool both = want_d && g.h != 8 && g.channels == 3;
+    int rc = KE_EUNSUPPORTED;
+#define KE_MX(W64, KS, DH, GEN, C) rc = launch_fused_mx<W64, KS, DH, GEN, C>(ctx, g, ch, cv, d_phash, d_t32, DH ? d_dhash : nullptr, DH ? d_t98 : nullptr, plan)
+#define KE_WIDE(KSH, QPT, DH, KDW, C) rc = launch_fused_wide<KSH, QPT, DH, KDW, C>(ctx, g, ch, cv, d_phash, d_t32, DH ? d_dhash : nullptr, DH ? d_t98 : nullptr, plan)
+    // ---- rows up to 768 pixels: 256-thread kernel, 32-row tiles
+    if (g.w <= 768) {
+        if (both && g.w <= 512) {                  // pHash + dHash in one pass over the pixels
+            switch (g.w) {
+                case 256: KE_MX(4, 3, true, false, 3); break;
+                case 384: KE_MX(6, 4, true, false, 3); break;
+                case 512: KE_MX(8, 5, true, false, 3); break;
+                default:
+                    switch ((g.w + 63) / 64) {
+                        case 2: KE_MX(2, 2, true, true, 3); break;
+                        case 3: KE_MX(3, 2, true, true, 3); break;
+                        case 4: KE_MX(4, 3, true, true, 3); break;
+                        case 5: KE_MX(5, 3, true, true, 3); break;
+                        case 6: KE_MX(6, 4, true, true, 3); break;
+                        case 7: KE_MX(7, 5, true, true, 3); break;
+                        case 8: KE_MX(8, 5, true, true, 3); break;
+                        default: break;
+                    }
+            }
+            if (rc == KE_OK) { *did_d = true; return KE_OK; }
+            if (rc != KE_EUNSUPPORTED) return rc;
+        }
+        // both hashes of RGB rows of 516..768 pixels: the wide-row kernel below has a dHash leg for them, this one does not
+        if (g.channels == 3 && !(both && g.w > 512)) {
+            switch (g.w) {          // widths with their own instantiation: compile-time row length
+                case 256: KE_MX(4, 3, false, false, 3); break;
+                case 384: KE_MX(6, 4, false, false, 3); break;
+                case 512: KE_MX(8, 5, false, false, 3); break;
+                case 640: KE_MX(10, 6, false, false, 3); break;
+                case 768: KE_MX(12, 7, false, false, 3); break;
+                default:
+                    switch ((g.w + 63) / 64) {   // any other multiple of 4: run-time row length, operand steps of the bucket
+                        case 2: KE_MX(2, 2, false, true, 3); break;
+                        case 3: KE_MX(3, 2, false, true, 3); break;
+                        case 4: KE_MX(4, 3, false, true, 3); break;
+                        case 5: KE_MX(5, 3, false, true, 3); break;
+                        case 6: KE_MX(6, 4, false, true, 3); break;
+                        case 7: KE_MX(7, 5, false, true, 3); break;
+                        case 8: KE_MX(8, 5, false, true, 3); break;
+                        case 9: KE_MX(9, 6, false, true, 3); break;
+                        case 10: KE_MX(10, 6, false, true, 3); break;
+                        case 11: KE_MX(11, 7, false, true, 3); break;
+                        default: break;          // 708..764: 8 operand steps do not fit the register file beside the pixel loads
+                    }
+            }
+            if (rc != KE_EUNSUPPORTED) return rc;
+        }
+        if (g.channels == 4 && g.w <= 640) {       // RGBX / RGBA rows: run-time row length per 64-pixel bucket
+            switch ((g.w + 63) / 64) {
+                case 2: KE_MX(2, 2, false, true, 4); break;
+                case 3: KE_MX(3, 2, false, true, 4); break;
+                case 4: KE_MX(4, 3, false, true, 4); break;
+                case 5: KE_MX(5, 3, false, true, 4); break;
+                case 6: KE_MX(6, 4, false, true, 4); break;
+                case 7: KE_MX(7, 5, false, true, 4); break;
+                case 8: KE_MX(8, 5, false, true, 4); break;
+                case 9: KE_MX(9, 6, false, true, 4); break;
+                case 10: KE_MX(10, 6, false, true, 4); break;
+                default: break;
+            }
+            if (rc != KE_EUNSUPPORTED) return rc;
+        }
+    }
+    // ---- wide rows (and what the kernel above left): 512-thread kernel, 16-row tiles
+    if (g.w > (g.channels == 4 ? 640 : both ? 512 : 704) || (g.channels == 3 && g.w > 704)) {
+        if (both) {                                // both hashes in one pass
+            if (g.w <= 1024) KE_WIDE(3, 8, true, 2, 3);
+            else if (g.w <= 1536) KE_WIDE(4, 12, true, 3, 3);
+            else KE_WIDE(5, 16, true, 4, 3);
+            if (rc == KE_OK) { *did_d = true; return KE_OK; }
+            if (rc != KE_EUNSUPPORTED) return rc;
+        }
+        if (g.channels == 4) {
+            if (g.w <= 1024) KE_WIDE(3, 8, false, 1, 4);
+            else if (g.w <= 1536) KE_WIDE(4, 12, false, 1, 4);
+            else KE_WIDE(5, 16, false, 1, 4);
+        } else {
+            if (g.w <= 1024) KE_WIDE(3, 8, false, 1, 3);
+            else if (g.w <= 1536) KE_WIDE(4, 12, false, 1, 3);
+            else KE_WIDE(5, 16, false, 1, 3);
+        }
+        if (rc != KE_EUNSUPPORTED) return rc;
+    }
+#undef KE_MX
+#undef KE_WIDE
+    // rows of 516..768 with both hashes wanted that the wide kernel could not take (LDS): pHash alone from the narrow one
+    if (both && g.w > 512 && g.w <= 768) return dispatch_single_pass(ctx, g, false, d_phash, d_t32, nullptr, nullptr, plan, did_d);
+    return KE_EUNSUPPORTED;
+}
+
+// The single-pass kernels per band of rows: for images whose transposed columns do not fit LDS, and for groups too
+// small to fill the GPU with one workgroup per image.  Tiles come out of ke_vtile as for every banded image.
+int resample_single_pass_banded(ke_ctx *ctx, const KeHashGroup &g, uint8_t *d_t32, uint8_t *d_t98, bool *did_d) {
+    *did_d = false;
+    if ((int64_t)g.h > (int64_t)g.w * 100 || g.h < 16) return KE_EUNSUPPORTED;
+    const KeAxisCoeffs *cvt = ke_get_coeffs(ctx, g.h, 32);
+    const KeAxisCoeffs *cvd = d_t98 ? ke_get_coeffs(ctx, g.h, 8) : nullptr;
+    if (!cvt || (d_t98 && !cvd)) return ke_fail(ctx, KE_EHIP, "coefficient upload failed");
+    KeBandPlan plan;
+    // bands: at most 1024 rows (32 KB of columns in LDS), and enough of them that the launch has ~4 workgroups per CU
+    const int64_t fill = (4 * (int64_t)ctx->cu_count + g.n - 1) / g.n;
+    // ... and short enough that two workgroups share a CU (80 KB each) where the kernel's fixed LDS allows it
+    const bool both = d_t98 != nullptr && g.channels == 3;
+    const int64_t fixed = (g.w <= 768 && !(both && g.w > 512)) ? 64 * (int64_t)(g.w + 32) + (both ? 4096 : 0)
+                                                               : 32 * (int64_t)(g.w + 32) + 12288 + (both ? 14336 : 0);
+    int64_t max_rows = (80 * 1024 - fixed) / (both ? 41 : 32) / 32 * 32 - 32;
+    if (max_rows < 128) max_rows = 1024;
+    max_rows = std::min<int64_t>(max_rows, 1024);
+    int64_t bands = std::max<int64_t>((g.h + max_rows - 1) / max_rows, std::min<int64_t>(fill, (g.h + 63) / 64));
+    plan.band_rows = (int)(((g.h + bands - 1) / bands + 31) / 32 * 32);
+    plan.bands = (g.h + plan.band_rows - 1) / plan.band_rows;
+    plan.hs_hp = ((std::max(cvt->span, g.h + 4) + 7) & ~7) + 8;
+    plan.hsd_hp = cvd ? ((std::max(cvd->span, g.h + 4) + 7) & ~7) + 8 : 8;
+    void *hs;
+    KE_TRY(ke_reserve(ctx, KE_BUF_TMP, (size_t)g.n * (32 * (size_t)plan.hs_hp + (cvd ? 9 * (size_t)plan.hsd_hp : 0)) + 8192, &hs));
+    plan.hs = (uint8_t *)hs;
+    plan.hsd = cvd ? plan.hs + (size_t)g.n * 32 * plan.hs_hp : nullptr;
+    KE_TRY(dispatch_single_pass(ctx, g, d_t98 != nullptr, nullptr, nullptr, nullptr, nullptr, &plan, did_d));
+    KE_TRY(launch_vtile(ctx, plan.hs, plan.hs_hp, g.n, 32, 32, cvt, d_t32));
+    if (*did_d) KE_TRY(launch_vtile(ctx, plan.hsd, plan.hsd_hp, g.n, 9, 8, cvd, d_t98));
+    return KE_OK;
+}
+
 }  // namespace
 
 int ke_launch_hash_group(ke_ctx *ctx, const KeHashGroup &g, uint64_t *d_phash, uint64_t *d_dhash, uint8_t *d_tile32_out,
@@ -1408,109 +1655,18 @@ int ke_launch_hash_group(ke_ctx *ctx, const KeHashGroup &g, uint64_t *d_phash, u
     const bool want_p = d_phash || d_tile32_out, want_d = d_dhash || d_tile98_out;
     bool p_done = false, d_done = false;
     // The single-pass kernels give one workgroup a whole image, so a small group of large images cannot fill the chip
-    // with them; it takes the banded path, which cuts every image into bands (a single image is spread over the whole
-    // GPU).  Measured crossover on MI355X: about 100 images at 512x512, 130-250 at 1024^2 and 2048^2, none below
-    // ~400 KB per image.  KE_FUSED_MIN_IMAGES overrides the threshold (tests set it to 1 to reach these kernels
+    // that way; such a group runs the same kernels per band of rows (a single image is spread over the whole GPU).
+    // Measured crossover on MI355X: about 100 images at 512x512, 130-250 at 1024^2 and 2048^2, none below ~400 KB per
+    // image.  KE_FUSED_MIN_IMAGES overrides the threshold (tests set it to 1 to reach the one-workgroup-per-image form
     // with a few images).
     const int64_t image_bytes = (int64_t)g.w * g.h * g.channels;
     int64_t fused_min = image_bytes < 400 * 1024 ? 1 : std::min<int64_t>(192, image_bytes / 8192);
     if (const char *e = getenv("KE_FUSED_MIN_IMAGES")) fused_min = atoll(e);
-    const bool fused_ok = g.n >= fused_min;
-    // ---- fused fast path: packed RGB, rows of a multiple of 4 pixels up to 768, both axes resampled
-    if (fused_ok && want_p && (g.channels == 3 || g.channels == 4) && g.w % 4 == 0 && g.w > 64 && g.w <= 768 && g.h != 32 && g.h >= 16 && g.h <= 4096 &&
-        !((int64_t)g.h > (int64_t)g.w * 100) && ((uintptr_t)g.pixels % 4 == 0) && (g.offsets || g.stride % 4 == 0)) {
-        const KeAxisCoeffs *ch = ke_get_coeffs(ctx, g.w, 32);
-        const KeAxisCoeffs *cv = ke_get_coeffs(ctx, g.h, 32);
-        if (!ch || !cv) return ke_fail(ctx, KE_EHIP, "coefficient upload failed");
-        int rc = KE_EUNSUPPORTED;
-        // offsets (ragged groups) are only 4-byte aligned when every image size is; w % 4 == 0 makes it so
-        if (want_d && g.h != 8 && g.channels == 3) {   // pHash + dHash in one pass over the pixels (rows up to 512)
-#define KE_GEND(B, K) case B: rc = launch_fused_mx<B, K, true, true>(ctx, g, ch, cv, d_phash, d_tile32_out, d_dhash, d_tile98_out); break
-            switch (g.w) {
-                case 256: rc = launch_fused_mx<4, 3, true>(ctx, g, ch, cv, d_phash, d_tile32_out, d_dhash, d_tile98_out); break;
-                case 384: rc = launch_fused_mx<6, 4, true>(ctx, g, ch, cv, d_phash, d_tile32_out, d_dhash, d_tile98_out); break;
-                case 512: rc = launch_fused_mx<8, 5, true>(ctx, g, ch, cv, d_phash, d_tile32_out, d_dhash, d_tile98_out); break;
-                default:
-                    switch ((g.w + 63) / 64) {
-                        KE_GEND(2, 2); KE_GEND(3, 2); KE_GEND(4, 3); KE_GEND(5, 3); KE_GEND(6, 4); KE_GEND(7, 5); KE_GEND(8, 5);
-                        default: break;
-                    }
-            }
-#undef KE_GEND
-            if (rc == KE_OK) p_done = d_done = true;
-            else if (rc != KE_EUNSUPPORTED) return rc;
-        }
-        // both hashes of RGB rows of 516..768 pixels: the wide-row kernel below has a dHash leg for them, this one does not
-        const bool wide_both = want_d && g.h != 8 && g.channels == 3 && g.w > 512;
-        if (!p_done && g.channels == 3 && !wide_both) {   // pHash alone (or the image is too tall for both column sets to fit in LDS)
-            rc = KE_EUNSUPPORTED;
-            switch (g.w) {          // widths with their own instantiation: compile-time row length
-                case 256: rc = launch_fused_mx<4, 3, false>(ctx, g, ch, cv, d_phash, d_tile32_out, nullptr, nullptr); break;
-                case 384: rc = launch_fused_mx<6, 4, false>(ctx, g, ch, cv, d_phash, d_tile32_out, nullptr, nullptr); break;
-                case 512: rc = launch_fused_mx<8, 5, false>(ctx, g, ch, cv, d_phash, d_tile32_out, nullptr, nullptr); break;
-                case 640: rc = launch_fused_mx<10, 6, false>(ctx, g, ch, cv, d_phash, d_tile32_out, nullptr, nullptr); break;
-                case 768: rc = launch_fused_mx<12, 7, false>(ctx, g, ch, cv, d_phash, d_tile32_out, nullptr, nullptr); break;
-                default:
-                    switch ((g.w + 63) / 64) {   // any other multiple of 4: run-time row length, operand steps of the bucket
-                        case 2: rc = launch_fused_mx<2, 2, false, true>(ctx, g, ch, cv, d_phash, d_tile32_out, nullptr, nullptr); break;
-                        case 3: rc = launch_fused_mx<3, 2, false, true>(ctx, g, ch, cv, d_phash, d_tile32_out, nullptr, nullptr); break;
-                        case 4: rc = launch_fused_mx<4, 3, false, true>(ctx, g, ch, cv, d_phash, d_tile32_out, nullptr, nullptr); break;
-                        case 5: rc = launch_fused_mx<5, 3, false, true>(ctx, g, ch, cv, d_phash, d_tile32_out, nullptr, nullptr); break;
-                        case 6: rc = launch_fused_mx<6, 4, false, true>(ctx, g, ch, cv, d_phash, d_tile32_out, nullptr, nullptr); break;
-                        case 7: rc = launch_fused_mx<7, 5, false, true>(ctx, g, ch, cv, d_phash, d_tile32_out, nullptr, nullptr); break;
-                        case 8: rc = launch_fused_mx<8, 5, false, true>(ctx, g, ch, cv, d_phash, d_tile32_out, nullptr, nullptr); break;
-                        case 9: rc = launch_fused_mx<9, 6, false, true>(ctx, g, ch, cv, d_phash, d_tile32_out, nullptr, nullptr); break;
-                        case 10: rc = launch_fused_mx<10, 6, false, true>(ctx, g, ch, cv, d_phash, d_tile32_out, nullptr, nullptr); break;
-                        case 11: rc = launch_fused_mx<11, 7, false, true>(ctx, g, ch, cv, d_phash, d_tile32_out, nullptr, nullptr); break;
-                        default: break;          // 708..764: 8 operand steps do not fit the register file beside the pixel loads
-                    }
-            }
-            if (rc == KE_OK) p_done = true;
-            else if (rc != KE_EUNSUPPORTED) return rc;
-        }
-        if (!p_done && g.channels == 4) {   // RGBX / RGBA rows: run-time row length per 64-pixel bucket
-            rc = KE_EUNSUPPORTED;
-#define KE_GEN4(B, K) case B: rc = launch_fused_mx<B, K, false, true, 4>(ctx, g, ch, cv, d_phash, d_tile32_out, nullptr, nullptr); break
-            switch ((g.w + 63) / 64) {
-                KE_GEN4(2, 2); KE_GEN4(3, 2); KE_GEN4(4, 3); KE_GEN4(5, 3); KE_GEN4(6, 4); KE_GEN4(7, 5); KE_GEN4(8, 5); KE_GEN4(9, 6);
-                KE_GEN4(10, 6);
-                default: break;
-            }
-#undef KE_GEN4
-            if (rc == KE_OK) p_done = true;
-            else if (rc != KE_EUNSUPPORTED) return rc;
-        }
-    }
-    // ---- wide rows: packed RGB, 704 < W <= 2048 (and the 708..764 gap of the kernel above)
-    if (fused_ok && want_p && !p_done && (g.channels == 3 || g.channels == 4) && g.w % 4 == 0 &&
-        g.w > (g.channels == 4 ? 640 : (want_d && g.h != 8) ? 512 : 704) &&
-        g.w <= 2048 && g.h != 32 && g.h >= 16 && g.h <= 4096 &&
-        !((int64_t)g.h > (int64_t)g.w * 100) && ((uintptr_t)g.pixels % 4 == 0) && (g.offsets || g.stride % 4 == 0)) {
-        const KeAxisCoeffs *ch = ke_get_coeffs(ctx, g.w, 32);
-        const KeAxisCoeffs *cv = ke_get_coeffs(ctx, g.h, 32);
-        if (!ch || !cv) return ke_fail(ctx, KE_EHIP, "coefficient upload failed");
-        int rc = KE_EUNSUPPORTED;
-        if (want_d && g.h != 8 && g.channels == 3) {    // both hashes in one pass
-            if (g.w <= 1024) rc = launch_fused_wide<3, 8, true, 2>(ctx, g, ch, cv, d_phash, d_tile32_out, d_dhash, d_tile98_out);
-            else if (g.w <= 1536) rc = launch_fused_wide<4, 12, true, 3>(ctx, g, ch, cv, d_phash, d_tile32_out, d_dhash, d_tile98_out);
-            else rc = launch_fused_wide<5, 16, true, 4>(ctx, g, ch, cv, d_phash, d_tile32_out, d_dhash, d_tile98_out);
-            if (rc == KE_OK) p_done = d_done = true;
-            else if (rc != KE_EUNSUPPORTED) return rc;
-        }
-        if (!p_done && g.channels == 4) {
-            if (g.w <= 1024) rc = launch_fused_wide<3, 8, false, 1, 4>(ctx, g, ch, cv, d_phash, d_tile32_out, nullptr, nullptr);
-            else if (g.w <= 1536) rc = launch_fused_wide<4, 12, false, 1, 4>(ctx, g, ch, cv, d_phash, d_tile32_out, nullptr, nullptr);
-            else rc = launch_fused_wide<5, 16, false, 1, 4>(ctx, g, ch, cv, d_phash, d_tile32_out, nullptr, nullptr);
-            if (rc == KE_OK) p_done = true;
-            else if (rc != KE_EUNSUPPORTED) return rc;
-        }
-        if (!p_done && g.channels == 3) {
-            if (g.w <= 1024) rc = launch_fused_wide<3, 8, false, 1>(ctx, g, ch, cv, d_phash, d_tile32_out, nullptr, nullptr);
-            else if (g.w <= 1536) rc = launch_fused_wide<4, 12, false, 1>(ctx, g, ch, cv, d_phash, d_tile32_out, nullptr, nullptr);
-            else rc = launch_fused_wide<5, 16, false, 1>(ctx, g, ch, cv, d_phash, d_tile32_out, nullptr, nullptr);
-            if (rc == KE_OK) p_done = true;
-            else if (rc != KE_EUNSUPPORTED) return rc;
-        }
+    if (want_p && g.n >= fused_min) {
+        bool did_d = false;
+        const int rc = dispatch_single_pass(ctx, g, want_d, d_phash, d_tile32_out, d_dhash, d_tile98_out, nullptr, &did_d);
+        if (rc == KE_OK) { p_done = true; d_done = did_d; }
+        else if (rc != KE_EUNSUPPORTED) return rc;
     }
     // ---- generic path, chunked so the first-pass scratch stays bounded
     if ((want_p && !p_done) || (want_d && !d_done)) {
@@ -1529,17 +1685,21 @@ int ke_launch_hash_group(ke_ctx *ctx, const KeHashGroup &g, uint64_t *d_phash, u
             const int64_t slot0 = g.out_idx ? 0 : f;
             if (g.out_idx) s.out_idx = g.out_idx + f;
             void *t32 = nullptr, *t98 = nullptr;
+            bool d_here = false;
+            if (want_d && !d_done) {
+                if (d_tile98_out) t98 = d_tile98_out + (size_t)f * 72;
+                else KE_TRY(ke_reserve(ctx, KE_BUF_TILE98, (size_t)s.n * 72, &t98));
+            }
             if (want_p && !p_done) {
                 if (d_tile32_out) t32 = d_tile32_out + (size_t)f * 1024;
                 else KE_TRY(ke_reserve(ctx, KE_BUF_TILE32, (size_t)s.n * 1024, &t32));
-                int rb = resample_strips(ctx, s, (uint8_t *)t32);
+                int rb = resample_single_pass_banded(ctx, s, (uint8_t *)t32, (uint8_t *)t98, &d_here);
+                if (rb == KE_EUNSUPPORTED) rb = resample_strips(ctx, s, (uint8_t *)t32);
                 if (rb == KE_EUNSUPPORTED) rb = resample_banded(ctx, s, 32, 32, (uint8_t *)t32);
                 if (rb == KE_EUNSUPPORTED) rb = resample_generic(ctx, s, 32, 32, (uint8_t *)t32);
                 KE_TRY(rb);
             }
-            if (want_d && !d_done) {
-                if (d_tile98_out) t98 = d_tile98_out + (size_t)f * 72;
-                else KE_TRY(ke_reserve(ctx, KE_BUF_TILE98, (size_t)s.n * 72, &t98));
+            if (want_d && !d_done && !d_here) {
                 int rb = resample_banded(ctx, s, 9, 8, (uint8_t *)t98);
                 if (rb == KE_EUNSUPPORTED) rb = resample_generic(ctx, s, 9, 8, (uint8_t *)t98);
                 KE_TRY(rb);

@@ -38,8 +38,8 @@ struct KeAxisCoeffs {
     int32_t *d_bounds = nullptr, *d_kk = nullptr, *d_start = nullptr, *d_bias = nullptr, *d_packed = nullptr;
     // chunked byte-plane layouts, by chunks-per-output (see KeChunkTable)
     std::map<int, struct KeChunkTable *> chunked;
-    // matrix-core operand layout of the same byte planes (see KeMxTable), built on first use
-    struct KeMxTable *mx = nullptr;
+    // matrix-core operand layouts of the same byte planes (see KeMxTable), built on first use, by (min_ks, align64)
+    std::map<int, struct KeMxTable *> mx;
 };
 
 // The tap matrix as B operands of v_mfma_i32_16x16x64_i8: the resample of one axis is the banded product

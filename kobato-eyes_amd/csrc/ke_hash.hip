@@ -1656,11 +1656,11 @@ int ke_launch_hash_group(ke_ctx *ctx, const KeHashGroup &g, uint64_t *d_phash, u
     bool p_done = false, d_done = false;
     // The single-pass kernels give one workgroup a whole image, so a small group of large images cannot fill the chip
     // that way; such a group runs the same kernels per band of rows (a single image is spread over the whole GPU).
-    // Measured crossover on MI355X: about 100 images at 512x512, 130-250 at 1024^2 and 2048^2, none below ~400 KB per
+    // Measured crossover on MI355X: about 200 images at 512x512 and 1024^2, 500-700 at 2048^2, none below ~400 KB per
     // image.  KE_FUSED_MIN_IMAGES overrides the threshold (tests set it to 1 to reach the one-workgroup-per-image form
     // with a few images).
     const int64_t image_bytes = (int64_t)g.w * g.h * g.channels;
-    int64_t fused_min = image_bytes < 400 * 1024 ? 1 : std::min<int64_t>(192, image_bytes / 8192);
+    int64_t fused_min = image_bytes < 400 * 1024 ? 1 : image_bytes < (8 << 20) ? 192 : 512;
     if (const char *e = getenv("KE_FUSED_MIN_IMAGES")) fused_min = atoll(e);
     if (want_p && g.n >= fused_min) {
         bool did_d = false;

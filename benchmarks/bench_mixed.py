@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """BASELINE configs[4] in a sample that fits one GPU: N mixed-resolution images (independent width/height from
-{256..4096}, weights 1/side), device resident, hashed through ke_hash_images (grouped by shape: fused kernel for
-256/384/512-wide groups, banded path for the rest).  One JSON line."""
+{256..4096}, weights 1/side), device resident, hashed through ke_hash_images (grouped by shape: single-pass kernels up
+to 2048 pixels wide -- per band of rows for tall images -- and the strip kernel beyond).  One JSON line."""
 from __future__ import annotations
 
 import argparse

@@ -1266,6 +1266,7 @@ struct KeStripArgs {
     const int32_t *mx_frag; // KeMxTable::frag, 8 * KSH steps per tile, bases multiples of 64
     int base0, base1;
     const int32_t *bias;
+    int ncols;              // output columns of the axis: 32 (pHash) or 9 (dHash)
     int bp;                 // pitch of one output column of the band staging area (bytes, multiple of 4)
     int x_off, hb_off;      // LDS offsets of the exchange slots and of the staging area
     uint8_t *hs;            // [img][32][hp]
@@ -1277,8 +1278,11 @@ constexpr int kSLP = kSW + 16;            // LDS pitch of a strip row (129 x 16 
 
 // The strip geometry is compile-time on purpose: a run-time strip width (equal strips, no nearly empty last one)
 // costs row/column registers per load slot, spills at 1024 threads x 128 registers and ran 25 % slower.
-template <int KSH>
+// NT: 16-output tiles of the axis (2: the 32 pHash columns, 1: the 9 dHash columns); the 16 waves split into NT groups
+// of PARTS = 16 / NT, one part of a tile's operand steps each.
+template <int KSH, int NT>
 __global__ __launch_bounds__(1024) void ke_hstrips(const KeStripArgs a) {
+    constexpr int PARTS = 16 / NT;
     constexpr int QPT = 16 * (kSW / 4) / 1024;     // 8 quads per thread per strip
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *Lt = smem;
@@ -1286,7 +1290,7 @@ __global__ __launch_bounds__(1024) void ke_hstrips(const KeStripArgs a) {
     uint8_t *HB = smem + a.hb_off;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int jt = wv & 1, kh = wv >> 1;
+    const int jt = NT == 2 ? (wv & 1) : 0, kh = NT == 2 ? (wv >> 1) : wv;
     const int64_t img = blockIdx.x / a.bands;
     const int band = blockIdx.x % a.bands;
     const uint8_t *src = a.pixels + (a.offsets ? a.offsets[img] : (uint64_t)img * a.stride);
@@ -1300,12 +1304,13 @@ __global__ __launch_bounds__(1024) void ke_hstrips(const KeStripArgs a) {
     for (int i = 0; i < KSH; ++i)
 #pragma unroll
         for (int p = 0; p < 3; ++p)
-            bf[i][p] = reinterpret_cast<const ke_v4i *>(a.mx_frag)[((jt * 8 * KSH + kh * KSH + i) * 3 + p) * 64 + lane];
+            bf[i][p] = reinterpret_cast<const ke_v4i *>(a.mx_frag)[((jt * PARTS * KSH + kh * KSH + i) * 3 + p) * 64 + lane];
     const int x_first = (jt ? a.base1 : a.base0) + 64 * KSH * kh;     // first tap column of this wave's steps (wave-uniform)
     const int ocol = 16 * jt + (lane & 15);
-    const int obias = a.bias[ocol];
+    const int obias = a.bias[min(ocol, a.ncols - 1)];
     const int a_row = (lane & 15) * kSLP + 16 * (lane >> 4);
-    ke_v4i *x_slot = X + jt * 448 + lane;                       // + 64 per eighth, + 896 for odd tiles
+    constexpr int XPAR = NT * (PARTS - 1) * 64;                  // slots of one tile parity
+    ke_v4i *x_slot = X + jt * (PARTS - 1) * 64 + lane;           // + 64 per part, + XPAR for odd tiles
     uint8_t *hb_dst = HB + (size_t)ocol * a.bp + 4 * (lane >> 4);
 
     // pixel quads of a strip: item = q*1024 + tid -> (row = item / 512, quad = item % 512)
@@ -1337,14 +1342,14 @@ __global__ __launch_bounds__(1024) void ke_hstrips(const KeStripArgs a) {
 #pragma unroll
     for (int p = 0; p < 3; ++p) acc[p] = ke_v4i{0, 0, 0, 0};
     auto finish = [&](int t) {                     // kh = 0 waves: tile t's column bytes from the eight parts
-        const ke_v4i *xs = x_slot + (t & 1) * 896;
+        const ke_v4i *xs = x_slot + (t & 1) * XPAR;
         ke_v4i sum = carry;
-#pragma unroll
-        for (int k = 0; k < 7; ++k) sum += xs[64 * k];
+#pragma nounroll
+        for (int k = 0; k < PARTS - 1; ++k) sum += xs[64 * k];     // not unrolled: 15 slots in flight would spill
         uint32_t packed = 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) packed |= (uint32_t)clip8_fixed((int)((uint32_t)sum[i] + (uint32_t)obias)) << (8 * i);
-        *reinterpret_cast<uint32_t *>(hb_dst + 16 * t) = packed ^ 0x80808080u;
+        if (ocol < a.ncols) *reinterpret_cast<uint32_t *>(hb_dst + 16 * t) = packed ^ 0x80808080u;
     };
     auto compute = [&](int it, const uint8_t *cur) {
         const int t = it / S, s = it - t * S;
@@ -1365,7 +1370,7 @@ __global__ __launch_bounds__(1024) void ke_hstrips(const KeStripArgs a) {
 #pragma unroll
             for (int p = 0; p < 3; ++p) acc[p] = ke_v4i{0, 0, 0, 0};
             if (kh) {
-                x_slot[(t & 1) * 896 + (kh - 1) * 64] = part;
+                x_slot[(t & 1) * XPAR + (kh - 1) * 64] = part;
             } else {
                 if (t > 0) finish(t - 1);
                 carry = part;
@@ -1391,8 +1396,8 @@ __global__ __launch_bounds__(1024) void ke_hstrips(const KeStripArgs a) {
     // write the band out: whole dwords along y (y_begin and bp are multiples of 4; hs rows are padded)
     {
         const int wpc = (y_end - y_begin + 3) / 4;
-        uint8_t *dst = a.hs + (size_t)img * 32 * a.hp + y_begin;
-        for (int e = tid; e < 32 * wpc; e += 1024) {
+        uint8_t *dst = a.hs + (size_t)img * a.ncols * a.hp + y_begin;
+        for (int e = tid; e < a.ncols * wpc; e += 1024) {
             const int col = e / wpc, k = e % wpc;
             *reinterpret_cast<uint32_t *>(dst + (size_t)col * a.hp + 4 * k) = *reinterpret_cast<const uint32_t *>(HB + col * a.bp + 4 * k);
         }
@@ -1401,25 +1406,27 @@ __global__ __launch_bounds__(1024) void ke_hstrips(const KeStripArgs a) {
 
 int launch_vtile(ke_ctx *ctx, const uint8_t *hs, int hp, int64_t n, int ow, int oh, const KeAxisCoeffs *cvt, uint8_t *d_tiles);
 
-// pHash tile (32 x 32) of packed RGB images 2052..5300 pixels wide, large groups only
-int resample_strips(ke_ctx *ctx, const KeHashGroup &g, uint8_t *d_tiles) {
-    if (g.channels != 3 || g.w % 4 || g.w <= 2048 || (int64_t)g.h > (int64_t)g.w * 100) return KE_EUNSUPPORTED;
+// (32 x 32) or (8 x 9) tile of packed RGB images 2816..5300 pixels wide, large groups only
+int resample_strips(ke_ctx *ctx, const KeHashGroup &g, int ow, int oh, uint8_t *d_tiles) {
+    if (!((ow == 32 && oh == 32) || (ow == 9 && oh == 8))) return KE_EUNSUPPORTED;
+    if (g.channels != 3 || g.w % 4 || g.w <= 2048 || (int64_t)g.h > (int64_t)g.w * 100 || g.h == oh) return KE_EUNSUPPORTED;
     if ((int64_t)g.w * g.h * 3 >= (1LL << 31) || (uintptr_t)g.pixels % 4 || !(g.offsets || g.stride % 4 == 0)) return KE_EUNSUPPORTED;
-    const KeAxisCoeffs *chz = ke_get_coeffs(ctx, g.w, 32);
-    const KeAxisCoeffs *cvt = ke_get_coeffs(ctx, g.h, 32);
+    const KeAxisCoeffs *chz = ke_get_coeffs(ctx, g.w, ow);
+    const KeAxisCoeffs *cvt = ke_get_coeffs(ctx, g.h, oh);
     if (!chz || !cvt) return ke_fail(ctx, KE_EHIP, "coefficient upload failed");
+    const int nt = (ow + 15) / 16, parts = 16 / nt;
     // natural step count with 64-aligned bases decides the instantiation
     int ks = 0;
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < nt; ++j) {
         int lo = g.w, hi = 0;
-        for (int o = 16 * j; o < 16 * j + 16; ++o) { lo = std::min(lo, chz->bounds[2 * o]); hi = std::max(hi, chz->bounds[2 * o] + chz->bounds[2 * o + 1]); }
+        for (int o = 16 * j; o < std::min(16 * j + 16, ow); ++o) { lo = std::min(lo, chz->bounds[2 * o]); hi = std::max(hi, chz->bounds[2 * o] + chz->bounds[2 * o + 1]); }
         ks = std::max(ks, (hi - (lo & ~63) + 63) / 64);
     }
-    const int ksh = (ks + 7) / 8;
+    const int ksh = std::max((ks + parts - 1) / parts, 3);
     if (ksh > 6) return KE_EUNSUPPORTED;
-    const KeMxTable *mx = ke_get_mx(ctx, chz, 8 * std::max(ksh, 3), true);
+    const KeMxTable *mx = ke_get_mx(ctx, chz, parts * ksh, true);
     if (!mx) return ke_fail(ctx, KE_EHIP, "coefficient upload failed");
-    if (mx->tiles != 2 || mx->ks != 8 * std::max(ksh, 3) || mx->base[0] % 64 || mx->base[1] % 64) return KE_EUNSUPPORTED;
+    if (mx->tiles != nt || mx->ks != parts * ksh || mx->base[0] % 64 || (nt == 2 && mx->base[1] % 64)) return KE_EUNSUPPORTED;
     KeStripArgs a;
     std::memset(&a, 0, sizeof a);
     a.pixels = g.pixels; a.offsets = g.offsets; a.stride = g.stride; a.w = g.w; a.h = g.h;
@@ -1437,30 +1444,30 @@ int resample_strips(ke_ctx *ctx, const KeHashGroup &g, uint8_t *d_tiles) {
     } else if (g.n * a.bands < 2 * (int64_t)ctx->cu_count) {
         return KE_EUNSUPPORTED;
     }
-    a.mx_frag = mx->d_frag; a.base0 = mx->base[0]; a.base1 = mx->base[1];
+    a.mx_frag = mx->d_frag; a.base0 = mx->base[0]; a.base1 = nt == 2 ? mx->base[1] : 0;
     a.bias = chz->d_bias;
+    a.ncols = ow;
     a.bp = a.band_rows + 4;
     size_t lds = 2 * (size_t)16 * kSLP;
-    a.x_off = (int)lds; lds += 2 * 2 * 7 * 1024;
-    a.hb_off = (int)lds; lds += (size_t)32 * a.bp;
+    a.x_off = (int)lds; lds += (size_t)2 * nt * (parts - 1) * 1024;
+    a.hb_off = (int)lds; lds += (size_t)ow * a.bp;
     a.hp = ((std::max(cvt->span, g.h + 4) + 7) & ~7) + 8;
     void *hs;
-    KE_TRY(ke_reserve(ctx, KE_BUF_TMP, (size_t)g.n * 32 * a.hp + 8192, &hs));
+    KE_TRY(ke_reserve(ctx, KE_BUF_TMP, (size_t)g.n * ow * a.hp + 8192, &hs));
     a.hs = (uint8_t *)hs;
     if ((int64_t)g.n * a.bands > 0x7fffffffLL) return ke_fail(ctx, KE_EUNSUPPORTED, "group too large for one launch");
     const dim3 grid((unsigned)(g.n * a.bands)), blk(1024);
-#define KE_STRIPS(K) do { \
-        KE_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&ke_hstrips<K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL(ke_hstrips<K>, grid, blk, lds, ctx->stream, a); } while (0)
-    switch (std::max(ksh, 3)) {
-        case 3: KE_STRIPS(3); break;
-        case 4: KE_STRIPS(4); break;
-        case 5: KE_STRIPS(5); break;
-        default: KE_STRIPS(6); break;
+#define KE_STRIPS(K, T) do { \
+        KE_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&ke_hstrips<K, T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((ke_hstrips<K, T>), grid, blk, lds, ctx->stream, a); } while (0)
+    if (nt == 2) {
+        switch (ksh) { case 3: KE_STRIPS(3, 2); break; case 4: KE_STRIPS(4, 2); break; case 5: KE_STRIPS(5, 2); break; default: KE_STRIPS(6, 2); break; }
+    } else {
+        switch (ksh) { case 3: KE_STRIPS(3, 1); break; case 4: KE_STRIPS(4, 1); break; case 5: KE_STRIPS(5, 1); break; default: KE_STRIPS(6, 1); break; }
     }
 #undef KE_STRIPS
     KE_HIP(ctx, hipGetLastError());
-    return launch_vtile(ctx, a.hs, a.hp, g.n, 32, 32, cvt, d_tiles);
+    return launch_vtile(ctx, a.hs, a.hp, g.n, ow, oh, cvt, d_tiles);
 }
 
 // Generic target: src images -> (oh x ow) u8 tiles, two single-axis passes in Pillow's order.
@@ -1694,13 +1701,14 @@ int ke_launch_hash_group(ke_ctx *ctx, const KeHashGroup &g, uint64_t *d_phash, u
                 if (d_tile32_out) t32 = d_tile32_out + (size_t)f * 1024;
                 else KE_TRY(ke_reserve(ctx, KE_BUF_TILE32, (size_t)s.n * 1024, &t32));
                 int rb = resample_single_pass_banded(ctx, s, (uint8_t *)t32, (uint8_t *)t98, &d_here);
-                if (rb == KE_EUNSUPPORTED) rb = resample_strips(ctx, s, (uint8_t *)t32);
+                if (rb == KE_EUNSUPPORTED) rb = resample_strips(ctx, s, 32, 32, (uint8_t *)t32);
                 if (rb == KE_EUNSUPPORTED) rb = resample_banded(ctx, s, 32, 32, (uint8_t *)t32);
                 if (rb == KE_EUNSUPPORTED) rb = resample_generic(ctx, s, 32, 32, (uint8_t *)t32);
                 KE_TRY(rb);
             }
             if (want_d && !d_done && !d_here) {
-                int rb = resample_banded(ctx, s, 9, 8, (uint8_t *)t98);
+                int rb = resample_strips(ctx, s, 9, 8, (uint8_t *)t98);
+                if (rb == KE_EUNSUPPORTED) rb = resample_banded(ctx, s, 9, 8, (uint8_t *)t98);
                 if (rb == KE_EUNSUPPORTED) rb = resample_generic(ctx, s, 9, 8, (uint8_t *)t98);
                 KE_TRY(rb);
             }

@@ -48,5 +48,22 @@ for k in range(cases):
             print("MISMATCH", dict(w=w, h=h, ch=ch, n=n, both=both, image=j), flush=True)
     if (k + 1) % 50 == 0:
         print(k + 1, "cases,", bad, "mismatches", flush=True)
+# ragged batches: images of many shapes in one ke_hash_images call (offsets, per-shape groups, output scatter)
+for k in range(max(1, cases // 50)):
+    imgs = []
+    for _ in range(int(rng.integers(5, 40))):
+        w = int(rng.choice([rng.integers(1, 300), rng.integers(17, 513) * 4, rng.integers(513, 1100) * 4, 512, 640, 1024]))
+        h = int(rng.choice([rng.integers(1, 64), rng.integers(16, 900), rng.integers(900, 2400)]))
+        if w * h > 3_000_000:
+            h = max(1, 3_000_000 // w)
+        imgs.append(rng.integers(0, 256, (h, w, 3), dtype=np.uint8))
+        if rng.integers(0, 4) == 0:
+            imgs.append(imgs[-1].copy())          # a second image of the same shape: groups of more than one
+    got_p, got_d, st = ctx.hash_images(imgs)
+    for j, im in enumerate(imgs):
+        ep, ed = O.hash_image(im)[:2]
+        if st[j] != 0 or int(got_p[j]) != ep or int(got_d[j]) != ed:
+            bad += 1
+            print("MISMATCH ragged", k, j, im.shape, flush=True)
 print("done:", cases, "cases,", bad, "mismatches")
 sys.exit(1 if bad else 0)

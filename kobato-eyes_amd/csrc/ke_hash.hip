@@ -394,7 +394,7 @@ typedef int ke_v4i __attribute__((ext_vector_type(4)));
 // later (after the tile's barrier).
 // GEN: the row length is a run-time value, any multiple of 4 in (64*(W64-1), 64*W64]; W64 and KS are then upper
 // bounds (operand steps past an output tile's window hold zero taps; what they read of the next row is ignored).
-// C: bytes per pixel, 3 (RGB) or 4 (RGBX/RGBA: the fourth byte is ignored, as convert("L") ignores it).
+// C: bytes per pixel, 3 (RGB), 4 (RGBX/RGBA: the fourth byte is ignored, as convert("L") ignores it) or 1 ("L").
 template <int W64, int KS, bool DH, bool GEN, int C>
 __global__ __launch_bounds__(256, 2) void ke_phash_fused_mx(const KeFusedArgs a) {
     constexpr uint32_t QB = 4u * C;              // bytes of a 4-pixel quad
@@ -1519,7 +1519,7 @@ int resample_generic(ke_ctx *ctx, const KeHashGroup &g, int ow, int oh, uint8_t 
 int dispatch_single_pass(ke_ctx *ctx, const KeHashGroup &g, bool want_d, uint64_t *d_phash, uint8_t *d_t32, uint64_t *d_dhash,
                          uint8_t *d_t98, const KeBandPlan *plan, bool *did_d) {
     *did_d = false;
-    if (!(g.channels == 3 || g.channels == 4) || g.w % 4 || g.w <= 64 || g.w > 2048 || g.h == 32 || g.h < 16 ||
+    if (g.w % 4 || g.w <= 64 || g.w > 2048 || g.h == 32 || g.h < 16 ||
         (!plan && g.h > 4096) || (int64_t)g.h > (int64_t)g.w * 100 || (uintptr_t)g.pixels % 4 || !(g.offsets || g.stride % 4 == 0) ||
         (int64_t)g.w * g.h * g.channels >= (1LL << 31))
         return KE_EUNSUPPORTED;
@@ -1578,6 +1578,23 @@ int dispatch_single_pass(ke_ctx *ctx, const KeHashGroup &g, bool want_d, uint64_
             }
             if (rc != KE_EUNSUPPORTED) return rc;
         }
+        if (g.channels == 1) {                     // 1-byte pixels: the luma step is a sign flip, 4-byte loads
+            switch ((g.w + 63) / 64) {
+                case 2: KE_MX(2, 2, false, true, 1); break;
+                case 3: KE_MX(3, 2, false, true, 1); break;
+                case 4: KE_MX(4, 3, false, true, 1); break;
+                case 5: KE_MX(5, 3, false, true, 1); break;
+                case 6: KE_MX(6, 4, false, true, 1); break;
+                case 7: KE_MX(7, 5, false, true, 1); break;
+                case 8: KE_MX(8, 5, false, true, 1); break;
+                case 9: KE_MX(9, 6, false, true, 1); break;
+                case 10: KE_MX(10, 6, false, true, 1); break;
+                case 11: KE_MX(11, 7, false, true, 1); break;
+                case 12: KE_MX(12, 8, false, true, 1); break;
+                default: break;
+            }
+            if (rc != KE_EUNSUPPORTED) return rc;
+        }
         if (g.channels == 4 && g.w <= 640) {       // RGBX / RGBA rows: run-time row length per 64-pixel bucket
             switch ((g.w + 63) / 64) {
                 case 2: KE_MX(2, 2, false, true, 4); break;
@@ -1595,7 +1612,7 @@ int dispatch_single_pass(ke_ctx *ctx, const KeHashGroup &g, bool want_d, uint64_
         }
     }
     // ---- wide rows (and what the kernel above left): 512-thread kernel, 16-row tiles
-    if (g.w > (g.channels == 4 ? 640 : both ? 512 : 704) || (g.channels == 3 && g.w > 704)) {
+    if (g.w > (g.channels == 4 ? 640 : g.channels == 1 ? 768 : both ? 512 : 704)) {
         if (both) {                                // both hashes in one pass
             if (g.w <= 1024) KE_WIDE(3, 8, true, 2, 3);
             else if (g.w <= 1536) KE_WIDE(4, 12, true, 3, 3);
@@ -1607,6 +1624,10 @@ int dispatch_single_pass(ke_ctx *ctx, const KeHashGroup &g, bool want_d, uint64_
             if (g.w <= 1024) KE_WIDE(3, 8, false, 1, 4);
             else if (g.w <= 1536) KE_WIDE(4, 12, false, 1, 4);
             else KE_WIDE(5, 16, false, 1, 4);
+        } else if (g.channels == 1) {
+            if (g.w <= 1024) KE_WIDE(3, 8, false, 1, 1);
+            else if (g.w <= 1536) KE_WIDE(4, 12, false, 1, 1);
+            else KE_WIDE(5, 16, false, 1, 1);
         } else {
             if (g.w <= 1024) KE_WIDE(3, 8, false, 1, 3);
             else if (g.w <= 1536) KE_WIDE(4, 12, false, 1, 3);

@@ -103,6 +103,10 @@ def test_phash_any_width_up_to_768_matrix_core_path(ctx):
                 _, ed, _, e98, _ = O.hash_image(px[j], want_tiles=True)
                 assert np.array_equal(t98[j], e98), (w, h, j, "tile98")
                 assert int(both_d[j]) == ed, (w, h, j, "dhash")
+        if k % 4 == 1:                                   # 1-byte pixels ("L" images): same kernels, 4-byte loads
+            g1 = np.ascontiguousarray(px[..., 1])
+            got1, _ = ctx.hash_uniform(g1, n, w, h, 1, want_dhash=False)
+            assert [int(v) for v in got1] == [O.hash_image(g1[j])[0] for j in range(n)], (w, h, "gray")
         if w <= 640 and k % 3 == 0:                      # RGBA / RGBX rows: the fourth byte is ignored, as convert("L") does
             px4 = np.concatenate([px, rng.integers(0, 256, (n, h, w, 1), dtype=np.uint8)], axis=3)
             got4, _ = ctx.hash_uniform(px4, n, w, h, 4, want_dhash=False)
@@ -127,6 +131,12 @@ def test_phash_wide_rows_matrix_core_path(ctx):
             ep, _, e32, _, _ = O.hash_image(px[j], want_tiles=True)
             assert np.array_equal(t32[j], e32), (w, h, j, "tile32")
             assert int(got_p[j]) == ep, (w, h, j)
+    # 1-byte pixels
+    for (w, h) in [(772, 40), (1024, 300), (1500, 64), (2048, 100)]:
+        g1 = rng.integers(0, 256, (2, h, w), dtype=np.uint8)
+        got1, got1d = ctx.hash_uniform(g1, 2, w, h, 1)
+        for j in range(2):
+            assert (int(got1[j]), int(got1d[j])) == O.hash_image(g1[j])[:2], (w, h, j, "gray")
     # RGBA / RGBX rows (644..2048): the fourth byte is ignored, as convert("L") ignores it
     for (w, h) in [(644, 40), (800, 600), (1024, 64), (1284, 100), (1920, 1080), (2048, 31)]:
         px = rng.integers(0, 256, (2, h, w, 4), dtype=np.uint8)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised sweep of the hashing dispatch against the CPU oracle (every kernel family: single-pass exact / run-time
-row length / wide rows / RGBA, banded, generic): python benchmarks/fuzz_shapes.py [cases] [seed].  Exits non-zero on
+row length / wide rows / RGBA, banded, generic): python tests/fuzz_shapes.py [cases] [seed] (test infrastructure: it checks the GPU library against oracle/).  Exits non-zero on
 the first mismatch.  KE_FUSED_MIN_IMAGES=1 so that a few images reach the single-pass kernels."""
 import os
 import sys

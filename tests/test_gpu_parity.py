@@ -537,3 +537,17 @@ def test_host_staging_chunks_match_device_path(ctx):
         assert (int(p_host[k]), int(d_host[k])) == O.hash_image(host[k])
     t32, t98 = ctx.luma_tiles_uniform(host[:1500], 1500, side, side, 3)
     assert np.array_equal(t32[1499], O.hash_image(host[1499], want_tiles=True)[2])
+
+
+@pytest.mark.parametrize("min_images", ["1", "1000000000"])
+def test_dispatch_sweep_random_shapes(min_images):
+    """tests/fuzz_shapes.py: random widths / heights / channel counts / one or both hashes and ragged batches through
+    ke_hash_uniform and ke_hash_images against the oracle, once with one workgroup per image and once in band mode."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, KE_FUSED_MIN_IMAGES=min_images)
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz_shapes.py"), "150", "1234"], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

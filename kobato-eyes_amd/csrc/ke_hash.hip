@@ -235,7 +235,8 @@ struct KeFusedArgs {
     const int32_t *h_bias;
     const int32_t *v_packed, *v_start, *v_bias;          // vertical axis: 32 outputs, ndwv window dwords
     int ndwv;
-    int qw, qw_inv, lp;   // GEN instantiations: quads per row (W / 4), ceil(2^32 / qw), LDS pitch of a luma row
+    int qw, qw_inv, lp;   // GEN instantiations: quads per row (ceil(W / 4)), ceil(2^32 / qw), LDS pitch of a luma row
+    int w, row_bytes;     // UNAL instantiations (W not a multiple of 4): row length in pixels and bytes
     int lt_half;    // LDS bytes of ONE luma tile buffer (two are allocated; the tail reuses them as scratch)
     int lt_bytes;   // = 2 * lt_half
     int hp;         // pitch of one HT column (bytes, multiple of 8)
@@ -255,6 +256,14 @@ struct KeFusedArgs {
     uint64_t *dhash;
     uint8_t *tile98_out;
 };
+
+// UNAL instantiations: a row whose length is not a multiple of 4 ends in a partial quad whose load also takes the first
+// pixels of the next row (harmless: those columns only meet zero taps).  The partial quad of the image's LAST row would
+// read past the image, so its load is clamped and its 1..3 pixels are patched into the LDS tile here, byte by byte.
+template <int C>
+__device__ __forceinline__ void patch_last_quad(const uint8_t *image_last_row, int w, uint8_t *lds_row) {
+    for (int x = w & ~3; x < w; ++x) lds_row[x] = (uint8_t)(luma_of(image_last_row + (size_t)x * C, C) ^ 0x80);
+}
 
 // Band mode of the single-pass kernels: the band's transposed columns (LDS, pitch hp) -> global scratch, whole dwords
 // along y (band starts and pitches are multiples of 4; the scratch rows are padded).
@@ -395,8 +404,9 @@ typedef int ke_v4i __attribute__((ext_vector_type(4)));
 // GEN: the row length is a run-time value, any multiple of 4 in (64*(W64-1), 64*W64]; W64 and KS are then upper
 // bounds (operand steps past an output tile's window hold zero taps; what they read of the next row is ignored).
 // C: bytes per pixel, 3 (RGB), 4 (RGBX/RGBA: the fourth byte is ignored, as convert("L") ignores it) or 1 ("L").
-template <int W64, int KS, bool DH, bool GEN, int C>
+template <int W64, int KS, bool DH, bool GEN, int C, bool UNAL>
 __global__ __launch_bounds__(256, 2) void ke_phash_fused_mx(const KeFusedArgs a) {
+    static_assert(!UNAL || GEN, "rows that are not a multiple of 4 pixels need the run-time row length");
     constexpr uint32_t QB = 4u * C;              // bytes of a 4-pixel quad
     constexpr int W = 64 * W64;
     constexpr int QPT = kRTM * (W / 4) / 256;    // (upper bound of the) quads per thread per 32-row tile
@@ -413,9 +423,10 @@ __global__ __launch_bounds__(256, 2) void ke_phash_fused_mx(const KeFusedArgs a)
     const int lane = tid & 63, wv = tid >> 6;
     const int64_t img = a.bands ? blockIdx.x / a.bands : blockIdx.x;
     const int y_begin = a.bands ? (int)(blockIdx.x % a.bands) * a.band_rows : 0;
-    const uint8_t *src = a.pixels + (a.offsets ? a.offsets[img] : (uint64_t)img * a.stride) + (size_t)y_begin * QW * QB;
+    const uint32_t row_bytes = UNAL ? (uint32_t)a.row_bytes : (uint32_t)QW * QB;
+    const uint8_t *src = a.pixels + (a.offsets ? a.offsets[img] : (uint64_t)img * a.stride) + (size_t)y_begin * row_bytes;
     const int h = a.bands ? min(a.band_rows, a.h - y_begin) : a.h;          // rows this workgroup turns into columns
-    const uint32_t image_bytes = (uint32_t)(a.h - y_begin) * (uint32_t)QW * QB;   // bytes from src to the end of the image
+    const uint32_t image_bytes = (uint32_t)(a.h - y_begin) * row_bytes;     // bytes from src to the end of the image
 
     // this wave's slice of the product: rows 16*mt.., outputs 16*jt..
     const int mt = wv >> 1, jt = wv & 1;
@@ -446,16 +457,21 @@ __global__ __launch_bounds__(256, 2) void ke_phash_fused_mx(const KeFusedArgs a)
 
     uint32_t raw[QPT][C];
     auto load_tile = [&](int t) {
-        const uint32_t tile_off = (uint32_t)t * ((uint32_t)QUADS_PER_TILE * QB);
+        const uint32_t tile_off = UNAL ? (uint32_t)t * (kRTM * row_bytes) : (uint32_t)t * ((uint32_t)QUADS_PER_TILE * QB);
         const uint8_t *tile_ptr = src + tile_off;                 // wave-uniform
         // last loadable quad, relative to the tile; slots past the tile's own quads (run-time row lengths leave some)
         // re-read its last quad instead of pulling the next tile's bytes a second time
-        const uint32_t lim = min(image_bytes - QB - tile_off, (uint32_t)(QUADS_PER_TILE - 1) * QB);
+        const uint32_t lim = UNAL ? image_bytes - QB - tile_off : min(image_bytes - QB - tile_off, (uint32_t)(QUADS_PER_TILE - 1) * QB);
 #pragma unroll
         for (int q = 0; q < QPT; ++q) {
             // Unconditional loads (a guarded load makes hipcc wait vmcnt(0) after each one): quads past the image
             // end re-read the last quad; those rows only ever meet zero tap weights.  Streamed once: non-temporal.
-            const uint32_t vo = (uint32_t)(q * 256 + tid) * QB;
+            uint32_t vo = (uint32_t)(q * 256 + tid) * QB;
+            if (UNAL) {                                           // rows are not quad-aligned: address by (row, quad)
+                const uint32_t i = min((uint32_t)(q * 256 + tid), (uint32_t)(QUADS_PER_TILE - 1));
+                const uint32_t row = __umulhi(i, (uint32_t)a.qw_inv);
+                vo = row * row_bytes + (i - row * (uint32_t)QW) * QB;
+            }
             const uint32_t off = vo < lim ? vo : lim;
             const uint32_t *p = reinterpret_cast<const uint32_t *>(tile_ptr + off);
 #pragma unroll
@@ -539,6 +555,11 @@ __global__ __launch_bounds__(256, 2) void ke_phash_fused_mx(const KeFusedArgs a)
         store_luma(Lt + ((t + 1) & 1) * a.lt_half);
         __syncthreads();
     }
+    if (UNAL) {
+        if (tid == 0 && y_begin + h == a.h)
+            patch_last_quad<C>(src + (size_t)(h - 1) * row_bytes, a.w, Lt + ((ntiles - 1) & 1) * a.lt_half + ((h - 1) - (ntiles - 1) * kRTM) * LP);
+        __syncthreads();
+    }
     hpass(ntiles - 1, Lt + ((ntiles - 1) & 1) * a.lt_half);
     __syncthreads();
     if (DH) {
@@ -560,11 +581,11 @@ struct KeBandPlan {
     int hs_hp, hsd_hp;
 };
 
-template <int W64, int KS, bool DH, bool GEN = false, int C = 3>
+template <int W64, int KS, bool DH, bool GEN = false, int C = 3, bool UNAL = false>
 int launch_fused_mx(ke_ctx *ctx, const KeHashGroup &g, const KeAxisCoeffs *ch, const KeAxisCoeffs *cv, uint64_t *d_phash,
                     uint8_t *d_tile32, uint64_t *d_dhash, uint8_t *d_tile98, const KeBandPlan *plan = nullptr) {
     const int W = g.w;
-    if (GEN ? (W > 64 * W64 || W <= 64 * (W64 - 1) || W % 4) : W != 64 * W64) return KE_EUNSUPPORTED;
+    if (GEN ? (W > 64 * W64 || W <= 64 * (W64 - 1) || (W % 4 != 0) != UNAL) : W != 64 * W64) return KE_EUNSUPPORTED;
     const KeMxTable *mx = ke_get_mx(ctx, ch, KS);     // at least KS steps per tile (zero-padded)
     if (!mx) return ke_fail(ctx, KE_EHIP, "coefficient upload failed");
     if (mx->tiles != 2 || mx->ks != KS) return KE_EUNSUPPORTED;
@@ -580,7 +601,8 @@ int launch_fused_mx(ke_ctx *ctx, const KeHashGroup &g, const KeAxisCoeffs *ch, c
     // one tile buffer: 32 padded rows + the part of the last row's operand window that overhangs the row
     constexpr int KD = (W64 + 1) / 2;
     const int overhang = std::max(0, std::max(std::max(mx->base[0], mx->base[1]) + 64 * KS, DH ? 128 * KD : 0) - W);
-    a.qw = W / 4;
+    a.qw = (W + 3) / 4;
+    a.w = W; a.row_bytes = W * C;
     a.qw_inv = (int)(uint32_t)((0x100000000ull + (uint64_t)a.qw - 1) / (uint64_t)a.qw);
     // row pitch: an odd number of 16-byte units, so the 16 rows of an operand land in distinct bank groups
     a.lp = GEN ? (((W + 15) / 16 + 1) | 1) * 16 : W + 16;
@@ -614,10 +636,10 @@ int launch_fused_mx(ke_ctx *ctx, const KeHashGroup &g, const KeAxisCoeffs *ch, c
     if (lds > 150 * 1024) return KE_EUNSUPPORTED;
     if (!plan && lds > 80 * 1024 && lds - (size_t)(32 * (a.hp - 136)) - (DH ? (size_t)(9 * (a.hpd - 136)) : 0) <= 80 * 1024) return KE_EUNSUPPORTED;
     if (lds > 64 * 1024)
-        KE_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&ke_phash_fused_mx<W64, KS, DH, GEN, C>),
+        KE_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&ke_phash_fused_mx<W64, KS, DH, GEN, C, UNAL>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (g.n * (plan ? plan->bands : 1) > 0x7fffffffLL) return ke_fail(ctx, KE_EUNSUPPORTED, "group too large for one launch");
-    hipLaunchKernelGGL((ke_phash_fused_mx<W64, KS, DH, GEN, C>), dim3((unsigned)(g.n * (plan ? plan->bands : 1))), dim3(256), lds, ctx->stream, a);
+    hipLaunchKernelGGL((ke_phash_fused_mx<W64, KS, DH, GEN, C, UNAL>), dim3((unsigned)(g.n * (plan ? plan->bands : 1))), dim3(256), lds, ctx->stream, a);
     KE_HIP(ctx, hipGetLastError());
     return KE_OK;
 }
@@ -633,7 +655,7 @@ int launch_fused_mx(ke_ctx *ctx, const KeHashGroup &g, const KeAxisCoeffs *ch, c
 // ---------------------------------------------------------------------------------------
 constexpr int kRTW = 16;
 
-template <int KSH, int QPT, bool DH, int KDW, int C>
+template <int KSH, int QPT, bool DH, int KDW, int C, bool UNAL>
 __global__ __launch_bounds__(512, 1) void ke_phash_fused_wide(const KeFusedArgs a) {
     constexpr uint32_t QB = 4u * C;              // bytes of a 4-pixel quad (RGB or RGBX)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -647,10 +669,11 @@ __global__ __launch_bounds__(512, 1) void ke_phash_fused_wide(const KeFusedArgs 
     const int64_t img = a.bands ? blockIdx.x / a.bands : blockIdx.x;
     const int y_begin = a.bands ? (int)(blockIdx.x % a.bands) * a.band_rows : 0;
     const int QW = a.qw, LP = a.lp;
-    const uint8_t *src = a.pixels + (a.offsets ? a.offsets[img] : (uint64_t)img * a.stride) + (size_t)y_begin * QW * QB;
+    const uint32_t row_bytes = UNAL ? (uint32_t)a.row_bytes : (uint32_t)QW * QB;
+    const uint8_t *src = a.pixels + (a.offsets ? a.offsets[img] : (uint64_t)img * a.stride) + (size_t)y_begin * row_bytes;
     const int h = a.bands ? min(a.band_rows, a.h - y_begin) : a.h;          // rows this workgroup turns into columns
     const int quads_per_tile = kRTW * QW;
-    const uint32_t image_bytes = (uint32_t)(a.h - y_begin) * (uint32_t)QW * QB;   // bytes from src to the end of the image
+    const uint32_t image_bytes = (uint32_t)(a.h - y_begin) * row_bytes;     // bytes from src to the end of the image
 
     ke_v4i bf[KSH][3];
 #pragma unroll
@@ -680,12 +703,17 @@ __global__ __launch_bounds__(512, 1) void ke_phash_fused_wide(const KeFusedArgs 
 
     uint32_t raw[QPT][C];
     auto load_tile = [&](int t) {
-        const uint32_t tile_off = (uint32_t)t * ((uint32_t)quads_per_tile * QB);
+        const uint32_t tile_off = UNAL ? (uint32_t)t * (kRTW * row_bytes) : (uint32_t)t * ((uint32_t)quads_per_tile * QB);
         const uint8_t *tile_ptr = src + tile_off;
-        const uint32_t lim = min(image_bytes - QB - tile_off, (uint32_t)(quads_per_tile - 1) * QB);
+        const uint32_t lim = UNAL ? image_bytes - QB - tile_off : min(image_bytes - QB - tile_off, (uint32_t)(quads_per_tile - 1) * QB);
 #pragma unroll
         for (int q = 0; q < QPT; ++q) {           // unconditional, clamped, non-temporal (see ke_phash_fused_mx)
-            const uint32_t vo = (uint32_t)(q * 512 + tid) * QB;
+            uint32_t vo = (uint32_t)(q * 512 + tid) * QB;
+            if (UNAL) {                                           // rows are not quad-aligned: address by (row, quad)
+                const uint32_t i = min((uint32_t)(q * 512 + tid), (uint32_t)(quads_per_tile - 1));
+                const uint32_t row = __umulhi(i, (uint32_t)a.qw_inv);
+                vo = row * row_bytes + (i - row * (uint32_t)QW) * QB;
+            }
             const uint32_t off = vo < lim ? vo : lim;
             const uint32_t *p = reinterpret_cast<const uint32_t *>(tile_ptr + off);
 #pragma unroll
@@ -781,6 +809,11 @@ __global__ __launch_bounds__(512, 1) void ke_phash_fused_wide(const KeFusedArgs 
         store_luma(Lt + ((t + 1) & 1) * a.lt_half);
         __syncthreads();
     }
+    if (UNAL) {
+        if (tid == 0 && y_begin + h == a.h)
+            patch_last_quad<C>(src + (size_t)(h - 1) * row_bytes, a.w, Lt + ((ntiles - 1) & 1) * a.lt_half + ((h - 1) - (ntiles - 1) * kRTW) * LP);
+        __syncthreads();
+    }
     hpass(ntiles - 1, Lt + ((ntiles - 1) & 1) * a.lt_half);
     __syncthreads();
     if (!kh) finish(ntiles - 1);
@@ -796,11 +829,11 @@ __global__ __launch_bounds__(512, 1) void ke_phash_fused_wide(const KeFusedArgs 
     fused_tail<(DH ? 1 : 0)>(a, Lt, HT, HTd, tid, img);
 }
 
-template <int KSH, int QPT, bool DH, int KDW, int C = 3>
+template <int KSH, int QPT, bool DH, int KDW, int C = 3, bool UNAL = false>
 int launch_fused_wide(ke_ctx *ctx, const KeHashGroup &g, const KeAxisCoeffs *ch, const KeAxisCoeffs *cv, uint64_t *d_phash,
                       uint8_t *d_tile32, uint64_t *d_dhash, uint8_t *d_tile98, const KeBandPlan *plan = nullptr) {
     const int W = g.w;
-    if (W % 4 || kRTW * (W / 4) > 512 * QPT) return KE_EUNSUPPORTED;
+    if ((W % 4 != 0) != UNAL || kRTW * ((W + 3) / 4) > 512 * QPT) return KE_EUNSUPPORTED;
     const KeMxTable *mx = ke_get_mx(ctx, ch, 4 * KSH);
     if (!mx) return ke_fail(ctx, KE_EHIP, "coefficient upload failed");
     if (mx->tiles != 2 || mx->ks != 4 * KSH) return KE_EUNSUPPORTED;
@@ -814,7 +847,8 @@ int launch_fused_wide(ke_ctx *ctx, const KeHashGroup &g, const KeAxisCoeffs *ch,
     const int rows_padded = plan ? plan->band_rows : ((g.h + kRTW - 1) / kRTW) * kRTW;
     if (plan) { a.bands = plan->bands; a.band_rows = plan->band_rows; a.hs = plan->hs; a.hsd = plan->hsd; a.hs_hp = plan->hs_hp; a.hsd_hp = plan->hsd_hp; }
     const int overhang = std::max(0, std::max(std::max(mx->base[0], mx->base[1]) + 64 * 4 * KSH, DH ? 512 * KDW : 0) - W);
-    a.qw = W / 4;
+    a.qw = (W + 3) / 4;
+    a.w = W; a.row_bytes = W * C;
     a.qw_inv = (int)(uint32_t)((0x100000000ull + (uint64_t)a.qw - 1) / (uint64_t)a.qw);
     a.lp = (((W + 15) / 16 + 1) | 1) * 16;
     a.lt_half = (kRTW * a.lp + overhang + 15) & ~15;
@@ -845,10 +879,10 @@ int launch_fused_wide(ke_ctx *ctx, const KeHashGroup &g, const KeAxisCoeffs *ch,
     // ... unless bands of rows bring it under 80 KB (two per CU): then the caller runs this kernel per band
     if (!plan && lds > 80 * 1024 && lds - (size_t)(32 * (a.hp - 136)) - (DH ? (size_t)(9 * (a.hpd - 136)) : 0) <= 80 * 1024) return KE_EUNSUPPORTED;
     if (lds > 64 * 1024)
-        KE_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&ke_phash_fused_wide<KSH, QPT, DH, KDW, C>),
+        KE_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&ke_phash_fused_wide<KSH, QPT, DH, KDW, C, UNAL>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (g.n * (plan ? plan->bands : 1) > 0x7fffffffLL) return ke_fail(ctx, KE_EUNSUPPORTED, "group too large for one launch");
-    hipLaunchKernelGGL((ke_phash_fused_wide<KSH, QPT, DH, KDW, C>), dim3((unsigned)(g.n * (plan ? plan->bands : 1))), dim3(512), lds, ctx->stream, a);
+    hipLaunchKernelGGL((ke_phash_fused_wide<KSH, QPT, DH, KDW, C, UNAL>), dim3((unsigned)(g.n * (plan ? plan->bands : 1))), dim3(512), lds, ctx->stream, a);
     KE_HIP(ctx, hipGetLastError());
     return KE_OK;
 }
@@ -1519,18 +1553,40 @@ int resample_generic(ke_ctx *ctx, const KeHashGroup &g, int ow, int oh, uint8_t 
 int dispatch_single_pass(ke_ctx *ctx, const KeHashGroup &g, bool want_d, uint64_t *d_phash, uint8_t *d_t32, uint64_t *d_dhash,
                          uint8_t *d_t98, const KeBandPlan *plan, bool *did_d) {
     *did_d = false;
-    if (g.w % 4 || g.w <= 64 || g.w > 2048 || g.h == 32 || g.h < 16 ||
-        (!plan && g.h > 4096) || (int64_t)g.h > (int64_t)g.w * 100 || (uintptr_t)g.pixels % 4 || !(g.offsets || g.stride % 4 == 0) ||
+    const bool unal = g.w % 4 != 0;                // rows that do not end on a 4-pixel boundary: RGB, pHash leg only
+    if (g.w <= 64 || g.w > (unal ? 1024 : 2048) || g.h == 32 || g.h < 16 || (unal && g.channels != 3) ||
+        (!plan && g.h > 4096) || (int64_t)g.h > (int64_t)g.w * 100 ||
+        (!unal && ((uintptr_t)g.pixels % 4 || !(g.offsets || g.stride % 4 == 0))) ||
         (int64_t)g.w * g.h * g.channels >= (1LL << 31))
         return KE_EUNSUPPORTED;
     // offsets (ragged groups) are only 4-byte aligned when every image size is; w % 4 == 0 makes it so
     const KeAxisCoeffs *ch = ke_get_coeffs(ctx, g.w, 32);
     const KeAxisCoeffs *cv = ke_get_coeffs(ctx, g.h, 32);
     if (!ch || !cv) return ke_fail(ctx, KE_EHIP, "coefficient upload failed");
-    const bool both = want_d && g.h != 8 && g.channels == 3;
+    const bool both = want_d && g.h != 8 && g.channels == 3 && !unal;
     int rc = KE_EUNSUPPORTED;
 #define KE_MX(W64, KS, DH, GEN, C) rc = launch_fused_mx<W64, KS, DH, GEN, C>(ctx, g, ch, cv, d_phash, d_t32, DH ? d_dhash : nullptr, DH ? d_t98 : nullptr, plan)
 #define KE_WIDE(KSH, QPT, DH, KDW, C) rc = launch_fused_wide<KSH, QPT, DH, KDW, C>(ctx, g, ch, cv, d_phash, d_t32, DH ? d_dhash : nullptr, DH ? d_t98 : nullptr, plan)
+    if (unal) {
+        if (g.w <= 704) {
+            switch ((g.w + 63) / 64) {
+                case 2: rc = launch_fused_mx<2, 2, false, true, 3, true>(ctx, g, ch, cv, d_phash, d_t32, nullptr, nullptr, plan); break;
+                case 3: rc = launch_fused_mx<3, 2, false, true, 3, true>(ctx, g, ch, cv, d_phash, d_t32, nullptr, nullptr, plan); break;
+                case 4: rc = launch_fused_mx<4, 3, false, true, 3, true>(ctx, g, ch, cv, d_phash, d_t32, nullptr, nullptr, plan); break;
+                case 5: rc = launch_fused_mx<5, 3, false, true, 3, true>(ctx, g, ch, cv, d_phash, d_t32, nullptr, nullptr, plan); break;
+                case 6: rc = launch_fused_mx<6, 4, false, true, 3, true>(ctx, g, ch, cv, d_phash, d_t32, nullptr, nullptr, plan); break;
+                case 7: rc = launch_fused_mx<7, 5, false, true, 3, true>(ctx, g, ch, cv, d_phash, d_t32, nullptr, nullptr, plan); break;
+                case 8: rc = launch_fused_mx<8, 5, false, true, 3, true>(ctx, g, ch, cv, d_phash, d_t32, nullptr, nullptr, plan); break;
+                case 9: rc = launch_fused_mx<9, 6, false, true, 3, true>(ctx, g, ch, cv, d_phash, d_t32, nullptr, nullptr, plan); break;
+                case 10: rc = launch_fused_mx<10, 6, false, true, 3, true>(ctx, g, ch, cv, d_phash, d_t32, nullptr, nullptr, plan); break;
+                default: rc = launch_fused_mx<11, 7, false, true, 3, true>(ctx, g, ch, cv, d_phash, d_t32, nullptr, nullptr, plan); break;
+            }
+            if (rc != KE_EUNSUPPORTED) return rc;
+        }
+        // wider rows stay on the banded kernel (funnel-shift loader): measured 3.9 TB/s here at 1599 pixels against 5.3 there
+        if (g.w <= 1024) rc = launch_fused_wide<3, 8, false, 1, 3, true>(ctx, g, ch, cv, d_phash, d_t32, nullptr, nullptr, plan);
+        return rc;
+    }
     // ---- rows up to 768 pixels: 256-thread kernel, 32-row tiles
     if (g.w <= 768) {
         if (both && g.w <= 512) {                  // pHash + dHash in one pass over the pixels

@@ -196,6 +196,23 @@ def test_phash_strip_kernel_for_rows_wider_than_2048(ctx):
             assert (int(got_p[j]), int(got_d[j])) == (ep, ed), (w, h, j)
 
 
+def test_phash_rows_not_a_multiple_of_4_pixels(ctx):
+    """RGB rows of 65..1024 pixels that do not end on a quad boundary take the single-pass kernels with (row, quad)
+    addressing, unaligned 12-byte loads and the image's last partial quad patched in LDS: every residue, short and tall
+    images, one image and small batches, both hashes (dHash from the banded kernel), ragged neighbours."""
+    rng = np.random.default_rng(8)
+    for (w, h) in [(65, 40), (66, 16), (67, 33), (131, 77), (301, 451), (333, 500), (501, 333), (513, 64), (683, 1024), (702, 31),
+                   (705, 100), (799, 600), (1001, 17), (1023, 682), (255, 2000)]:
+        for n in (1, 3):
+            px = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
+            got_p, got_d = ctx.hash_uniform(px, n, w, h, 3)
+            t32, _ = ctx.luma_tiles_uniform(px, n, w, h, 3, want98=False)
+            for j in range(n):
+                ep, ed, e32, _, _ = O.hash_image(px[j], want_tiles=True)
+                assert np.array_equal(t32[j], e32), (w, h, n, j, "tile32")
+                assert (int(got_p[j]), int(got_d[j])) == (ep, ed), (w, h, n, j)
+
+
 def test_extreme_pixels_fused(ctx):
     """Saturated inputs exercise the clip after each pass and the signed-byte bias."""
     rng = np.random.default_rng(0)

@@ -1608,6 +1608,7 @@ int dispatch_single_pass(ke_ctx *ctx, const KeHashGroup &g, bool want_d, uint64_
             }
             if (rc == KE_OK) { *did_d = true; return KE_OK; }
             if (rc != KE_EUNSUPPORTED) return rc;
+            if (!plan) return KE_EUNSUPPORTED;     // both legs did not fit one workgroup per image: per band they do (one pass)
         }
         // both hashes of RGB rows of 516..768 pixels: the wide-row kernel below has a dHash leg for them, this one does not
         if (g.channels == 3 && !(both && g.w > 512)) {
@@ -1675,6 +1676,7 @@ int dispatch_single_pass(ke_ctx *ctx, const KeHashGroup &g, bool want_d, uint64_
             else KE_WIDE(5, 16, true, 4, 3);
             if (rc == KE_OK) { *did_d = true; return KE_OK; }
             if (rc != KE_EUNSUPPORTED) return rc;
+            if (!plan) return KE_EUNSUPPORTED;     // as above
         }
         if (g.channels == 4) {
             if (g.w <= 1024) KE_WIDE(3, 8, false, 1, 4);

@@ -1554,7 +1554,7 @@ int dispatch_single_pass(ke_ctx *ctx, const KeHashGroup &g, bool want_d, uint64_
                          uint8_t *d_t98, const KeBandPlan *plan, bool *did_d) {
     *did_d = false;
     const bool unal = g.w % 4 != 0;                // rows that do not end on a 4-pixel boundary: RGB, pHash leg only
-    if (g.w <= 64 || g.w > (unal ? 1024 : 2048) || g.h == 32 || g.h < 16 || (unal && g.channels != 3) ||
+    if (g.w <= 64 || g.w > (unal ? 1024 : g.channels == 3 ? 2816 : 2048) || g.h == 32 || g.h < 16 || (unal && g.channels != 3) ||
         (!plan && g.h > 4096) || (int64_t)g.h > (int64_t)g.w * 100 ||
         (!unal && ((uintptr_t)g.pixels % 4 || !(g.offsets || g.stride % 4 == 0))) ||
         (int64_t)g.w * g.h * g.channels >= (1LL << 31))
@@ -1670,7 +1670,7 @@ int dispatch_single_pass(ke_ctx *ctx, const KeHashGroup &g, bool want_d, uint64_
     }
     // ---- wide rows (and what the kernel above left): 512-thread kernel, 16-row tiles
     if (g.w > (g.channels == 4 ? 640 : g.channels == 1 ? 768 : both ? 512 : 704)) {
-        if (both) {                                // both hashes in one pass
+        if (both && g.w <= 2048) {                 // both hashes in one pass
             if (g.w <= 1024) KE_WIDE(3, 8, true, 2, 3);
             else if (g.w <= 1536) KE_WIDE(4, 12, true, 3, 3);
             else KE_WIDE(5, 16, true, 4, 3);
@@ -1689,7 +1689,9 @@ int dispatch_single_pass(ke_ctx *ctx, const KeHashGroup &g, bool want_d, uint64_
         } else {
             if (g.w <= 1024) KE_WIDE(3, 8, false, 1, 3);
             else if (g.w <= 1536) KE_WIDE(4, 12, false, 1, 3);
-            else KE_WIDE(5, 16, false, 1, 3);
+            else if (g.w <= 2048) KE_WIDE(5, 16, false, 1, 3);
+            else if (g.w <= 2560) KE_WIDE(6, 20, false, 1, 3);      // 2560x1440-class rows: below the strip kernel's range
+            else KE_WIDE(7, 22, false, 1, 3);
         }
         if (rc != KE_EUNSUPPORTED) return rc;
     }

@@ -114,12 +114,13 @@ def test_phash_any_width_up_to_768_matrix_core_path(ctx):
 
 
 def test_phash_wide_rows_matrix_core_path(ctx):
-    """RGB rows of 708..2048 pixels take the 512-thread variant (16-row tiles, each output tile's operand steps split
+    """RGB rows of 708..2812 pixels take the 512-thread variant (16-row tiles, each output tile's operand steps split
     over four waves that meet through LDS): widths across its three instantiations, heights around the tile size,
     tall images (LDS-limited), full-range noise; tile and bits against the oracle."""
     rng = np.random.default_rng(12)
     shapes = [(708, 100), (720, 480), (800, 600), (832, 33), (960, 540), (1024, 768), (1028, 64), (1152, 864), (1280, 720),
-              (1440, 900), (1536, 1000), (1540, 17), (1600, 1200), (1920, 1080), (2048, 1100), (2048, 16), (2000, 3000), (1024, 4096)]
+              (1440, 900), (1536, 1000), (1540, 17), (1600, 1200), (1920, 1080), (2048, 1100), (2048, 16), (2000, 3000), (1024, 4096),
+              (2052, 64), (2304, 1296), (2560, 1440), (2564, 300), (2736, 1824), (2812, 33), (2560, 3000)]
     shapes += [(w, 16 + (w // 4) % 70) for w in range(712, 2049, 92)]
     for (w, h) in shapes:
         n = 2

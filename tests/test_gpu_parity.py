@@ -569,3 +569,14 @@ def test_dispatch_sweep_random_shapes(min_images):
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz_shapes.py"), "150", "1234"], env=env, capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_scan_sweep_random_tables():
+    """tests/fuzz_scan.py: random table sizes around the tile edges, thresholds, band shapes, duplicate ids, size ratio,
+    bucket cap and shard counts against the oracle's reference-shaped scan."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz_scan.py"), "120", "99"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

@@ -82,7 +82,12 @@ int ke_memcpy(ke_ctx *ctx, void *dst, const void *src, size_t bytes);   /* any d
  * heights[i] rows of widths[i]*channels bytes, no row padding.
  * phash_out / dhash_out: unsigned 64-bit hashes (either may be NULL).  The signed wrap of
  * src/sig/phash.py:29-30 / src/core/fastsig.py:19-21 is the host's reinterpretation.
- * status_out (nullable): KE_IMG_* per image; hashes of failed images are 0. */
+ * status_out (nullable): KE_IMG_* per image; hashes of failed images are 0.
+ *
+ * Tuning knob (environment, read at every call): KE_FUSED_MIN_IMAGES = smallest group of equally sized images that is
+ * hashed with one workgroup per image; smaller groups are cut into bands of rows so that a few large images still fill
+ * the GPU.  Unset: chosen from the image size (about 200 images for 0.4-8 MB images, 512 above).  Results do not depend
+ * on it. */
 int ke_hash_images(ke_ctx *ctx, const uint8_t *pixels, const uint64_t *offsets, const int32_t *widths,
                    const int32_t *heights, int32_t channels, int64_t n, uint64_t *phash_out,
                    uint64_t *dhash_out, int32_t *status_out);

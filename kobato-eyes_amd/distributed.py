@@ -69,6 +69,7 @@ def gather_edges(edges: np.ndarray, *, group=None, dst: Optional[int] = None) ->
 
 
 _edge_slots_hint: dict = {}     # per process group: edge records every rank sends along with its count
+_edge_buffers: dict = {}        # (group, device, width, world) -> (send record, gathered records), reused across calls
 
 
 def allgather_edge_buffers(edges_u8, count: int, *, group=None):
@@ -86,12 +87,17 @@ def allgather_edge_buffers(edges_u8, count: int, *, group=None):
     key = id(group) if group is not None else 0
     slots = _edge_slots_hint.get(key, 1024)
     width = 8 + slots * 24
-    send = torch.zeros(width, dtype=torch.uint8, device=dev)
+    # the record and the gathered buffer live across calls: no allocation or fill kernel on the step's critical path
+    bufs = _edge_buffers.get((key, str(dev), width, world))
+    if bufs is None:
+        bufs = (torch.zeros(width, dtype=torch.uint8, device=dev), torch.empty(world * width, dtype=torch.uint8, device=dev))
+        _edge_buffers.clear()
+        _edge_buffers[(key, str(dev), width, world)] = bufs
+    send, gathered = bufs
     send[:8] = torch.tensor([int(count)], dtype=torch.int64).view(torch.uint8).to(dev)
     head = min(int(count), slots) * 24
     if head:
         send[8:8 + head] = edges_u8[:head]
-    gathered = torch.empty(world * width, dtype=torch.uint8, device=dev)
     dist.all_gather_into_tensor(gathered, send, group=group)
     host = gathered.cpu().numpy().reshape(world, width)
     counts = [int(v) for v in np.ascontiguousarray(host[:, :8]).view(np.int64)[:, 0]]

@@ -29,7 +29,7 @@ struct SsimArgs {
     const uint8_t *images;
     const int64_t *pa, *pb;
     int w, h;
-    int col_blocks, bands, items_per_pair;
+    int col_blocks, block_cols, bands, items_per_pair;
     int64_t n_items;
     double *partial;   // [pair][items_per_pair]
 };
@@ -80,6 +80,29 @@ __device__ __forceinline__ uint32_t load_luma4(uintptr_t ad, uintptr_t last_dwor
     return out;
 }
 
+// The same four luma bytes when the quad starts on a dword boundary (rows of a multiple of 4 pixels, lane columns a
+// multiple of 4): C dword loads, no funnel shifts, bytes packed with two v_perm.
+template <int C>
+__device__ __forceinline__ uint32_t load_luma4_aligned(const uint8_t *ptr) {
+    const uint32_t *p = reinterpret_cast<const uint32_t *>(ptr);
+    if (C == 1) return p[0];
+    constexpr uint32_t CHI = 0x001D964Cu, CLO = 0x002F468Bu;
+    uint32_t s[4];
+    if (C == 3) {
+        const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
+        const uint32_t p1 = __builtin_amdgcn_alignbyte(d1, d0, 3), p2 = __builtin_amdgcn_alignbyte(d2, d1, 2);
+        s[0] = (__builtin_amdgcn_udot4(d0, CHI, 0u, false) << 8) + __builtin_amdgcn_udot4(d0, CLO, 0x8000u, false);
+        s[1] = (__builtin_amdgcn_udot4(p1, CHI, 0u, false) << 8) + __builtin_amdgcn_udot4(p1, CLO, 0x8000u, false);
+        s[2] = (__builtin_amdgcn_udot4(p2, CHI, 0u, false) << 8) + __builtin_amdgcn_udot4(p2, CLO, 0x8000u, false);
+        s[3] = (__builtin_amdgcn_udot4(d2, CHI << 8, 0u, false) << 8) + __builtin_amdgcn_udot4(d2, CLO << 8, 0x8000u, false);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            s[k] = (__builtin_amdgcn_udot4(p[k], CHI, 0u, false) << 8) + __builtin_amdgcn_udot4(p[k], CLO, 0x8000u, false);
+    }
+    return __builtin_amdgcn_perm(s[1], s[0], 0x0C0C0602u) | __builtin_amdgcn_perm(s[3], s[2], 0x06020C0Cu);   // byte 2 of each sum
+}
+
 // x = L/255 in float32, correctly rounded for every L in 0..255 (checked for all 256 values in exact rational
 // arithmetic): 1/255 = r_hi + r_lo to 48 bits, L * r_lo rounded, then one fma -- L/255 is never close to a float32
 // rounding boundary (255 is odd), so the 2^-24 ulp this loses cannot change the result.
@@ -90,7 +113,9 @@ __device__ __forceinline__ float unit_of(uint32_t L) {
 }
 
 // PX pixels per lane (4 or 8): a wave covers 64*PX halo columns, 64*PX - 6 interior ones.
-template <int C, int PX>
+// AL: rows and lane columns start on dword boundaries (width a multiple of 4, aligned base): aligned loader, and the
+// wave's interior width is rounded down to a multiple of 4 so that every block does.
+template <int C, int PX, bool AL>
 __global__ __launch_bounds__(256, 2) void ke_ssim_waves(const SsimArgs a) {
     constexpr int NW = PX / 4;                              // luma dwords per row per image per lane
     const int lane = threadIdx.x & 63;
@@ -99,7 +124,7 @@ __global__ __launch_bounds__(256, 2) void ke_ssim_waves(const SsimArgs a) {
     const int64_t pair = item / a.items_per_pair;
     const int sub = (int)(item % a.items_per_pair);
     const int band = sub / a.col_blocks, cb = sub % a.col_blocks;
-    const int block_cols = 64 * PX - 6;
+    const int block_cols = a.block_cols;                    // interior columns per wave: 64*PX - 6, or that rounded down to 4
     const int x0 = cb * block_cols;
     const int y0 = band * kBandRows;                       // first halo row; interior rows y0+3 ..
     const int y_int_end = min(a.h - 3, y0 + 3 + kBandRows);  // one past the last interior row of this band
@@ -110,6 +135,9 @@ __global__ __launch_bounds__(256, 2) void ke_ssim_waves(const SsimArgs a) {
     const uintptr_t lastB = ((uintptr_t)B + img_bytes - 1) & ~(uintptr_t)3;
     int xc = x0 + PX * lane;                                // this lane's first column
     xc = xc < a.w ? xc : a.w - 1;                           // lanes past the right edge load something valid; never used
+    int xq[NW];                                             // AL: first column of each 4-pixel group, kept inside the row
+#pragma unroll
+    for (int n = 0; n < NW; ++n) xq[n] = min(x0 + PX * lane + 4 * n, a.w - 4);
 
     uint32_t ra[7][NW], rb[7][NW];                          // luma bytes of the seven most recent rows
     double sx[PX], sy[PX], sxx[PX], syy[PX], sxy[PX];
@@ -129,8 +157,14 @@ __global__ __launch_bounds__(256, 2) void ke_ssim_waves(const SsimArgs a) {
         uint32_t na[NW], nb[NW];
 #pragma unroll
         for (int n = 0; n < NW; ++n) {
-            na[n] = load_luma4<C>((uintptr_t)A + off + (size_t)n * 4 * C, lastA);
-            nb[n] = load_luma4<C>((uintptr_t)B + off + (size_t)n * 4 * C, lastB);
+            if (AL) {
+                const size_t o = ((size_t)y * a.w + xq[n]) * C;
+                na[n] = load_luma4_aligned<C>(A + o);
+                nb[n] = load_luma4_aligned<C>(B + o);
+            } else {
+                na[n] = load_luma4<C>((uintptr_t)A + off + (size_t)n * 4 * C, lastA);
+                nb[n] = load_luma4<C>((uintptr_t)B + off + (size_t)n * 4 * C, lastB);
+            }
         }
         // slide: drop the oldest row, add the new one.  The first six rows of a band subtract the zeros the
         // ring starts with (L = 0 -> x = 0), so no special case.
@@ -234,6 +268,14 @@ int ke_launch_ssim(ke_ctx *ctx, const uint8_t *d_images, int w, int h, int chann
     const int cb4 = (w - 6 + 249) / 250, cb8 = (w - 6 + 505) / 506;
     const int px = (cb8 * 506 < cb4 * 250) ? 8 : 4;
     a.col_blocks = px == 8 ? cb8 : cb4;
+    a.block_cols = 64 * px - 6;
+    // aligned loads need dword-aligned quads: width a multiple of 4, image base and size multiples of 4, and every
+    // block starting on a multiple of 4 -- one block, or blocks of 248 / 504 columns when that does not add a block
+    bool al = w % 4 == 0 && (uintptr_t)d_images % 4 == 0 && ((size_t)w * h * channels) % 4 == 0;
+    if (al && a.col_blocks > 1) {
+        const int bca = a.block_cols & ~3;
+        if ((w - 6 + bca - 1) / bca == a.col_blocks) a.block_cols = bca; else al = false;
+    }
     a.bands = (h - 6 + kBandRows - 1) / kBandRows;
     a.items_per_pair = a.col_blocks * a.bands;
     a.n_items = n_pairs * a.items_per_pair;
@@ -243,7 +285,8 @@ int ke_launch_ssim(ke_ctx *ctx, const uint8_t *d_images, int w, int h, int chann
     KE_TRY(ke_reserve(ctx, KE_BUF_SCAN_AUX, (size_t)a.n_items * sizeof(double), &part));
     a.partial = (double *)part;
     const dim3 grid((unsigned)blocks), blk(256);
-#define KE_SSIM_LAUNCH(CH, PXV) hipLaunchKernelGGL((ke_ssim_waves<CH, PXV>), grid, blk, 0, ctx->stream, a)
+#define KE_SSIM_LAUNCH(CH, PXV) do { if (al) hipLaunchKernelGGL((ke_ssim_waves<CH, PXV, true>), grid, blk, 0, ctx->stream, a); \
+                                     else hipLaunchKernelGGL((ke_ssim_waves<CH, PXV, false>), grid, blk, 0, ctx->stream, a); } while (0)
     if (channels == 3) { if (px == 8) KE_SSIM_LAUNCH(3, 8); else KE_SSIM_LAUNCH(3, 4); }
     else if (channels == 1) { if (px == 8) KE_SSIM_LAUNCH(1, 8); else KE_SSIM_LAUNCH(1, 4); }
     else { if (px == 8) KE_SSIM_LAUNCH(4, 8); else KE_SSIM_LAUNCH(4, 4); }

@@ -46,61 +46,62 @@ __device__ __forceinline__ float mean7(double s) {
     return (float)(s * r);
 }
 
-// Four consecutive pixels of one row starting at byte address `ad` (any alignment) -> four luma bytes.
+// Luma of four RGB(X) pixels held in p[0..3] (one pixel per dword, channel bytes 0..2): byte 2 of each 16.16 sum, packed.
+__device__ __forceinline__ uint32_t luma4_from_pixels(const uint32_t *p, bool last_shifted) {
+    constexpr uint32_t CHI = 0x001D964Cu, CLO = 0x002F468Bu;     // 19595 = 76*256+139, 38470 = 150*256+70, 7471 = 29*256+47
+    uint32_t s[4];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) s[k] = (__builtin_amdgcn_udot4(p[k], CHI, 0u, false) << 8) + __builtin_amdgcn_udot4(p[k], CLO, 0x8000u, false);
+    // packed RGB: the fourth pixel sits in bytes 1..3 of its dword -- shift the weights, not the data
+    s[3] = last_shifted ? (__builtin_amdgcn_udot4(p[3], CHI << 8, 0u, false) << 8) + __builtin_amdgcn_udot4(p[3], CLO << 8, 0x8000u, false)
+                        : (__builtin_amdgcn_udot4(p[3], CHI, 0u, false) << 8) + __builtin_amdgcn_udot4(p[3], CLO, 0x8000u, false);
+    return __builtin_amdgcn_perm(s[1], s[0], 0x0C0C0602u) | __builtin_amdgcn_perm(s[3], s[2], 0x06020C0Cu);
+}
+
+// Four consecutive pixels of one row starting `off` bytes into the image (any alignment) -> four luma bytes.
+// base: the image pointer rounded down to a dword (wave-uniform), off: byte offset from it, last: offset of the last
+// whole dword of the image -- all 32-bit, so a load is scalar base + clamped vector offset.
 template <int C>
-__device__ __forceinline__ uint32_t load_luma4(uintptr_t ad, uintptr_t last_dword) {
-    const uintptr_t al = ad & ~(uintptr_t)3;
-    const int sb = (int)(ad & 3);
+__device__ __forceinline__ uint32_t load_luma4(const uint8_t *base, uint32_t off, uint32_t last) {
+    const uint32_t al = off & ~3u;
+    const int sb = (int)(off & 3u);
     uint32_t wv[C + 1], d[C];
 #pragma unroll
-    for (int k = 0; k <= C; ++k) {
-        const uintptr_t x = al + 4 * k;
-        wv[k] = *reinterpret_cast<const uint32_t *>(x < last_dword ? x : last_dword);
-    }
+    for (int k = 0; k <= C; ++k) wv[k] = *reinterpret_cast<const uint32_t *>(base + min(al + 4u * k, last));
 #pragma unroll
     for (int k = 0; k < C; ++k) d[k] = __builtin_amdgcn_alignbyte(wv[k + 1], wv[k], sb);
     if (C == 1) return d[0];
-    constexpr uint32_t CHI = 0x001D964Cu, CLO = 0x002F468Bu;     // 19595 = 76*256+139, 38470 = 150*256+70, 7471 = 29*256+47
     uint32_t p[4];
     if (C == 3) {
         p[0] = d[0];
         p[1] = __builtin_amdgcn_alignbyte(d[1], d[0], 3);
         p[2] = __builtin_amdgcn_alignbyte(d[2 % C], d[1], 2);
-        p[3] = d[2 % C] >> 8;
+        p[3] = d[2 % C];
     } else {
 #pragma unroll
         for (int k = 0; k < 4; ++k) p[k] = d[k % C];
     }
-    uint32_t out = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const uint32_t sum = (__builtin_amdgcn_udot4(p[k], CHI, 0u, false) << 8) + __builtin_amdgcn_udot4(p[k], CLO, 0x8000u, false);
-        out |= ((sum >> 16) & 0xFFu) << (8 * k);
-    }
-    return out;
+    return luma4_from_pixels(p, C == 3);
 }
 
 // The same four luma bytes when the quad starts on a dword boundary (rows of a multiple of 4 pixels, lane columns a
 // multiple of 4): C dword loads, no funnel shifts, bytes packed with two v_perm.
 template <int C>
 __device__ __forceinline__ uint32_t load_luma4_aligned(const uint8_t *ptr) {
-    const uint32_t *p = reinterpret_cast<const uint32_t *>(ptr);
-    if (C == 1) return p[0];
-    constexpr uint32_t CHI = 0x001D964Cu, CLO = 0x002F468Bu;
-    uint32_t s[4];
+    const uint32_t *q = reinterpret_cast<const uint32_t *>(ptr);
+    if (C == 1) return q[0];
+    uint32_t p[4];
     if (C == 3) {
-        const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
-        const uint32_t p1 = __builtin_amdgcn_alignbyte(d1, d0, 3), p2 = __builtin_amdgcn_alignbyte(d2, d1, 2);
-        s[0] = (__builtin_amdgcn_udot4(d0, CHI, 0u, false) << 8) + __builtin_amdgcn_udot4(d0, CLO, 0x8000u, false);
-        s[1] = (__builtin_amdgcn_udot4(p1, CHI, 0u, false) << 8) + __builtin_amdgcn_udot4(p1, CLO, 0x8000u, false);
-        s[2] = (__builtin_amdgcn_udot4(p2, CHI, 0u, false) << 8) + __builtin_amdgcn_udot4(p2, CLO, 0x8000u, false);
-        s[3] = (__builtin_amdgcn_udot4(d2, CHI << 8, 0u, false) << 8) + __builtin_amdgcn_udot4(d2, CLO << 8, 0x8000u, false);
+        const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
+        p[0] = d0;
+        p[1] = __builtin_amdgcn_alignbyte(d1, d0, 3);
+        p[2] = __builtin_amdgcn_alignbyte(d2, d1, 2);
+        p[3] = d2;
     } else {
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            s[k] = (__builtin_amdgcn_udot4(p[k], CHI, 0u, false) << 8) + __builtin_amdgcn_udot4(p[k], CLO, 0x8000u, false);
+        for (int k = 0; k < 4; ++k) p[k] = q[k % C];
     }
-    return __builtin_amdgcn_perm(s[1], s[0], 0x0C0C0602u) | __builtin_amdgcn_perm(s[3], s[2], 0x06020C0Cu);   // byte 2 of each sum
+    return luma4_from_pixels(p, C == 3);
 }
 
 // x = L/255 in float32, correctly rounded for every L in 0..255 (checked for all 256 values in exact rational
@@ -131,8 +132,10 @@ __global__ __launch_bounds__(256, 2) void ke_ssim_waves(const SsimArgs a) {
     const size_t img_bytes = (size_t)a.w * a.h * C;
     const uint8_t *A = a.images + (size_t)a.pa[pair] * img_bytes;
     const uint8_t *B = a.images + (size_t)a.pb[pair] * img_bytes;
-    const uintptr_t lastA = ((uintptr_t)A + img_bytes - 1) & ~(uintptr_t)3;
-    const uintptr_t lastB = ((uintptr_t)B + img_bytes - 1) & ~(uintptr_t)3;
+    // unaligned loader: dword-aligned bases (wave-uniform) + 32-bit byte offsets
+    const uint32_t dA = (uint32_t)((uintptr_t)A & 3), dB = (uint32_t)((uintptr_t)B & 3);
+    const uint8_t *A0 = A - dA, *B0 = B - dB;
+    const uint32_t lastA = (dA + (uint32_t)img_bytes - 1u) & ~3u, lastB = (dB + (uint32_t)img_bytes - 1u) & ~3u;
     int xc = x0 + PX * lane;                                // this lane's first column
     xc = xc < a.w ? xc : a.w - 1;                           // lanes past the right edge load something valid; never used
     int xq[NW];                                             // AL: first column of each 4-pixel group, kept inside the row
@@ -153,7 +156,7 @@ __global__ __launch_bounds__(256, 2) void ke_ssim_waves(const SsimArgs a) {
     double local = 0.0;
     const int y_last = y_int_end + 3;                       // one past the last halo row
     for (int y = y0; y < y_last; ++y) {
-        const size_t off = ((size_t)y * a.w + xc) * C;
+        const uint32_t off = ((uint32_t)y * (uint32_t)a.w + (uint32_t)xc) * C;
         uint32_t na[NW], nb[NW];
 #pragma unroll
         for (int n = 0; n < NW; ++n) {
@@ -162,8 +165,8 @@ __global__ __launch_bounds__(256, 2) void ke_ssim_waves(const SsimArgs a) {
                 na[n] = load_luma4_aligned<C>(A + o);
                 nb[n] = load_luma4_aligned<C>(B + o);
             } else {
-                na[n] = load_luma4<C>((uintptr_t)A + off + (size_t)n * 4 * C, lastA);
-                nb[n] = load_luma4<C>((uintptr_t)B + off + (size_t)n * 4 * C, lastB);
+                na[n] = load_luma4<C>(A0, dA + off + (uint32_t)n * 4 * C, lastA);
+                nb[n] = load_luma4<C>(B0, dB + off + (uint32_t)n * 4 * C, lastB);
             }
         }
         // slide: drop the oldest row, add the new one.  The first six rows of a band subtract the zeros the
@@ -261,6 +264,7 @@ int ke_launch_ssim(ke_ctx *ctx, const uint8_t *d_images, int w, int h, int chann
         KE_HIP(ctx, hipGetLastError());
         return KE_OK;
     }
+    if ((int64_t)w * h * channels >= (1LL << 31)) return ke_fail(ctx, KE_EUNSUPPORTED, "image too large for the SSIM kernel");
     SsimArgs a;
     a.images = d_images; a.pa = d_pa; a.pb = d_pb;
     a.w = w; a.h = h;

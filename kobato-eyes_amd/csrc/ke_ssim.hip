@@ -87,16 +87,14 @@ __device__ __forceinline__ uint32_t load_luma4(const uint8_t *base, uint32_t off
 // The same four luma bytes when the quad starts on a dword boundary (rows of a multiple of 4 pixels, lane columns a
 // multiple of 4): C dword loads, no funnel shifts, bytes packed with two v_perm.
 template <int C>
-__device__ __forceinline__ uint32_t load_luma4_aligned(const uint8_t *ptr) {
-    const uint32_t *q = reinterpret_cast<const uint32_t *>(ptr);
+__device__ __forceinline__ uint32_t luma4_of_aligned(const uint32_t *q) {     // q: the C dwords of an aligned quad
     if (C == 1) return q[0];
     uint32_t p[4];
     if (C == 3) {
-        const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
-        p[0] = d0;
-        p[1] = __builtin_amdgcn_alignbyte(d1, d0, 3);
-        p[2] = __builtin_amdgcn_alignbyte(d2, d1, 2);
-        p[3] = d2;
+        p[0] = q[0];
+        p[1] = __builtin_amdgcn_alignbyte(q[1], q[0], 3);
+        p[2] = __builtin_amdgcn_alignbyte(q[2 % C], q[1], 2);
+        p[3] = q[2 % C];
     } else {
 #pragma unroll
         for (int k = 0; k < 4; ++k) p[k] = q[k % C];
@@ -155,15 +153,38 @@ __global__ __launch_bounds__(256, 2) void ke_ssim_waves(const SsimArgs a) {
     const float C1 = (float)(0.01 * 0.01), C2 = (float)(0.03 * 0.03);
     double local = 0.0;
     const int y_last = y_int_end + 3;                       // one past the last halo row
+    // AL with 8 pixels per lane (2 waves/SIMD): the next row's quads are fetched one iteration ahead (raw dwords), so their
+    // latency hides behind the arithmetic (+5 % at 512x512; with 4 pixels per lane the extra registers cost more than it gains)
+    constexpr bool PF = AL && PX == 8;
+    uint32_t qa[NW][C], qb[NW][C];
+    auto fetch = [&](int y) {
+        const int yc = min(y, y_last - 1);
+#pragma unroll
+        for (int n = 0; n < NW; ++n) {
+            const uint32_t o = ((uint32_t)yc * (uint32_t)a.w + (uint32_t)xq[n]) * C;
+#pragma unroll
+            for (int k = 0; k < C; ++k) {
+                qa[n][k] = reinterpret_cast<const uint32_t *>(A + o)[k];
+                qb[n][k] = reinterpret_cast<const uint32_t *>(B + o)[k];
+            }
+        }
+    };
+    if (PF) fetch(y0);
     for (int y = y0; y < y_last; ++y) {
         const uint32_t off = ((uint32_t)y * (uint32_t)a.w + (uint32_t)xc) * C;
         uint32_t na[NW], nb[NW];
+        if (PF) {
+#pragma unroll
+            for (int n = 0; n < NW; ++n) { na[n] = luma4_of_aligned<C>(qa[n]); nb[n] = luma4_of_aligned<C>(qb[n]); }
+            fetch(y + 1);
+        }
 #pragma unroll
         for (int n = 0; n < NW; ++n) {
-            if (AL) {
-                const size_t o = ((size_t)y * a.w + xq[n]) * C;
-                na[n] = load_luma4_aligned<C>(A + o);
-                nb[n] = load_luma4_aligned<C>(B + o);
+            if (PF) {
+            } else if (AL) {
+                const uint32_t o = ((uint32_t)y * (uint32_t)a.w + (uint32_t)xq[n]) * C;
+                na[n] = luma4_of_aligned<C>(reinterpret_cast<const uint32_t *>(A + o));
+                nb[n] = luma4_of_aligned<C>(reinterpret_cast<const uint32_t *>(B + o));
             } else {
                 na[n] = load_luma4<C>(A0, dA + off + (uint32_t)n * 4 * C, lastA);
                 nb[n] = load_luma4<C>(B0, dB + off + (uint32_t)n * 4 * C, lastB);

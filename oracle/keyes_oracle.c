@@ -391,14 +391,30 @@ static inline uint64_t ko_splitmix64(uint64_t z) {
 #define KO_P2 0xCA5A826395121157ull
 #define KO_P3 0x9E6C63D0676A9A99ull
 
-static inline void ko_synth_identity(uint64_t seed, int64_t i, int64_t *base, int *delta, int *is_variant) {
+/* Identity of corpus image i.  Ordinary images are their own base.  Every index = 9 (mod 10) from 19 on is a
+ * VARIANT of an earlier base: brightness shift delta in [-3, 3] and a fraction cell_q/32 of the 16x16 cells
+ * replaced.  Two variant classes:
+ *   ordinary  : fresh per-pixel noise (noise_index = i), cell_q = 1  -> SSIM vs the base 0.886-0.945;
+ *   low-noise : from index 1000 on, variants with bit 52 of r set REUSE THE BASE'S per-pixel noise
+ *               (noise_index = base) and replace cell_q = 1..4 of 32 cells -> SSIM vs the base spreads over
+ *               roughly 0.93-0.99, so the reference's ssim_threshold = 0.95 cuts inside the class (BASELINE
+ *               configs[3]).  The first 1000 images (BASELINE configs[0]) are as in round 1. */
+#define KO_SYNTH_LOWNOISE_FROM 1000
+static inline void ko_synth_identity2(uint64_t seed, int64_t i, int64_t *base, int *delta, int *is_variant,
+                                      int64_t *noise_index, int *cell_q) {
     uint64_t r = ko_splitmix64(seed ^ (0x51ED270B0E3A6F5Dull + (uint64_t)i * KO_P1));
     *is_variant = (i >= 10) && (i % 10 == 9);
+    *noise_index = i;
+    *cell_q = 1;
     if (*is_variant) {
         int64_t c = (int64_t)((r >> 8) % (uint64_t)i);
         if (c % 10 == 9) c -= 1;
         *base = c;
         *delta = (int)((r >> 44) % 7) - 3;
+        if (i >= KO_SYNTH_LOWNOISE_FROM && ((r >> 52) & 1)) {
+            *noise_index = c;
+            *cell_q = 1 + (int)((r >> 53) & 3);
+        }
     } else {
         *base = i;
         *delta = 0;
@@ -407,14 +423,22 @@ static inline void ko_synth_identity(uint64_t seed, int64_t i, int64_t *base, in
 
 /* (base index, brightness delta, is_variant) of corpus image `index`. */
 KO_API void ko_synth_info(uint64_t seed, int64_t index, int64_t *base, int32_t *delta, int32_t *is_variant) {
-    int d, v;
-    ko_synth_identity(seed, index, base, &d, &v);
+    int d, v, q; int64_t ni;
+    ko_synth_identity2(seed, index, base, &d, &v, &ni, &q);
     *delta = d; *is_variant = v;
 }
 
+/* the same plus the variant class: low_noise = 1 when the variant reuses its base's noise, cell_q = replaced cells per 32 */
+KO_API void ko_synth_info2(uint64_t seed, int64_t index, int64_t *base, int32_t *delta, int32_t *is_variant,
+                           int32_t *low_noise, int32_t *cell_q) {
+    int d, v, q; int64_t ni;
+    ko_synth_identity2(seed, index, base, &d, &v, &ni, &q);
+    *delta = d; *is_variant = v; *low_noise = (ni != index); *cell_q = q;
+}
+
 KO_API void ko_synth_rgb(uint64_t seed, int64_t index, int w, int h, uint8_t *out) {
-    int64_t base; int delta, variant;
-    ko_synth_identity(seed, index, &base, &delta, &variant);
+    int64_t base, noise_index; int delta, variant, cell_q;
+    ko_synth_identity2(seed, index, &base, &delta, &variant, &noise_index, &cell_q);
     for (int y = 0; y < h; y++) {
         int cy = (int)(((int64_t)y * 16) / h);
         for (int x = 0; x < w; x++) {
@@ -422,9 +446,9 @@ KO_API void ko_synth_rgb(uint64_t seed, int64_t index, int w, int h, uint8_t *ou
             uint64_t cell = ko_splitmix64((seed + 1) ^ ((uint64_t)base * KO_P1 + (uint64_t)cy * KO_P2 + (uint64_t)cx * KO_P3));
             if (variant) {
                 uint64_t m = ko_splitmix64((seed + 2) ^ ((uint64_t)index * KO_P1 + (uint64_t)cy * KO_P2 + (uint64_t)cx * KO_P3));
-                if ((m & 31) == 0) cell = m >> 8;
+                if ((int)(m & 31) < cell_q) cell = m >> 8;
             }
-            uint64_t u = ko_splitmix64(seed ^ ((uint64_t)index * KO_P1 + (uint64_t)y * KO_P2 + (uint64_t)x * KO_P3));
+            uint64_t u = ko_splitmix64(seed ^ ((uint64_t)noise_index * KO_P1 + (uint64_t)y * KO_P2 + (uint64_t)x * KO_P3));
             uint8_t *p = out + ((size_t)y * w + x) * 3;
             for (int c = 0; c < 3; c++) {
                 int v = (int)((cell >> (8 * c)) & 0xFF) + (int)((u >> (20 * c)) & 7) - 4 + delta;

@@ -77,6 +77,8 @@ def lib() -> C.CDLL:
         L.ko_synth_rgb.restype = None
         L.ko_synth_info.argtypes = [C.c_uint64, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.ko_synth_info.restype = None
+        L.ko_synth_info2.argtypes = [C.c_uint64, C.c_int64, C.POINTER(C.c_int64)] + [C.POINTER(C.c_int32)] * 4
+        L.ko_synth_info2.restype = None
         L.ko_synth_hashes.argtypes = [C.c_uint64, C.c_int64, C.c_void_p]
         L.ko_synth_hashes.restype = None
         L.ko_scan_banded.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int,
@@ -253,6 +255,13 @@ def synth_info(index: int, seed: int = SEED) -> tuple[int, int, bool]:
     b, d, v = C.c_int64(), C.c_int32(), C.c_int32()
     lib().ko_synth_info(seed, index, C.byref(b), C.byref(d), C.byref(v))
     return int(b.value), int(d.value), bool(v.value)
+
+
+def synth_info2(index: int, seed: int = SEED) -> tuple[int, int, bool, bool, int]:
+    """(base, delta, is_variant, low_noise, replaced cells per 32): the variant class of corpus image `index`."""
+    b, d, v, ln, q = C.c_int64(), C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+    lib().ko_synth_info2(seed, index, C.byref(b), C.byref(d), C.byref(v), C.byref(ln), C.byref(q))
+    return int(b.value), int(d.value), bool(v.value), bool(ln.value), int(q.value)
 
 
 def synth_rgb_batch(first: int, n: int, w: int, h: int, seed: int = SEED) -> np.ndarray:

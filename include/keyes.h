@@ -79,7 +79,9 @@ int ke_memcpy(ke_ctx *ctx, void *dst, const void *src, size_t bytes);   /* any d
  * n interleaved 8-bit images.  channels: 1 (mode "L"), 3 (RGB) or 4 (RGBX/RGBA; the fourth
  * byte is ignored, as Pillow's convert("L") ignores it).  Image i starts at
  * pixels + offsets[i] (offsets == NULL: images are packed back to back) and is
- * heights[i] rows of widths[i]*channels bytes, no row padding.
+ * heights[i] rows of widths[i]*channels bytes, no row padding.  Any byte offset is accepted; the fastest kernels
+ * are used for size groups whose images all start on a 4-byte boundary (pad offsets to a multiple of 4 -- the Python
+ * host pads to 16 -- when packing a device-resident batch).
  * phash_out / dhash_out: unsigned 64-bit hashes (either may be NULL).  The signed wrap of
  * src/sig/phash.py:29-30 / src/core/fastsig.py:19-21 is the host's reinterpretation.
  * status_out (nullable): KE_IMG_* per image; hashes of failed images are 0.
@@ -95,6 +97,17 @@ int ke_hash_images(ke_ctx *ctx, const uint8_t *pixels, const uint64_t *offsets, 
 /* Same, n equally sized images packed back to back (the BASELINE configs). */
 int ke_hash_uniform(ke_ctx *ctx, const uint8_t *pixels, int64_t n, int32_t width, int32_t height,
                     int32_t channels, uint64_t *phash_out, uint64_t *dhash_out);
+
+/* The same two calls with one more output: margin_out[i] (float32, host or device, nullable) = min over the 64 DCT
+ * coefficients of |coef - mean(AC)| for image i, i.e. the distance of the closest bit decision `coef > mean`
+ * (src/sig/phash.py:41-42) from a tie.  pHash bits can only differ between DCT implementations (this library's folded
+ * fp64 DCT vs OpenCV's float32 cv2.dct, src/sig/phash.py:38) where this margin is of the order of the implementations'
+ * rounding differences (~1e-4 and below); callers count such images to know their exposure.  Needs phash_out. */
+int ke_hash_uniform_ex(ke_ctx *ctx, const uint8_t *pixels, int64_t n, int32_t width, int32_t height,
+                       int32_t channels, uint64_t *phash_out, uint64_t *dhash_out, float *margin_out);
+int ke_hash_images_ex(ke_ctx *ctx, const uint8_t *pixels, const uint64_t *offsets, const int32_t *widths,
+                      const int32_t *heights, int32_t channels, int64_t n, uint64_t *phash_out,
+                      uint64_t *dhash_out, int32_t *status_out, float *margin_out);
 
 /* Debug/parity hook: the resampled luma tiles the hashes are computed from
  * (reference sig.phash._to_grayscale, src/sig/phash.py:21-26).  tile32_out: n*1024 bytes
@@ -132,6 +145,14 @@ int ke_cluster_labels(const ke_edge *edges, int64_t n_edges, int64_t n_nodes, in
  * pairs of equally sized images.  images: n_images interleaved images of width x height x
  * channels (1, 3 or 4; luma is taken exactly as convert("L") does), packed back to back.
  * pair_a/pair_b index into them.  ssim_out[k] is NaN when width or height < 7. */
+/* Two kernels compute it.  KE_SSIM_FAST (default): every 7x7 window sum is an exact integer (luma 0..255) carried in
+ * float32, variances formed without cancellation error -- equal to skimage's float32 arithmetic up to what skimage's own
+ * intermediates round away (measured |delta| < 1e-5; the bar of BASELINE.json is 1e-4); images of fewer than 4096
+ * windows ((w-6)*(h-6)) always take the exact kernel, where a single window's rounding is not averaged out.  KE_SSIM_EXACT: every float32 /
+ * float64 rounding of scipy.ndimage.uniform_filter and of skimage's elementwise steps reproduced one by one, bit-identical
+ * to the oracle, 3-4x slower. */
+enum { KE_SSIM_FAST = 0, KE_SSIM_EXACT = 1 };
+int ke_ssim_set_mode(ke_ctx *ctx, int32_t mode);
 int ke_ssim_pairs_uniform(ke_ctx *ctx, const uint8_t *images, int64_t n_images, int32_t width,
                           int32_t height, int32_t channels, const int64_t *pair_a, const int64_t *pair_b,
                           int64_t n_pairs, double *ssim_out);

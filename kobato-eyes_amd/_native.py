@@ -25,8 +25,8 @@ FILTER_LANCZOS, FILTER_BILINEAR, FILTER_BICUBIC = 0, 1, 2   # include/keyes.h KE
 EXPORTS = (
     "ke_abi_version", "ke_create", "ke_create_error", "ke_destroy", "ke_last_error", "ke_set_stream",
     "ke_get_stream", "ke_synchronize", "ke_device_info", "ke_malloc", "ke_free", "ke_memcpy",
-    "ke_hash_images", "ke_hash_uniform", "ke_luma_tiles_uniform", "ke_hamming_scan", "ke_cluster_labels",
-    "ke_ssim_pairs_uniform", "ke_resize_luma_uniform", "ke_fit_luma_uniform", "ke_tile_ahash", "ke_sad_pairs", "ke_synth_rgb",
+    "ke_hash_images", "ke_hash_uniform", "ke_hash_images_ex", "ke_hash_uniform_ex", "ke_luma_tiles_uniform", "ke_hamming_scan",
+    "ke_cluster_labels", "ke_ssim_pairs_uniform", "ke_ssim_set_mode", "ke_resize_luma_uniform", "ke_fit_luma_uniform", "ke_tile_ahash", "ke_sad_pairs", "ke_synth_rgb",
     "ke_synth_rgb_indexed",
     "ke_synth_hashes", "ke_last_kernel_ms",
 )
@@ -73,11 +73,14 @@ def load_library() -> C.CDLL:
         lib.ke_memcpy.argtypes = [vp, vp, vp, C.c_size_t]
         lib.ke_hash_images.argtypes = [vp, vp, vp, vp, vp, i32, i64, vp, vp, vp]
         lib.ke_hash_uniform.argtypes = [vp, vp, i64, i32, i32, i32, vp, vp]
+        lib.ke_hash_images_ex.argtypes = [vp, vp, vp, vp, vp, i32, i64, vp, vp, vp, vp]
+        lib.ke_hash_uniform_ex.argtypes = [vp, vp, i64, i32, i32, i32, vp, vp, vp]
         lib.ke_luma_tiles_uniform.argtypes = [vp, vp, i64, i32, i32, i32, vp, vp]
         lib.ke_hamming_scan.argtypes = [vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, dbl, i64, vp, i64,
                                         C.POINTER(i64), vp]
         lib.ke_cluster_labels.argtypes = [vp, i64, i64, vp]
         lib.ke_ssim_pairs_uniform.argtypes = [vp, vp, i64, i32, i32, i32, vp, vp, i64, vp]
+        lib.ke_ssim_set_mode.argtypes = [vp, i32]
         lib.ke_resize_luma_uniform.argtypes = [vp, vp, i64, i32, i32, i32, i32, i32, i32, vp]
         lib.ke_fit_luma_uniform.argtypes = [vp, vp, i64, i32, i32, i32, i32, i32, i32, vp]
         lib.ke_tile_ahash.argtypes = [vp, vp, i64, i32, i32, vp]
@@ -88,8 +91,8 @@ def load_library() -> C.CDLL:
         lib.ke_last_kernel_ms.argtypes = [vp, i32]
         lib.ke_last_kernel_ms.restype = dbl
         for name in ("ke_set_stream", "ke_synchronize", "ke_device_info", "ke_malloc", "ke_free", "ke_memcpy",
-                     "ke_hash_images", "ke_hash_uniform", "ke_luma_tiles_uniform", "ke_hamming_scan",
-                     "ke_cluster_labels", "ke_ssim_pairs_uniform", "ke_resize_luma_uniform", "ke_fit_luma_uniform", "ke_tile_ahash",
+                     "ke_hash_images", "ke_hash_uniform", "ke_hash_images_ex", "ke_hash_uniform_ex", "ke_luma_tiles_uniform", "ke_hamming_scan",
+                     "ke_cluster_labels", "ke_ssim_pairs_uniform", "ke_ssim_set_mode", "ke_resize_luma_uniform", "ke_fit_luma_uniform", "ke_tile_ahash",
                      "ke_sad_pairs", "ke_synth_rgb", "ke_synth_rgb_indexed", "ke_synth_hashes"):
             getattr(lib, name).restype = C.c_int
         _lib = lib
@@ -169,9 +172,10 @@ class Context:
 
     # -- hashing ----------------------------------------------------------------------------
     def hash_uniform(self, pixels, n: int, width: int, height: int, channels: int, *, want_phash=True,
-                     want_dhash=True, phash_out=None, dhash_out=None):
+                     want_dhash=True, phash_out=None, dhash_out=None, margin_out=None):
         """pixels: host ndarray (n,h,w[,c]) u8 or a device pointer.  Returns (phash u64[n] | None, dhash | None)
-        as host arrays unless explicit output buffers (host arrays or device pointers) are given."""
+        as host arrays unless explicit output buffers (host arrays or device pointers) are given.
+        margin_out: float32[n] host array or device pointer that receives the pHash tie margins (ke_hash_uniform_ex)."""
         if isinstance(pixels, np.ndarray):
             pixels = np.ascontiguousarray(pixels, dtype=np.uint8)
             if pixels.size != n * width * height * channels:
@@ -179,8 +183,12 @@ class Context:
         ph = phash_out if phash_out is not None else (np.empty(n, np.uint64) if want_phash else None)
         dh = dhash_out if dhash_out is not None else (np.empty(n, np.uint64) if want_dhash else None)
         with self._lock:
-            self._check(self._lib.ke_hash_uniform(self._h, _addr(pixels), n, width, height, channels, _addr(ph),
-                                                  _addr(dh)), "ke_hash_uniform")
+            if margin_out is not None:
+                self._check(self._lib.ke_hash_uniform_ex(self._h, _addr(pixels), n, width, height, channels, _addr(ph),
+                                                         _addr(dh), _addr(margin_out)), "ke_hash_uniform_ex")
+            else:
+                self._check(self._lib.ke_hash_uniform(self._h, _addr(pixels), n, width, height, channels, _addr(ph),
+                                                      _addr(dh)), "ke_hash_uniform")
         return ph, dh
 
     def luma_tiles_uniform(self, pixels, n: int, width: int, height: int, channels: int, *, want32=True, want98=True):
@@ -193,8 +201,9 @@ class Context:
                                                         _addr(t98)), "ke_luma_tiles_uniform")
         return t32, t98
 
-    def hash_images(self, images: Sequence[np.ndarray], *, want_dhash=True):
-        """Ragged batch of host images sharing one channel count.  Returns (phash, dhash|None, status)."""
+    def hash_images(self, images: Sequence[np.ndarray], *, want_dhash=True, want_margin=False):
+        """Ragged batch of host images sharing one channel count.  Returns (phash, dhash|None, status), plus the
+        float32 tie margins as a fourth item with ``want_margin``."""
         n = len(images)
         if n == 0:
             return np.empty(0, np.uint64), (np.empty(0, np.uint64) if want_dhash else None), np.empty(0, np.int32)
@@ -205,18 +214,20 @@ class Context:
         widths = np.array([im.shape[1] for im in images], np.int32)
         heights = np.array([im.shape[0] for im in images], np.int32)
         sizes = widths.astype(np.int64) * heights * ch
+        padded = (sizes + 15) & ~np.int64(15)          # every image starts on a 16-byte boundary (see keyes.h)
         offsets = np.zeros(n, np.uint64)
-        offsets[1:] = np.cumsum(sizes[:-1]).astype(np.uint64)
-        flat = np.empty(int(sizes.sum()), np.uint8)
+        offsets[1:] = np.cumsum(padded[:-1]).astype(np.uint64)
+        flat = np.zeros(int(padded.sum()), np.uint8)
         for im, off, sz in zip(images, offsets, sizes):
             flat[int(off):int(off) + int(sz)] = np.ascontiguousarray(im, dtype=np.uint8).reshape(-1)
         ph = np.empty(n, np.uint64)
         dh = np.empty(n, np.uint64) if want_dhash else None
         status = np.empty(n, np.int32)
+        margin = np.empty(n, np.float32) if want_margin else None
         with self._lock:
-            self._check(self._lib.ke_hash_images(self._h, _addr(flat), _addr(offsets), _addr(widths), _addr(heights), ch, n,
-                                                 _addr(ph), _addr(dh), _addr(status)), "ke_hash_images")
-        return ph, dh, status
+            self._check(self._lib.ke_hash_images_ex(self._h, _addr(flat), _addr(offsets), _addr(widths), _addr(heights), ch, n,
+                                                    _addr(ph), _addr(dh), _addr(status), _addr(margin)), "ke_hash_images_ex")
+        return (ph, dh, status, margin) if want_margin else (ph, dh, status)
 
     # -- scan -------------------------------------------------------------------------------
     def hamming_scan(self, hashes, n: int, *, ids=None, sizes=None, threshold=8, band_bits=16, band_count=4,
@@ -250,6 +261,11 @@ class Context:
         return labels
 
     # -- ssim -------------------------------------------------------------------------------
+    def ssim_set_mode(self, exact: bool) -> None:
+        """False (default): integer-sum kernel, within 1e-5 of skimage's float32 arithmetic; True: the kernel that
+        reproduces every rounding (bit-identical to the oracle, 3-4x slower)."""
+        self._check(self._lib.ke_ssim_set_mode(self._h, 1 if exact else 0), "ke_ssim_set_mode")
+
     def ssim_pairs_uniform(self, images, n_images: int, width: int, height: int, channels: int, pair_a, pair_b):
         if isinstance(images, np.ndarray):
             images = np.ascontiguousarray(images, dtype=np.uint8)

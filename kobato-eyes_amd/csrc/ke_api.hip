@@ -296,17 +296,25 @@ struct HashOutputs {
 // Chunk size for host-resident pixel input: bounded staging buffer.
 constexpr size_t kStageBytes = (size_t)1 << 30;
 
+struct MarginScope {   // the kernels of one call find the margin array in the context; cleared on every exit path
+    ke_ctx *ctx;
+    ~MarginScope() { ctx->margin_cur = nullptr; }
+};
+
 int hash_uniform_impl(ke_ctx *ctx, const uint8_t *pixels, int64_t n, int w, int h, int ch, uint64_t *phash_out,
-                      uint64_t *dhash_out, uint8_t *t32_out, uint8_t *t98_out) {
+                      uint64_t *dhash_out, uint8_t *t32_out, uint8_t *t98_out, float *margin_out = nullptr) {
     if (!ctx) return KE_EINVAL;
     if (n < 0 || (n > 0 && !pixels)) return ke_fail(ctx, KE_EINVAL, "pixels is NULL");
     if (w <= 0 || h <= 0) return ke_fail(ctx, KE_EINVAL, "width/height must be positive (got %dx%d)", w, h);
     if (ch != 1 && ch != 3 && ch != 4) return ke_fail(ctx, KE_EINVAL, "channels must be 1, 3 or 4 (got %d)", ch);
+    if (margin_out && !phash_out) return ke_fail(ctx, KE_EINVAL, "margin_out needs phash_out");
     if (n == 0) return KE_OK;
     KE_HIP(ctx, hipSetDevice(ctx->device));
     trim_coeff_cache(ctx);
     const size_t img_bytes = (size_t)w * h * ch;
     const bool in_dev = ke_is_device_ptr(pixels);
+    const bool stage_m = margin_out && !ke_is_device_ptr(margin_out);
+    MarginScope margin_scope{ctx};
     HashOutputs o;
     o.stage_p = phash_out && !ke_is_device_ptr(phash_out);
     o.stage_d = dhash_out && !ke_is_device_ptr(dhash_out);
@@ -325,6 +333,8 @@ int hash_uniform_impl(ke_ctx *ctx, const uint8_t *pixels, int64_t n, int w, int 
         o.d_t98 = t98_out ? t98_out + (size_t)first * 72 : nullptr;
         if (o.stage_p) { KE_TRY(ke_reserve(ctx, KE_BUF_OUT0, (size_t)m * 8, &tmp)); o.d_phash = (uint64_t *)tmp; }
         if (o.stage_d) { KE_TRY(ke_reserve(ctx, KE_BUF_OUT1, (size_t)m * 8, &tmp)); o.d_dhash = (uint64_t *)tmp; }
+        ctx->margin_cur = margin_out ? margin_out + first : nullptr;
+        if (stage_m) { KE_TRY(ke_reserve(ctx, KE_BUF_OUT2, (size_t)m * 4, &tmp)); ctx->margin_cur = (float *)tmp; }
         // tiles requested by a host caller are produced straight into the scratch tile buffers
         KeHashGroup g{(const uint8_t *)d_px, nullptr, img_bytes, nullptr, m, w, h, ch};
         uint8_t *d_t32 = o.stage_t32 ? nullptr : o.d_t32, *d_t98 = o.stage_t98 ? nullptr : o.d_t98;
@@ -335,11 +345,13 @@ int hash_uniform_impl(ke_ctx *ctx, const uint8_t *pixels, int64_t n, int w, int 
             KE_HIP(ctx, hipMemcpyAsync(phash_out + first, o.d_phash, (size_t)m * 8, hipMemcpyDeviceToHost, ctx->stream));
         if (o.stage_d)
             KE_HIP(ctx, hipMemcpyAsync(dhash_out + first, o.d_dhash, (size_t)m * 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (stage_m)
+            KE_HIP(ctx, hipMemcpyAsync(margin_out + first, ctx->margin_cur, (size_t)m * 4, hipMemcpyDeviceToHost, ctx->stream));
         if (o.stage_t32)
             KE_HIP(ctx, hipMemcpyAsync(t32_out + (size_t)first * 1024, d_t32, (size_t)m * 1024, hipMemcpyDeviceToHost, ctx->stream));
         if (o.stage_t98)
             KE_HIP(ctx, hipMemcpyAsync(t98_out + (size_t)first * 72, d_t98, (size_t)m * 72, hipMemcpyDeviceToHost, ctx->stream));
-        if (!in_dev || o.stage_p || o.stage_d || o.stage_t32 || o.stage_t98)
+        if (!in_dev || o.stage_p || o.stage_d || o.stage_t32 || o.stage_t98 || stage_m)
             KE_HIP(ctx, hipStreamSynchronize(ctx->stream));  // staging buffers are reused by the next chunk
     }
     ke_time_end(ctx, KE_T_HASH);
@@ -353,15 +365,21 @@ KE_API int ke_hash_uniform(ke_ctx *ctx, const uint8_t *pixels, int64_t n, int32_
     return hash_uniform_impl(ctx, pixels, n, width, height, channels, phash_out, dhash_out, nullptr, nullptr);
 }
 
+KE_API int ke_hash_uniform_ex(ke_ctx *ctx, const uint8_t *pixels, int64_t n, int32_t width, int32_t height,
+                              int32_t channels, uint64_t *phash_out, uint64_t *dhash_out, float *margin_out) {
+    return hash_uniform_impl(ctx, pixels, n, width, height, channels, phash_out, dhash_out, nullptr, nullptr, margin_out);
+}
+
 KE_API int ke_luma_tiles_uniform(ke_ctx *ctx, const uint8_t *pixels, int64_t n, int32_t width, int32_t height,
                                  int32_t channels, uint8_t *tile32_out, uint8_t *tile98_out) {
     return hash_uniform_impl(ctx, pixels, n, width, height, channels, nullptr, nullptr, tile32_out, tile98_out);
 }
 
-KE_API int ke_hash_images(ke_ctx *ctx, const uint8_t *pixels, const uint64_t *offsets, const int32_t *widths,
-                          const int32_t *heights, int32_t channels, int64_t n, uint64_t *phash_out,
-                          uint64_t *dhash_out, int32_t *status_out) {
+static int hash_images_impl(ke_ctx *ctx, const uint8_t *pixels, const uint64_t *offsets, const int32_t *widths,
+                            const int32_t *heights, int32_t channels, int64_t n, uint64_t *phash_out,
+                            uint64_t *dhash_out, int32_t *status_out, float *margin_out) {
     if (!ctx) return KE_EINVAL;
+    if (margin_out && !phash_out) return ke_fail(ctx, KE_EINVAL, "margin_out needs phash_out");
     if (n < 0 || (n > 0 && (!pixels || !widths || !heights)))
         return ke_fail(ctx, KE_EINVAL, "pixels/widths/heights must be non-NULL");
     if (channels != 1 && channels != 3 && channels != 4)
@@ -400,6 +418,13 @@ KE_API int ke_hash_images(ke_ctx *ctx, const uint8_t *pixels, const uint64_t *of
         else { KE_TRY(ke_reserve(ctx, KE_BUF_OUT1, (size_t)n * 8, &tmp)); d_dh = (uint64_t *)tmp; }
         KE_HIP(ctx, hipMemsetAsync(d_dh, 0, (size_t)n * 8, ctx->stream));
     }
+    const bool m_dev = margin_out && ke_is_device_ptr(margin_out);
+    MarginScope margin_scope{ctx};
+    if (margin_out) {
+        if (m_dev) ctx->margin_cur = margin_out;
+        else { KE_TRY(ke_reserve(ctx, KE_BUF_OUT2, (size_t)n * 4, &tmp)); ctx->margin_cur = (float *)tmp; }
+        KE_HIP(ctx, hipMemsetAsync(ctx->margin_cur, 0, (size_t)n * 4, ctx->stream));
+    }
     ke_time_begin(ctx, KE_T_HASH);
     if (in_dev) {
         // device-resident batch: one metadata upload for all shape groups ([offsets | output slots] per group),
@@ -426,6 +451,10 @@ KE_API int ke_hash_images(ke_ctx *ctx, const uint8_t *pixels, const uint64_t *of
             const uint64_t *d_off = (const uint64_t *)meta + spans[gi].first;
             const int64_t m = (int64_t)spans[gi].second;
             KeHashGroup g{pixels, d_off, (uint64_t)w * h * channels, (const int64_t *)(d_off + m), m, w, h, channels};
+            // the dword loaders of the single-pass and aligned banded kernels want every image of the group on a dword
+            // boundary; a packed stream loses that after the first image whose byte size is not a multiple of 4
+            for (int64_t idx : kv.second)
+                if (((uintptr_t)pixels + off[idx]) % 4 != 0) { g.misaligned = true; break; }
             KE_TRY(ke_launch_hash_group(ctx, g, d_ph, d_dh, nullptr, nullptr));
             ++gi;
         }
@@ -463,8 +492,22 @@ KE_API int ke_hash_images(ke_ctx *ctx, const uint8_t *pixels, const uint64_t *of
         KE_HIP(ctx, hipMemcpyAsync(phash_out, d_ph, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
     if (dhash_out && !d_dev)
         KE_HIP(ctx, hipMemcpyAsync(dhash_out, d_dh, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (margin_out && !m_dev)
+        KE_HIP(ctx, hipMemcpyAsync(margin_out, ctx->margin_cur, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
     KE_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return KE_OK;
+}
+
+KE_API int ke_hash_images(ke_ctx *ctx, const uint8_t *pixels, const uint64_t *offsets, const int32_t *widths,
+                          const int32_t *heights, int32_t channels, int64_t n, uint64_t *phash_out,
+                          uint64_t *dhash_out, int32_t *status_out) {
+    return hash_images_impl(ctx, pixels, offsets, widths, heights, channels, n, phash_out, dhash_out, status_out, nullptr);
+}
+
+KE_API int ke_hash_images_ex(ke_ctx *ctx, const uint8_t *pixels, const uint64_t *offsets, const int32_t *widths,
+                             const int32_t *heights, int32_t channels, int64_t n, uint64_t *phash_out,
+                             uint64_t *dhash_out, int32_t *status_out, float *margin_out) {
+    return hash_images_impl(ctx, pixels, offsets, widths, heights, channels, n, phash_out, dhash_out, status_out, margin_out);
 }
 
 // ---- scan ------------------------------------------------------------------------------------
@@ -543,6 +586,13 @@ KE_API int ke_hamming_scan(ke_ctx *ctx, const uint64_t *hashes, const int64_t *i
 }
 
 // ---- ssim ------------------------------------------------------------------------------------
+KE_API int ke_ssim_set_mode(ke_ctx *ctx, int32_t mode) {
+    if (!ctx) return KE_EINVAL;
+    if (mode != KE_SSIM_FAST && mode != KE_SSIM_EXACT) return ke_fail(ctx, KE_EINVAL, "unknown SSIM mode %d", mode);
+    ctx->ssim_exact = mode == KE_SSIM_EXACT;
+    return KE_OK;
+}
+
 KE_API int ke_ssim_pairs_uniform(ke_ctx *ctx, const uint8_t *images, int64_t n_images, int32_t width, int32_t height,
                                  int32_t channels, const int64_t *pair_a, const int64_t *pair_b, int64_t n_pairs,
                                  double *ssim_out) {

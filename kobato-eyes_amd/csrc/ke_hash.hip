@@ -116,7 +116,9 @@ __device__ double dct32_one(const double *x, int k) {
 
 // tile: 32x32 u8 in LDS; Td: 256 doubles in LDS; cf: 64 floats in LDS.  All 256 threads of
 // the workgroup call this; the hash is returned in thread 0 (undefined elsewhere).
-__device__ uint64_t tile32_to_phash(const uint8_t *tile, double *Td, float *cf, int tid) {
+// margin (nullable): min over the 64 coefficients of |coef - mean| in float32 -- how close the image is to a tie of the
+// bit decision `coef > mean` (src/sig/phash.py:41-42), the one place where another DCT implementation could differ.
+__device__ uint64_t tile32_to_phash(const uint8_t *tile, double *Td, float *cf, int tid, float *margin = nullptr) {
     {
         const int y = tid >> 3, kx = tid & 7;
         double x[32];
@@ -152,6 +154,12 @@ __device__ uint64_t tile32_to_phash(const uint8_t *tile, double *Td, float *cf, 
         const float mean = res / 63.0f;
         const unsigned long long m = __ballot(cf[tid] > mean);  // lane i <-> flat[i]
         hash = __brevll(m);                                     // flat[0] is the MSB (:43-45)
+        if (margin) {                                           // workgroup-uniform
+            float mg = fabsf(cf[tid] - mean);
+#pragma unroll
+            for (int s = 32; s > 0; s >>= 1) mg = fminf(mg, __shfl_xor(mg, s));
+            if (tid == 0) *margin = mg;
+        }
     }
     return hash;
 }
@@ -159,7 +167,8 @@ __device__ uint64_t tile32_to_phash(const uint8_t *tile, double *Td, float *cf, 
 __global__ __launch_bounds__(256) void ke_tiles_to_hashes(const uint8_t *__restrict__ tile32,
                                                            const uint8_t *__restrict__ tile98,
                                                            const int64_t *__restrict__ out_idx,
-                                                           uint64_t *__restrict__ phash, uint64_t *__restrict__ dhash) {
+                                                           uint64_t *__restrict__ phash, uint64_t *__restrict__ dhash,
+                                                           float *__restrict__ margin) {
     __shared__ __attribute__((aligned(16))) uint8_t s_tile[1024];
     __shared__ double s_T[256];
     __shared__ float s_cf[64];
@@ -169,7 +178,7 @@ __global__ __launch_bounds__(256) void ke_tiles_to_hashes(const uint8_t *__restr
     if (phash) {
         reinterpret_cast<uint32_t *>(s_tile)[tid] = reinterpret_cast<const uint32_t *>(tile32 + (size_t)img * 1024)[tid];
         __syncthreads();
-        const uint64_t hv = tile32_to_phash(s_tile, s_T, s_cf, tid);
+        const uint64_t hv = tile32_to_phash(s_tile, s_T, s_cf, tid, margin ? margin + slot : nullptr);
         if (tid == 0) phash[slot] = hv;
     }
     if (dhash && tid < 64) {
@@ -241,6 +250,7 @@ struct KeFusedArgs {
     int lt_bytes;   // = 2 * lt_half
     int hp;         // pitch of one HT column (bytes, multiple of 8)
     uint64_t *phash;
+    float *margin;        // nullable: tie margin per image (same slot as phash)
     uint8_t *tile32_out;  // nullable debug output
     // dHash side (DH instantiations): operands of the 9-output horizontal axis, 8 output rows x 3 chunks vertically
     const int32_t *mxd_frag, *hd_bias;
@@ -319,8 +329,9 @@ __device__ __forceinline__ void fused_tail(const KeFusedArgs &a, uint8_t *Lt, co
     if (a.tile32_out)
         reinterpret_cast<uint32_t *>(a.tile32_out + (size_t)img * 1024)[tid] = reinterpret_cast<const uint32_t *>(T32)[tid];
     // ---- K2: DCT corner, mean, bits
-    const uint64_t hv = tile32_to_phash(T32, Td, cf, tid);
-    if (tid == 0 && a.phash) a.phash[a.out_idx ? a.out_idx[img] : img] = hv;
+    const int64_t slot = a.out_idx ? a.out_idx[img] : img;
+    const uint64_t hv = tile32_to_phash(T32, Td, cf, tid, (a.margin && a.phash) ? a.margin + slot : nullptr);
+    if (tid == 0 && a.phash) a.phash[slot] = hv;
     if (NDWD > 0) {
         // ---- K1' + K3 for dHash: 8 rows x 9 columns, each output = 3 chunk sums (threads 0..215)
         __syncthreads();
@@ -610,7 +621,7 @@ int launch_fused_mx(ke_ctx *ctx, const KeHashGroup &g, const KeAxisCoeffs *ch, c
     a.lt_bytes = 2 * a.lt_half;
     a.hp = ((std::max(plan ? 0 : cv->span, rows_padded) + 7) & ~7) + 8;
     a.hpd = 8;
-    a.phash = d_phash; a.tile32_out = d_tile32;
+    a.phash = d_phash; a.tile32_out = d_tile32; a.margin = ctx->margin_cur;
     size_t lds = std::max<size_t>((size_t)a.lt_bytes + (size_t)32 * a.hp, 4096);
     if (DH) {
         const KeAxisCoeffs *chd = ke_get_coeffs(ctx, g.w, 9), *cvd = ke_get_coeffs(ctx, g.h, 8);
@@ -855,7 +866,7 @@ int launch_fused_wide(ke_ctx *ctx, const KeHashGroup &g, const KeAxisCoeffs *ch,
     a.lt_bytes = 2 * a.lt_half;
     a.hp = ((std::max(plan ? 0 : cv->span, rows_padded) + 7) & ~7) + 8;
     a.hpd = 8;
-    a.phash = d_phash; a.tile32_out = d_tile32;
+    a.phash = d_phash; a.tile32_out = d_tile32; a.margin = ctx->margin_cur;
     size_t lds = (size_t)a.lt_bytes + (size_t)32 * a.hp;
     if (DH) {
         const KeAxisCoeffs *chd = ke_get_coeffs(ctx, g.w, 9), *cvd = ke_get_coeffs(ctx, g.h, 8);
@@ -1187,10 +1198,10 @@ int resample_banded(ke_ctx *ctx, const KeHashGroup &g, int ow, int oh, uint8_t *
     KE_TRY(ke_reserve(ctx, KE_BUF_TMP, (size_t)g.n * ow * a.hp + 8192, &hs));     // + slack: ke_vtile_mx reads whole steps
     a.hs = (uint8_t *)hs;
     if ((int64_t)g.n * a.bands > 0x7fffffffLL) return ke_fail(ctx, KE_EUNSUPPORTED, "group too large for one launch");
-    // "aligned" = every row starts on a quad boundary of the packed stream (w % 4 == 0), so a
-    // quad is DW whole dwords and the last quad of the image ends with the image.  gfx950 global loads tolerate a base
-    // that is not 4-byte aligned, so ragged batches keep this path; other widths take the funnel-shift loader.
-    const bool aligned = g.w % 4 == 0;
+    // "aligned" = every row starts on a quad boundary of the packed stream (w % 4 == 0) and every image starts on a
+    // dword boundary, so a quad is DW whole dwords and the last quad of the image ends with the image.  Other widths, and
+    // ragged batches in which some image starts off a dword boundary, take the funnel-shift loader.
+    const bool aligned = g.w % 4 == 0 && !g.misaligned;
     for (int first = 0; first < ow; first += per_launch) {
         a.out_first = first;
         a.nout = std::min(per_launch, ow - first);
@@ -1443,7 +1454,7 @@ int launch_vtile(ke_ctx *ctx, const uint8_t *hs, int hp, int64_t n, int ow, int 
 // (32 x 32) or (8 x 9) tile of packed RGB images 2816..5300 pixels wide, large groups only
 int resample_strips(ke_ctx *ctx, const KeHashGroup &g, int ow, int oh, uint8_t *d_tiles) {
     if (!((ow == 32 && oh == 32) || (ow == 9 && oh == 8))) return KE_EUNSUPPORTED;
-    if (g.channels != 3 || g.w % 4 || g.w <= 2048 || (int64_t)g.h > (int64_t)g.w * 100 || g.h == oh) return KE_EUNSUPPORTED;
+    if (g.misaligned || g.channels != 3 || g.w % 4 || g.w <= 2048 || (int64_t)g.h > (int64_t)g.w * 100 || g.h == oh) return KE_EUNSUPPORTED;
     if ((int64_t)g.w * g.h * 3 >= (1LL << 31) || (uintptr_t)g.pixels % 4 || !(g.offsets || g.stride % 4 == 0)) return KE_EUNSUPPORTED;
     const KeAxisCoeffs *chz = ke_get_coeffs(ctx, g.w, ow);
     const KeAxisCoeffs *cvt = ke_get_coeffs(ctx, g.h, oh);
@@ -1554,12 +1565,13 @@ int dispatch_single_pass(ke_ctx *ctx, const KeHashGroup &g, bool want_d, uint64_
                          uint8_t *d_t98, const KeBandPlan *plan, bool *did_d) {
     *did_d = false;
     const bool unal = g.w % 4 != 0;                // rows that do not end on a 4-pixel boundary: RGB, pHash leg only
+    if (g.misaligned) return KE_EUNSUPPORTED;      // some image of the group does not start on a dword boundary: banded funnel-shift loader
     if (g.w <= 64 || g.w > (unal ? 1024 : g.channels == 3 ? 2816 : 2048) || g.h == 32 || g.h < 16 || (unal && g.channels != 3) ||
         (!plan && g.h > 4096) || (int64_t)g.h > (int64_t)g.w * 100 ||
         (!unal && ((uintptr_t)g.pixels % 4 || !(g.offsets || g.stride % 4 == 0))) ||
         (int64_t)g.w * g.h * g.channels >= (1LL << 31))
         return KE_EUNSUPPORTED;
-    // offsets (ragged groups) are only 4-byte aligned when every image size is; w % 4 == 0 makes it so
+    // ragged groups: ke_hash_images checks every offset and sets g.misaligned when one is not a multiple of 4
     const KeAxisCoeffs *ch = ke_get_coeffs(ctx, g.w, 32);
     const KeAxisCoeffs *cv = ke_get_coeffs(ctx, g.h, 32);
     if (!ch || !cv) return ke_fail(ctx, KE_EHIP, "coefficient upload failed");
@@ -1797,7 +1809,7 @@ int ke_launch_hash_group(ke_ctx *ctx, const KeHashGroup &g, uint64_t *d_phash, u
             uint64_t *dh = (d_dhash && !d_done) ? d_dhash + slot0 : nullptr;
             if (ph || dh) {
                 hipLaunchKernelGGL(ke_tiles_to_hashes, dim3((unsigned)s.n), dim3(256), 0, ctx->stream, (const uint8_t *)t32,
-                                   (const uint8_t *)t98, s.out_idx, ph, dh);
+                                   (const uint8_t *)t98, s.out_idx, ph, dh, (ph && ctx->margin_cur) ? ctx->margin_cur + slot0 : nullptr);
                 KE_HIP(ctx, hipGetLastError());
             }
         }

@@ -84,6 +84,7 @@ enum {
     KE_BUF_TILE98,
     KE_BUF_OUT0,         // staged outputs
     KE_BUF_OUT1,
+    KE_BUF_OUT2,         // staged tie margins
     KE_BUF_META,         // offsets / out_idx arrays
     KE_BUF_SCAN_IN,
     KE_BUF_SCAN_AUX,
@@ -106,6 +107,8 @@ struct ke_ctx {
     std::map<std::tuple<int, int, uint32_t, uint32_t>, KeAxisCoeffs *> coeffs;   // key: (in_size, out_size * 4 + filter, bits of in0, in1)
     hipEvent_t ev0[KE_T_COUNT] = {}, ev1[KE_T_COUNT] = {};
     bool ev_valid[KE_T_COUNT] = {};
+    bool ssim_exact = false;         // ke_ssim_set_mode: false = integer-sum kernel (default), true = fp64-carry kernel
+    float *margin_cur = nullptr;     // device array the hash kernels of the CURRENT call write tie margins to (slot = hash slot)
     bool dct_tables_ready = false;   // __constant__ tables are per device: uploaded once per context
 };
 
@@ -148,6 +151,7 @@ struct KeHashGroup {
     const int64_t *out_idx;    // device, nullable (then output slot k)
     int64_t n;
     int w, h, channels;
+    bool misaligned = false;   // some image of the group starts at an address that is not a multiple of 4
 };
 int ke_launch_hash_group(ke_ctx *ctx, const KeHashGroup &g, uint64_t *d_phash, uint64_t *d_dhash,
                          uint8_t *d_tile32_out, uint8_t *d_tile98_out);

@@ -11,6 +11,8 @@
 //
 // Layout: see ke_ssim_waves below.  A second tiny kernel adds the partial sums of a pair in a fixed order
 // (bitwise reproducible) and divides.
+#include <type_traits>
+
 #include "ke_internal.h"
 
 namespace {
@@ -30,8 +32,9 @@ struct SsimArgs {
     const int64_t *pa, *pb;
     int w, h;
     int col_blocks, block_cols, bands, items_per_pair;
+    int band_rows;     // interior rows per wave (fast kernel; the exact kernel walks kBandRows)
     int64_t n_items;
-    double *partial;   // [pair][items_per_pair]
+    double *partial;   // [pair][items_per_pair]; the fast kernel stores 2^26-scaled integer sums in the same slots
 };
 
 // float32(s / 7) for a window sum s, as scipy stores it (double quotient, then the cast): one multiply by RN(1/7).
@@ -262,6 +265,234 @@ __global__ __launch_bounds__(256, 2) void ke_ssim_waves(const SsimArgs a) {
     if (lane == 0) a.partial[item] = local;
 }
 
+// ---------------------------------------------------------------------------------------
+// Fast variant (the default): the same wave layout, but every window sum is an exact INTEGER carried in float32.
+//
+// With integer luma L in 0..255 the five window sums of skimage's SSIM are integers below 2^24, hence exact in
+// float32 in any order -- so the fp64 carries of the exact kernel (150 VALU instructions per pixel pair, VALU-issue
+// bound at 0.2 of HBM) are unnecessary.  Further, SSIM needs vx + vy, vxy, ux*uy and ux^2 + uy^2 only, which follow
+// from FOUR box filters over p = La + Lb and m = La - Lb instead of five over (x, y, xx, yy, xy):
+//     SP = sum p, SM = sum m, SPP = sum p^2 (<= 49 * 510^2 < 2^24), SMM = sum m^2          (7 x 7 window)
+//     2 ux uy      = (SP^2 - SM^2) c1        ux^2 + uy^2 = (SP^2 + SM^2) c1        c1 = 1 / (2 (49*255)^2)
+//     2 vxy        = (Np - Nm) c2            vx + vy     = (Np + Nm) c2            c2 = 1 / (2*48*49*255^2)
+//     Np = 49 SPP - SP^2,  Nm = 49 SMM - SM^2   (49/48 = skimage's sample-covariance normalisation)
+// Np / Nm are formed without cancellation error: P = RN(S^2), e2 = fma(S, S, -P) (exact), e1 = fma(49, Q, -P) (exact
+// whenever |N| < 2^24, i.e. exactly where cancellation would hurt), N = e1 - e2.  What differs from the exact kernel
+// is therefore only what skimage's own float32 intermediates round away: |delta SSIM| stays below 1e-5 (measured over
+// the golden pairs and the 100 000-image corpus' candidate edges; tests/test_gpu_parity.py), the bar being 1e-4.
+//
+// All (p, m) quantities travel as float2 so the sums are v_pk_add_f32 / v_pk_fma_f32 (two per instruction); the ring of
+// the seven most recent rows is unrolled in place (no register moves); the 3-column halos come from the neighbouring
+// lanes through ds_bpermute (LDS crossbar, no VALU issue slot); four quotients share one v_rcp_f32.
+// ---------------------------------------------------------------------------------------
+typedef float ke_f2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ ke_f2 pk_fma(ke_f2 a, ke_f2 b, ke_f2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+// 16.16 luma sum of one pixel held in a dword (channel bytes 0..2, or 1..3 when `shifted`); byte 2 of the result is L
+__device__ __forceinline__ uint32_t luma_sum(uint32_t p, bool shifted) {
+    constexpr uint32_t CHI = 0x001D964Cu, CLO = 0x002F468Bu;
+    return shifted ? (__builtin_amdgcn_udot4(p, CHI << 8, 0u, false) << 8) + __builtin_amdgcn_udot4(p, CLO << 8, 0x8000u, false)
+                   : (__builtin_amdgcn_udot4(p, CHI, 0u, false) << 8) + __builtin_amdgcn_udot4(p, CLO, 0x8000u, false);
+}
+__device__ __forceinline__ float byte2_f32(uint32_t s) { return (float)((s >> 16) & 0xFFu); }   // v_cvt_f32_ubyte2
+
+// The C dwords of an aligned quad -> four luma values as floats (integers 0..255)
+template <int C>
+__device__ __forceinline__ void quad_to_f32(const uint32_t *q, float *out) {
+    if (C == 1) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) out[k] = (float)((q[0] >> (8 * k)) & 0xFFu);   // v_cvt_f32_ubyte0..3
+    } else if (C == 3) {
+        out[0] = byte2_f32(luma_sum(q[0], false));
+        out[1] = byte2_f32(luma_sum(__builtin_amdgcn_alignbyte(q[1], q[0], 3), false));
+        out[2] = byte2_f32(luma_sum(__builtin_amdgcn_alignbyte(q[2 % C], q[1], 2), false));
+        out[3] = byte2_f32(luma_sum(q[2 % C], true));
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) out[k] = byte2_f32(luma_sum(q[k % C], false));
+    }
+}
+
+// keeps the compiler from folding (float)a + (float)b into an integer add + one more conversion (costs an instruction)
+__device__ __forceinline__ float opaque(float x) { asm("" : "+v"(x)); return x; }
+
+template <int C, int PX, bool AL>
+__global__ __launch_bounds__(256, 2) void ke_ssim_fast(const SsimArgs a) {
+    constexpr int NW = PX / 4;
+    const int lane = threadIdx.x & 63;
+    const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= a.n_items) return;
+    const int64_t pair = item / a.items_per_pair;
+    const int sub = (int)(item % a.items_per_pair);
+    const int band = sub / a.col_blocks, cb = sub % a.col_blocks;
+    const int block_cols = a.block_cols;
+    const int x0 = cb * block_cols;
+    const int y0 = band * a.band_rows;                      // first halo row; interior rows y0 + 3 ..
+    const int y_last = min(a.h - 3, y0 + 3 + a.band_rows) + 3;   // one past the last halo row (>= y0 + 7)
+    const size_t img_bytes = (size_t)a.w * a.h * C;
+    const uint8_t *A = a.images + (size_t)a.pa[pair] * img_bytes;
+    const uint8_t *B = a.images + (size_t)a.pb[pair] * img_bytes;
+    const uint32_t dA = (uint32_t)((uintptr_t)A & 3), dB = (uint32_t)((uintptr_t)B & 3);
+    const uint8_t *A0 = A - dA, *B0 = B - dB;
+    const uint32_t lastA = (dA + (uint32_t)img_bytes - 1u) & ~3u, lastB = (dB + (uint32_t)img_bytes - 1u) & ~3u;
+    int xc = x0 + PX * lane;
+    xc = xc < a.w ? xc : a.w - 1;
+    int xq[NW];
+#pragma unroll
+    for (int n = 0; n < NW; ++n) xq[n] = min(x0 + PX * lane + 4 * n, a.w - 4);
+
+    // column k of this lane counts iff it is an interior column of the block and of the image
+    bool ink[PX];                                           // loop-invariant lane masks (scalar register pairs)
+#pragma unroll
+    for (int k = 0; k < PX; ++k) {
+        const int bc = PX * lane + k;
+        ink[k] = (bc >= 3) && (bc < 3 + block_cols) && (x0 + bc < a.w - 3);
+    }
+    const int addr_l = ((lane + 63) & 63) * 4, addr_r = ((lane + 1) & 63) * 4;   // ds_bpermute byte addresses of the neighbours
+
+    ke_f2 ring[7][PX];                                      // (p, m) of the seven most recent rows
+    ke_f2 vs[PX], vq[PX];                                   // vertical window sums (sum p, sum m), (sum p^2, sum m^2)
+#pragma unroll
+    for (int k = 0; k < PX; ++k) {
+        vs[k] = vq[k] = ke_f2{0.f, 0.f};
+#pragma unroll
+        for (int d = 0; d < 7; ++d) ring[d][k] = ke_f2{0.f, 0.f};
+    }
+    const float c1 = (float)(1.0 / (2.0 * (49.0 * 255.0) * (49.0 * 255.0)));
+    const float c2 = (float)(1.0 / (2.0 * 48.0 * 49.0 * 255.0 * 255.0));
+    const float C1 = (float)(0.01 * 0.01), C2 = (float)(0.03 * 0.03);
+    // Row sums are quantised to 2^-26 (finer than the float32 they come from) and added as integers, so a pair's score does
+    // not depend on how its rows are cut into bands or on the order of the partial sums: one launch or many give equal bits.
+    long long local = 0;
+
+    // The luma of the NEXT row travels from iteration to iteration as floats: its loads are issued at the top of an
+    // iteration and converted at the bottom, behind the arithmetic of the current row.
+    float xa[PX], xb[PX];
+    uint32_t qa[NW][C], qb[NW][C];
+    auto issue = [&](int y) {                               // raw quads of row y (clamped to the band)
+        const int yc = min(y, y_last - 1);
+#pragma unroll
+        for (int n = 0; n < NW; ++n) {
+            if (AL) {
+                const uint32_t o = ((uint32_t)yc * (uint32_t)a.w + (uint32_t)xq[n]) * C;
+#pragma unroll
+                for (int k = 0; k < C; ++k) {
+                    qa[n][k] = reinterpret_cast<const uint32_t *>(A + o)[k];
+                    qb[n][k] = reinterpret_cast<const uint32_t *>(B + o)[k];
+                }
+            } else {
+                const uint32_t off = ((uint32_t)yc * (uint32_t)a.w + (uint32_t)xc) * C + (uint32_t)n * 4 * C;
+                qa[n][0] = load_luma4<C>(A0, dA + off, lastA);
+                qb[n][0] = load_luma4<C>(B0, dB + off, lastB);
+            }
+        }
+    };
+    auto convert = [&]() {
+#pragma unroll
+        for (int n = 0; n < NW; ++n) {
+            if (AL) {
+                quad_to_f32<C>(qa[n], xa + 4 * n);
+                quad_to_f32<C>(qb[n], xb + 4 * n);
+            } else {
+                quad_to_f32<1>(qa[n], xa + 4 * n);
+                quad_to_f32<1>(qb[n], xb + 4 * n);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < PX; ++k) { xa[k] = opaque(xa[k]); xb[k] = opaque(xb[k]); }
+    };
+    // slide the vertical windows: - the row that leaves (ring slot `slot` holds it; zeros at the band start), + the new row
+    auto vertical = [&](auto slot_c) {
+        constexpr int slot = decltype(slot_c)::value;
+#pragma unroll
+        for (int k = 0; k < PX; ++k) {
+            vs[k] = vs[k] - ring[slot][k];
+            vq[k] = pk_fma(-ring[slot][k], ring[slot][k], vq[k]);
+            ring[slot][k] = ke_f2{xa[k] + xb[k], xa[k] - xb[k]};
+            vs[k] = vs[k] + ring[slot][k];
+            vq[k] = pk_fma(ring[slot][k], ring[slot][k], vq[k]);
+        }
+    };
+    auto outputs = [&](bool valid) {
+        ke_f2 ws[PX + 6], wq[PX + 6];                       // [left 3 | own PX | right 3]
+#pragma unroll
+        for (int k = 0; k < PX; ++k) { ws[3 + k] = vs[k]; wq[3 + k] = vq[k]; }
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                ws[e][c] = __int_as_float(__builtin_amdgcn_ds_bpermute(addr_l, __float_as_int(vs[PX - 3 + e][c])));
+                wq[e][c] = __int_as_float(__builtin_amdgcn_ds_bpermute(addr_l, __float_as_int(vq[PX - 3 + e][c])));
+                ws[PX + 3 + e][c] = __int_as_float(__builtin_amdgcn_ds_bpermute(addr_r, __float_as_int(vs[e][c])));
+                wq[PX + 3 + e][c] = __int_as_float(__builtin_amdgcn_ds_bpermute(addr_r, __float_as_int(vq[e][c])));
+            }
+        }
+        // own columns first (the halo values are still in flight), then the halos
+        ke_f2 hs = (ws[3] + ws[4]) + (ws[5] + ws[6]), hq = (wq[3] + wq[4]) + (wq[5] + wq[6]);
+        hs = hs + ((ws[0] + ws[1]) + ws[2]);
+        hq = hq + ((wq[0] + wq[1]) + wq[2]);
+        float num[PX], den[PX];
+#pragma unroll
+        for (int k = 0; k < PX; ++k) {
+            if (k > 0) { hs = hs + (ws[k + 6] - ws[k - 1]); hq = hq + (wq[k + 6] - wq[k - 1]); }
+            const ke_f2 P = hs * hs;
+            const ke_f2 e2 = pk_fma(hs, hs, -P);
+            const ke_f2 e1 = pk_fma(ke_f2{49.f, 49.f}, hq, -P);
+            const ke_f2 N = e1 - e2;                        // (Np, Nm)
+            // difference and sum of the two halves: two plain VALU operations each (the packed form with operand swizzles
+            // the compiler would pick costs three)
+            const ke_f2 d1 = {opaque(P[0] - P[1]), opaque(P[0] + P[1])};
+            const ke_f2 d2 = {opaque(N[0] - N[1]), opaque(N[0] + N[1])};
+            const ke_f2 ab1 = pk_fma(d1, ke_f2{c1, c1}, ke_f2{C1, C1});   // (A1, B1)
+            const ke_f2 ab2 = pk_fma(d2, ke_f2{c2, c2}, ke_f2{C2, C2});   // (A2, B2)
+            const ke_f2 nd = ab1 * ab2;
+            num[k] = ink[k] ? nd[0] : 0.f;
+            den[k] = nd[1];
+        }
+        // four quotients per reciprocal: n0/d0 + .. + n3/d3 = (N01 D23 + N23 D01) / (D01 D23); every d >= C1*C2 = 9e-8
+        float rowsum = 0.f;
+#pragma unroll
+        for (int g = 0; g < PX; g += 4) {
+            const float D01 = den[g] * den[g + 1], D23 = den[g + 2] * den[g + 3];
+            const float N01 = __builtin_fmaf(num[g], den[g + 1], num[g + 1] * den[g]);
+            const float N23 = __builtin_fmaf(num[g + 2], den[g + 3], num[g + 3] * den[g + 2]);
+            const float Nn = __builtin_fmaf(N01, D23, N23 * D01);
+            rowsum = __builtin_fmaf(Nn, __builtin_amdgcn_rcpf(D01 * D23), rowsum);
+        }
+        const int q = __float2int_rn(rowsum * 67108864.0f);   // |rowsum| <= PX + eps
+        local += valid ? (long long)q : 0ll;
+    };
+
+    issue(y0);
+    convert();
+    // the first six halo rows only fill the windows (ring slots 0..5)
+#define KE_FILL(S) do { issue(y0 + (S) + 1); vertical(std::integral_constant<int, (S)>{}); convert(); } while (0)
+    KE_FILL(0); KE_FILL(1); KE_FILL(2); KE_FILL(3); KE_FILL(4); KE_FILL(5);
+#undef KE_FILL
+    // from the seventh row on every row completes a window; rows are taken seven at a time so that the ring slot of a
+    // row is a compile-time constant (no register moves); rows past the band's end are computed on the clamped last
+    // row and weighted 0
+    for (int yb = y0 + 6; yb < y_last; yb += 7) {
+#define KE_ROW(R) do { issue(yb + (R) + 1); vertical(std::integral_constant<int, ((R) + 6) % 7>{}); \
+                       outputs(yb + (R) < y_last); convert(); } while (0)
+        KE_ROW(0); KE_ROW(1); KE_ROW(2); KE_ROW(3); KE_ROW(4); KE_ROW(5); KE_ROW(6);
+#undef KE_ROW
+    }
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) local += __shfl_down(local, s);
+    if (lane == 0) reinterpret_cast<long long *>(a.partial)[item] = local;
+}
+
+__global__ void ke_ssim_finish_fixed(const long long *__restrict__ partial, int tiles, int64_t n_pairs, double denom,
+                                     double *__restrict__ out) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_pairs) return;
+    long long s = 0;
+    for (int t = 0; t < tiles; ++t) s += partial[(size_t)p * tiles + t];
+    out[p] = ((double)s * (1.0 / 67108864.0)) / denom;
+}
+
 __global__ void ke_ssim_finish(const double *__restrict__ partial, int tiles, int64_t n_pairs, double denom,
                                double *__restrict__ out) {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -301,7 +532,23 @@ int ke_launch_ssim(ke_ctx *ctx, const uint8_t *d_images, int w, int h, int chann
         const int bca = a.block_cols & ~3;
         if ((w - 6 + bca - 1) / bca == a.col_blocks) a.block_cols = bca; else al = false;
     }
-    a.bands = (h - 6 + kBandRows - 1) / kBandRows;
+    a.band_rows = kBandRows;
+    // Images of fewer than 4096 windows always take the exact kernel: skimage's float32 intermediates can be off by up to
+    // ~1e-4 in a single window of a bright, nearly flat image (uxx - ux*ux cancels); over thousands of windows that
+    // averages far below 1e-5, in a 7x7 image (one window) it is the whole score.  Such images cost nothing either way.
+    const bool exact = ctx->ssim_exact || (int64_t)(w - 6) * (h - 6) < 4096;
+    if (!exact) {
+        // the fast kernel takes rows seven at a time: bands of 7*G interior rows, G as large as leaves >= ~8 waves per SIMD
+        // of work in the launch (each band re-reads 6 halo rows), at most 18 (126 rows)
+        const int64_t groups_total = (h - 6 + 6) / 7;
+        const int64_t cols = px == 8 ? cb8 : cb4;
+        int64_t G = groups_total * n_pairs * cols / 8192;
+        G = std::max<int64_t>(2, std::min<int64_t>(18, G));
+        const int64_t nb = (groups_total + G - 1) / G;
+        G = (groups_total + nb - 1) / nb;                   // equalise the bands
+        a.band_rows = (int)(7 * G);
+    }
+    a.bands = (h - 6 + a.band_rows - 1) / a.band_rows;
     a.items_per_pair = a.col_blocks * a.bands;
     a.n_items = n_pairs * a.items_per_pair;
     const int64_t blocks = (a.n_items + 3) / 4;
@@ -310,15 +557,22 @@ int ke_launch_ssim(ke_ctx *ctx, const uint8_t *d_images, int w, int h, int chann
     KE_TRY(ke_reserve(ctx, KE_BUF_SCAN_AUX, (size_t)a.n_items * sizeof(double), &part));
     a.partial = (double *)part;
     const dim3 grid((unsigned)blocks), blk(256);
-#define KE_SSIM_LAUNCH(CH, PXV) do { if (al) hipLaunchKernelGGL((ke_ssim_waves<CH, PXV, true>), grid, blk, 0, ctx->stream, a); \
-                                     else hipLaunchKernelGGL((ke_ssim_waves<CH, PXV, false>), grid, blk, 0, ctx->stream, a); } while (0)
+#define KE_SSIM_LAUNCH(CH, PXV) do { \
+        if (exact) { if (al) hipLaunchKernelGGL((ke_ssim_waves<CH, PXV, true>), grid, blk, 0, ctx->stream, a); \
+                               else hipLaunchKernelGGL((ke_ssim_waves<CH, PXV, false>), grid, blk, 0, ctx->stream, a); } \
+        else { if (al) hipLaunchKernelGGL((ke_ssim_fast<CH, PXV, true>), grid, blk, 0, ctx->stream, a); \
+               else hipLaunchKernelGGL((ke_ssim_fast<CH, PXV, false>), grid, blk, 0, ctx->stream, a); } } while (0)
     if (channels == 3) { if (px == 8) KE_SSIM_LAUNCH(3, 8); else KE_SSIM_LAUNCH(3, 4); }
     else if (channels == 1) { if (px == 8) KE_SSIM_LAUNCH(1, 8); else KE_SSIM_LAUNCH(1, 4); }
     else { if (px == 8) KE_SSIM_LAUNCH(4, 8); else KE_SSIM_LAUNCH(4, 4); }
 #undef KE_SSIM_LAUNCH
     KE_HIP(ctx, hipGetLastError());
-    hipLaunchKernelGGL(ke_ssim_finish, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, ctx->stream,
-                       (const double *)part, a.items_per_pair, n_pairs, (double)(w - 6) * (double)(h - 6), d_out);
+    if (exact)
+        hipLaunchKernelGGL(ke_ssim_finish, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, ctx->stream,
+                           (const double *)part, a.items_per_pair, n_pairs, (double)(w - 6) * (double)(h - 6), d_out);
+    else
+        hipLaunchKernelGGL(ke_ssim_finish_fixed, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, ctx->stream,
+                           (const long long *)part, a.items_per_pair, n_pairs, (double)(w - 6) * (double)(h - 6), d_out);
     KE_HIP(ctx, hipGetLastError());
     return KE_OK;
 }

@@ -129,7 +129,10 @@ int ke_luma_tiles_uniform(ke_ctx *ctx, const uint8_t *pixels, int64_t n, int32_t
  * capacity -- the caller then retries with a larger buffer.  Edge order is unspecified.
  * counters_out (nullable, 4 x u64, host): [0] pairs evaluated by this shard,
  * [1] sum over emitted edges of the number of shared bands (the reference's "ham=" funnel
- * counter, src/dup/scanner.py:292-299), [2] edges emitted, [3] reserved. */
+ * counter, src/dup/scanner.py:292-299), [2] edges emitted, [3] bucket pairs of the WHOLE table (the same on every
+ * shard): sum over bands and band values of C(bucket size, 2) for the buckets the reference walks (size >= 2, under
+ * the pair cap) -- its "pairs total=" counter before pairs of equal file id are taken out (src/dup/scanner.py:258-270;
+ * the host subtracts those, they need the ids grouped).  With no size filter "size=" equals it. */
 int ke_hamming_scan(ke_ctx *ctx, const uint64_t *hashes, const int64_t *ids, const int64_t *sizes, int64_t n,
                     int32_t part_index, int32_t part_count, int32_t threshold, int32_t band_bits,
                     int32_t band_count, double size_ratio, int64_t bucket_pair_cap, ke_edge *edges_out,

@@ -526,8 +526,6 @@ KE_API int ke_hamming_scan(ke_ctx *ctx, const uint64_t *hashes, const int64_t *i
     if (part_count <= 0 || part_index < 0 || part_index >= part_count)
         return ke_fail(ctx, KE_EINVAL, "bad shard %d/%d", part_index, part_count);
     if (capacity < 0 || (capacity > 0 && !edges_out)) return ke_fail(ctx, KE_EINVAL, "edges_out is NULL");
-    if (bucket_pair_cap > 0 && band_bits > 24)
-        return ke_fail(ctx, KE_EUNSUPPORTED, "bucket_pair_cap needs band_bits <= 24 (got %d)", band_bits);
     *n_edges_out = 0;
     if (counters_out) std::memset(counters_out, 0, 4 * sizeof(uint64_t));
     if (n < 2) return KE_OK;
@@ -565,7 +563,7 @@ KE_API int ke_hamming_scan(ke_ctx *ctx, const uint64_t *hashes, const int64_t *i
     unsigned long long pairs = 0;
     KE_TRY(ke_launch_scan(ctx, (const uint64_t *)d_h, (const int64_t *)d_ids, (const int64_t *)d_sizes, n, part_index,
                           part_count, threshold, band_bits, band_count, size_ratio, bucket_pair_cap, d_edges, capacity,
-                          d_cnt, &pairs));
+                          d_cnt, &pairs, counters_out != nullptr));
     unsigned long long h_cnt[4];
     KE_HIP(ctx, hipMemcpyAsync(h_cnt, d_cnt, sizeof h_cnt, hipMemcpyDeviceToHost, ctx->stream));
     KE_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -165,7 +165,7 @@ int ke_launch_sad_pairs(ke_ctx *ctx, const uint8_t *d_thumbs, int64_t pixels, co
 int ke_launch_scan(ke_ctx *ctx, const uint64_t *d_hashes, const int64_t *d_ids, const int64_t *d_sizes, int64_t n,
                    int part_index, int part_count, int threshold, int band_bits, int band_count, double size_ratio,
                    int64_t bucket_pair_cap, ke_edge *d_edges, int64_t capacity, unsigned long long *d_counters,
-                   unsigned long long *pairs_evaluated);
+                   unsigned long long *pairs_evaluated, bool want_bucket_pairs);
 int ke_launch_ssim(ke_ctx *ctx, const uint8_t *d_images, int w, int h, int channels, const int64_t *d_pa,
                    const int64_t *d_pb, int64_t n_pairs, double *d_out);
 int ke_launch_synth_rgb(ke_ctx *ctx, uint64_t seed, int64_t first, const int64_t *d_indices, int64_t n, int w, int h,

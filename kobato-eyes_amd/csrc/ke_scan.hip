@@ -16,6 +16,8 @@
 // (2 xor + 2 popcount + min per pair) topped out at 7-8 Tpairs/s on VALU issue.
 #include <cmath>
 
+#include <hipcub/hipcub.hpp>
+
 #include "ke_internal.h"
 
 namespace {
@@ -44,7 +46,8 @@ struct ScanArgs {
     int64_t n_tiles;        // total tiles in the triangle
     int threshold, band_bits, band_count;
     double size_ratio;
-    const uint32_t *hist;   // nullable: band_count tables of 2^band_bits bucket sizes
+    const uint32_t *hist;   // nullable: band_count tables of 2^band_bits bucket sizes (band_bits <= 24) ...
+    const uint32_t *blen;   // ... or, for wider bands, the size of hash i's bucket in band b at blen[b * n + i]
     unsigned long long cap;
     ke_edge *edges;
     int64_t capacity;
@@ -70,8 +73,9 @@ __device__ void consider_pair(const ScanArgs &a, int64_t gi, int64_t gj, uint64_
     for (int b = 0; b < a.band_count; ++b) {
         const int sh = b * a.band_bits;
         if (((d >> sh) & mask) != 0) continue;
-        if (a.hist) {                                                  // KE_DUP_BUCKET_PAIR_CAP, :262-263
-            const unsigned long long len = a.hist[((size_t)b << a.band_bits) + (size_t)((x >> sh) & mask)];
+        if (a.cap) {                                                   // KE_DUP_BUCKET_PAIR_CAP, :262-263
+            const unsigned long long len = a.hist ? a.hist[((size_t)b << a.band_bits) + (size_t)((x >> sh) & mask)]
+                                                  : a.blen[(size_t)b * (size_t)a.n + (size_t)gi];
             if (len * (len - 1) / 2 > a.cap) continue;
         }
         bands |= 1 << (b < 31 ? b : 31);
@@ -208,12 +212,50 @@ __global__ void ke_band_hist(const uint64_t *__restrict__ hashes, int64_t n, int
     for (int b = 0; b < band_count; ++b) atomicAdd(&hist[((size_t)b << band_bits) + (size_t)((x >> (b * band_bits)) & mask)], 1u);
 }
 
+// sum over buckets of C(len, 2) for the buckets the reference would walk (len >= 2, pairs <= cap when a cap is set):
+// its "pairs total" funnel counter before the same-file-id exclusion (src/dup/scanner.py:258-270)
+__global__ void ke_hist_pairs(const uint32_t *__restrict__ hist, size_t bins, unsigned long long cap, unsigned long long *out) {
+    unsigned long long s = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < bins; i += (size_t)gridDim.x * blockDim.x) {
+        const unsigned long long len = hist[i];
+        const unsigned long long p = len * (len - 1) / 2;
+        if (len >= 2 && (!cap || p <= cap)) s += p;
+    }
+    for (int d = 32; d > 0; d >>= 1) s += __shfl_down(s, d);
+    if ((threadIdx.x & 63) == 0 && s) atomicAdd(out, s);
+}
+
+// Wide bands (2^band_bits bins do not fit a table): the band values are sorted together with their positions and the
+// run lengths are read off the sorted keys.
+__global__ void ke_band_keys(const uint64_t *__restrict__ hashes, int64_t n, int shift, uint64_t mask, uint64_t *__restrict__ keys,
+                             uint32_t *__restrict__ pos) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    keys[i] = (hashes[i] >> shift) & mask;
+    pos[i] = (uint32_t)i;
+}
+
+// thread i starts a run iff keys[i] != keys[i-1]; it walks to the end of its run, writes the length to every member's
+// slot and adds the run's pairs.  Runs are short unless the corpus is degenerate (then the walk is long but correct).
+__global__ void ke_run_lengths(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ pos, int64_t n, unsigned long long cap,
+                               uint32_t *__restrict__ blen, unsigned long long *out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (i > 0 && keys[i - 1] == keys[i]) return;
+    int64_t e = i + 1;
+    while (e < n && keys[e] == keys[i]) ++e;
+    const unsigned long long len = (unsigned long long)(e - i);
+    for (int64_t k = i; k < e; ++k) blen[pos[k]] = (uint32_t)len;
+    const unsigned long long p = len * (len - 1) / 2;
+    if (len >= 2 && (!cap || p <= cap)) atomicAdd(out, p);
+}
+
 }  // namespace
 
 int ke_launch_scan(ke_ctx *ctx, const uint64_t *d_hashes, const int64_t *d_ids, const int64_t *d_sizes, int64_t n,
                    int part_index, int part_count, int threshold, int band_bits, int band_count, double size_ratio,
                    int64_t bucket_pair_cap, ke_edge *d_edges, int64_t capacity, unsigned long long *d_counters,
-                   unsigned long long *pairs_evaluated) {
+                   unsigned long long *pairs_evaluated, bool want_bucket_pairs) {
     ScanArgs a;
     a.hashes = d_hashes; a.ids = d_ids; a.sizes = (size_ratio > 0.0) ? d_sizes : nullptr;
     a.n = n;
@@ -224,18 +266,48 @@ int ke_launch_scan(ke_ctx *ctx, const uint64_t *d_hashes, const int64_t *d_ids, 
     a.tile_step = part_count;
     a.threshold = threshold; a.band_bits = band_bits; a.band_count = band_count;
     a.size_ratio = size_ratio;
-    a.hist = nullptr;
+    a.hist = nullptr; a.blen = nullptr;
     a.cap = bucket_pair_cap > 0 ? (unsigned long long)bucket_pair_cap : 0ull;
     a.edges = d_edges; a.capacity = capacity; a.counters = d_counters;
-    if (bucket_pair_cap > 0) {
+    // Bucket sizes per band: needed by the pair cap, and they give the reference's "pairs total" counter (counters[3]).
+    if ((bucket_pair_cap > 0 || want_bucket_pairs) && band_bits <= 24) {
         void *h;
-        const size_t bytes = ((size_t)band_count << band_bits) * sizeof(uint32_t);
+        const size_t bins = (size_t)band_count << band_bits, bytes = bins * sizeof(uint32_t);
         KE_TRY(ke_reserve(ctx, KE_BUF_SCAN_HIST, bytes, &h));
         KE_HIP(ctx, hipMemsetAsync(h, 0, bytes, ctx->stream));
         hipLaunchKernelGGL(ke_band_hist, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_hashes, n, band_bits,
                            band_count, (uint32_t *)h);
         KE_HIP(ctx, hipGetLastError());
         a.hist = (const uint32_t *)h;
+        if (want_bucket_pairs) {
+            const unsigned blocks = (unsigned)std::min<size_t>((bins + 255) / 256, 2048);
+            hipLaunchKernelGGL(ke_hist_pairs, dim3(blocks), dim3(256), 0, ctx->stream, (const uint32_t *)h, bins, a.cap, d_counters + 3);
+            KE_HIP(ctx, hipGetLastError());
+        }
+    } else if (bucket_pair_cap > 0 || want_bucket_pairs) {
+        if (n > 0xffffffffLL) return ke_fail(ctx, KE_EUNSUPPORTED, "bands wider than 24 bits need n < 2^32");
+        // sort (band value, position) per band; scratch: keys in/out, positions in/out, per-hash lengths, cub temp storage
+        size_t temp_bytes = 0;
+        KE_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, (const uint64_t *)nullptr, (uint64_t *)nullptr,
+                                                       (const uint32_t *)nullptr, (uint32_t *)nullptr, (int)n, 0, band_bits, ctx->stream));
+        const size_t kb = ((size_t)n * 8 + 255) & ~(size_t)255, pb = ((size_t)n * 4 + 255) & ~(size_t)255;
+        void *scratch, *lens;
+        KE_TRY(ke_reserve(ctx, KE_BUF_SCAN_AUX, 2 * kb + 2 * pb + temp_bytes + 256, &scratch));
+        KE_TRY(ke_reserve(ctx, KE_BUF_SCAN_HIST, (size_t)band_count * n * sizeof(uint32_t), &lens));
+        uint8_t *sp = (uint8_t *)scratch;
+        uint64_t *k_in = (uint64_t *)sp, *k_out = (uint64_t *)(sp + kb);
+        uint32_t *p_in = (uint32_t *)(sp + 2 * kb), *p_out = (uint32_t *)(sp + 2 * kb + pb);
+        void *temp = sp + 2 * kb + 2 * pb;
+        const uint64_t mask = band_bits >= 64 ? ~0ull : ((1ull << band_bits) - 1ull);
+        const dim3 grid((unsigned)((n + 255) / 256)), blk(256);
+        for (int b = 0; b < band_count; ++b) {
+            hipLaunchKernelGGL(ke_band_keys, grid, blk, 0, ctx->stream, d_hashes, n, b * band_bits, mask, k_in, p_in);
+            KE_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, k_in, k_out, p_in, p_out, (int)n, 0, band_bits, ctx->stream));
+            hipLaunchKernelGGL(ke_run_lengths, grid, blk, 0, ctx->stream, k_out, p_out, n, a.cap, (uint32_t *)lens + (size_t)b * n,
+                               want_bucket_pairs ? d_counters + 3 : d_counters + 3);
+            KE_HIP(ctx, hipGetLastError());
+        }
+        a.blen = (const uint32_t *)lens;
     }
     const int64_t my_tiles = a.n_tiles > part_index ? (a.n_tiles - part_index + part_count - 1) / part_count : 0;
     const int64_t n_pad = (int64_t)a.nb * kTile;     // the kernel reads whole tiles: operands beyond n are zero

@@ -160,6 +160,14 @@ def _safe_positive_int(value: Optional[str]) -> Optional[int]:
     return parsed if parsed > 0 else None
 
 
+def _size_ok(size_a: int, size_b: int, ratio: float) -> bool:
+    """src/dup/scanner.py:358-370."""
+    if not ratio or ratio <= 0 or size_a <= 0 or size_b <= 0:
+        return True
+    smaller, larger = (size_a, size_b) if size_a < size_b else (size_b, size_a)
+    return smaller / larger >= ratio
+
+
 def _cosine(left: DuplicateFile, right: DuplicateFile) -> Optional[float]:
     """float64 cosine of two embeddings; None = "cannot tell, let it pass" (src/dup/scanner.py:383-400)."""
     u, v = left.embedding, right.embedding
@@ -198,9 +206,73 @@ class DuplicateScanner:
             hashes, n, ids=ids, sizes=sizes if ratio > 0 else None, threshold=cfg.hamming_threshold,
             band_bits=cfg.band_bits, band_count=cfg.band_count, size_ratio=ratio, bucket_pair_cap=cap or 0,
             part_index=self._part[0], part_count=self._part[1])
-        return self._edges_from_raw(candidates, hashes, ids, raw, counters)
+        return self._edges_from_raw(candidates, hashes, ids, raw, counters, sizes=sizes, ratio=ratio, cap=cap)
 
-    def _edges_from_raw(self, candidates, hashes, ids, raw, counters) -> dict:
+    # -- the reference's funnel counters (src/dup/scanner.py:258-299) ---------------------------------------------
+    def _band_values(self, hashes: np.ndarray, band: int) -> np.ndarray:
+        cfg = self._config
+        mask = np.uint64((1 << cfg.band_bits) - 1) if cfg.band_bits < 64 else np.uint64(_MASK64)
+        return (hashes >> np.uint64(band * cfg.band_bits)) & mask
+
+    def _same_id_bucket_pairs(self, hashes, ids, sizes, ratio, cap) -> tuple[int, int]:
+        """Bucket pairs of equal file id (the reference skips them before counting, :266): (all, those passing the
+        size filter).  Only ids that occur more than once are looked at."""
+        uniq, inverse, counts = np.unique(ids, return_inverse=True, return_counts=True)
+        if not (counts > 1).any():
+            return 0, 0
+        cfg = self._config
+        total = sized = 0
+        bucket_len = []
+        for band in range(cfg.band_count):
+            vals = self._band_values(hashes, band)
+            _, inv, cnt = np.unique(vals, return_inverse=True, return_counts=True)
+            bucket_len.append((vals, cnt[inv]))
+        for g in np.nonzero(counts > 1)[0]:
+            pos = np.nonzero(inverse == g)[0]
+            for x in range(len(pos) - 1):
+                for y in range(x + 1, len(pos)):
+                    i, j = int(pos[x]), int(pos[y])
+                    for vals, blen in bucket_len:
+                        if vals[i] != vals[j]:
+                            continue
+                        length = int(blen[i])
+                        if cap is not None and length * (length - 1) // 2 > cap:
+                            continue
+                        total += 1
+                        sized += _size_ok(int(sizes[i]), int(sizes[j]), ratio)
+        return total, sized
+
+    def _pairs_after_size(self, hashes, sizes, ratio, cap) -> int:
+        """Bucket pairs passing the size filter (:358-370), equal ids included: per bucket the sizes are sorted and the
+        partners of each member counted with a binary search whose boundary is settled by the reference's own float
+        division (smaller / larger >= ratio)."""
+        cfg = self._config
+        total = 0
+        for band in range(cfg.band_count):
+            vals = self._band_values(hashes, band)
+            order = np.argsort(vals, kind="stable")
+            sv = vals[order]
+            starts = np.nonzero(np.concatenate(([True], sv[1:] != sv[:-1])))[0]
+            ends = np.concatenate((starts[1:], [len(sv)]))
+            for s0, e0 in zip(starts.tolist(), ends.tolist()):
+                m = e0 - s0
+                if m < 2 or (cap is not None and m * (m - 1) // 2 > cap):
+                    continue
+                sz = np.sort(sizes[order[s0:e0]])
+                free = int((sz <= 0).sum())                   # a missing / non-positive size passes with everyone
+                pos = sz[free:].astype(np.float64)
+                k = len(pos)
+                total += free * (free - 1) // 2 + free * k
+                if k >= 2:
+                    lo = np.searchsorted(pos, ratio * pos, side="left")
+                    for _ in range(2):                        # settle the boundary by the exact predicate
+                        lo = np.where((lo > 0) & (pos[np.maximum(lo - 1, 0)] / pos >= ratio), lo - 1, lo)
+                    for _ in range(2):
+                        lo = np.where((lo < k) & ~(pos[np.minimum(lo, k - 1)] / pos >= ratio), lo + 1, lo)
+                    total += int(np.maximum(np.arange(k) - lo, 0).sum())
+        return total
+
+    def _edges_from_raw(self, candidates, hashes, ids, raw, counters, *, sizes=None, ratio=0.0, cap=None) -> dict:
         cfg = self._config
         order = np.lexsort((raw["b"], raw["a"]))
         raw = raw[order]
@@ -238,10 +310,20 @@ class DuplicateScanner:
                 hits.sort(key=lambda t: (bucket_rank(t[0], t[3]), t[0], t[1]))
             a, b, h, _ = hits[0]
             edges[key] = DuplicateEdge(int(ids[a]), int(ids[b]), int(h))
-        self.last_counters = {"pairs_evaluated": int(counters[0]), "after_ham": int(counters[1]),
-                              "after_cosine": after_cos, "edges": len(edges)}
-        logger.info("dup: pairs evaluated=%d -> ham=%d -> cosine=%d -> edges=%d", int(counters[0]), int(counters[1]),
-                    after_cos, len(edges))
+        # "pairs total" = the device's bucket-pair count (band histograms) minus bucket pairs of equal file id; "size" =
+        # the same with the size filter.  A shard reports the whole table's figures for these two (they do not depend on
+        # the tiles it was dealt), its own share for the rest.
+        same_total, same_sized = self._same_id_bucket_pairs(hashes, ids, sizes if sizes is not None else np.zeros(len(ids), np.int64),
+                                                            ratio, cap)
+        pair_total = int(counters[3]) - same_total
+        if ratio > 0 and sizes is not None:
+            after_size = self._pairs_after_size(hashes, sizes, ratio, cap) - same_sized
+        else:
+            after_size = pair_total
+        self.last_counters = {"pairs_evaluated": int(counters[0]), "pair_total": pair_total, "after_size": after_size,
+                              "after_ham": int(counters[1]), "after_cosine": after_cos, "edges": len(edges)}
+        logger.info("dup: pairs total=%d -> size=%d -> ham=%d -> cosine=%d -> edges=%d", pair_total, after_size,
+                    int(counters[1]), after_cos, len(edges))
         return edges
 
     def _log_bucket_stats(self, hashes: np.ndarray, cap: Optional[int]) -> None:

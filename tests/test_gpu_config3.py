@@ -54,7 +54,10 @@ def test_one_million_hash_scan_matches_oracle(ctx):
         got, counters = ctx.hamming_scan(d, n, threshold=8)
         assert _key(got) == _key(exp)
         assert int(counters[0]) == n * (n - 1) // 2
-        assert int(counters[1]) == int(exp_counters[1]) and int(counters[2]) == len(exp)   # "ham=" funnel counter, edges
+        # the reference's funnel counters: "pairs total" from the band histograms (ids are distinct here, no size filter:
+        # "size" equals it), "ham" = shared bands summed over the edges
+        assert int(counters[3]) == int(exp_counters[0]) == int(exp_counters[1])
+        assert int(counters[1]) == int(exp_counters[2]) and int(counters[2]) == len(exp)
         # the 8 shards of configs[2]/[3]: union == the same set, nothing twice, pair space tiled exactly once
         parts, pairs = [], 0
         for p in range(8):

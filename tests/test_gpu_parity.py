@@ -278,8 +278,9 @@ def test_scanner_dropin_matches_reference(ctx, name, monkeypatch):
     if len(files) >= 2:
         edges = scanner.candidate_edges([f for f in files])
         assert sorted([a, b, e.hamming] for (a, b), e in edges.items()) == sc["edges"]
-        if sc["counters"] is not None:
-            assert scanner.last_counters["after_ham"] == sc["counters"][2]   # the "ham=" funnel counter
+        if sc["counters"] is not None:                       # the reference's funnel: pairs total -> size -> ham -> cosine (:292-299)
+            c = scanner.last_counters
+            assert [c["pair_total"], c["after_size"], c["after_ham"], c["after_cosine"]] == sc["counters"], c
 
 
 @pytest.mark.parametrize("n,t,bb,bc", [(20000, 8, 16, 4), (5000, 10, 8, 8), (3000, 64, 16, 4), (1025, 8, 16, 4),
@@ -653,8 +654,18 @@ def test_abi_edge_cases(ctx):
     ]:
         with pytest.raises(ValueError, match=msg):
             call()
-    with pytest.raises(RuntimeError, match="needs band_bits <= 24"):
-        ctx.hamming_scan(np.zeros(4, np.uint64), 4, band_bits=32, band_count=2, bucket_pair_cap=10)
+    # KE_DUP_BUCKET_PAIR_CAP with bands too wide for a bucket table (the reference takes any band shape with the cap):
+    # bucket sizes come from sorted band values instead
+    rng = np.random.default_rng(3)
+    wide = rng.integers(0, 1 << 63, 3000, dtype=np.uint64)
+    wide[:200] = (wide[:200] & np.uint64(0xFFFFFFFF00000000)) | np.uint64(0x1234ABCD)        # one 200-member bucket in band 0
+    wide[200:212] = (wide[200:212] & np.uint64(0x00000000FFFFFFFF)) | np.uint64(0x0BADF00D << 32)   # 12 + 12 members in band 1
+    wide[212:224] = wide[200:212] ^ np.uint64(1)                                          # (near-duplicates of those)
+    for cap in (100, 500, 30000):
+        exp, exp_c = O.scan_banded(wide, threshold=40, band_bits=32, band_count=2, bucket_pair_cap=cap)
+        got, c = ctx.hamming_scan(wide, len(wide), threshold=40, band_bits=32, band_count=2, bucket_pair_cap=cap)
+        key = lambda e: sorted(map(tuple, e[["a", "b", "h", "bands"]].tolist()))
+        assert key(got) == key(exp) and int(c[3]) == int(exp_c[0]), cap
     # a 1 x 1 image and a 1-pixel-wide strip still hash (generic passes)
     for shape in [(1, 1, 3), (300, 1, 3), (1, 300, 3)]:
         px = np.random.default_rng(1).integers(0, 256, shape, dtype=np.uint8)

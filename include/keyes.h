@@ -10,8 +10,10 @@
  *   - every function returns 0 on success or a negative KE_E* code; ke_last_error(ctx)
  *     returns a human-readable message for the last failure on that context;
  *   - no exceptions cross the boundary, no torch types appear in any signature;
- *   - data pointers may be HOST or DEVICE memory (decided with hipPointerGetAttributes);
- *     host buffers are staged through the context's pinned buffers;
+ *   - data pointers may be HOST or DEVICE memory (decided with hipPointerGetAttributes); a pageable host buffer is
+ *     copied to a device scratch in chunks of up to 1 GB with hipMemcpyAsync and hashed chunk by chunk (the call blocks);
+ *     producers that can write their pixels where they are told -- decoders -- use the pinned staging buffers of
+ *     ke_stage_* instead, whose copies overlap the kernels of the previous batch;
  *   - all work of a context is ordered on ONE HIP stream (ke_set_stream / ke_get_stream);
  *     calls return after the work has been ENQUEUED when every pointer is device memory,
  *     and after it has COMPLETED when any output pointer is host memory or the function
@@ -108,6 +110,29 @@ int ke_hash_uniform_ex(ke_ctx *ctx, const uint8_t *pixels, int64_t n, int32_t wi
 int ke_hash_images_ex(ke_ctx *ctx, const uint8_t *pixels, const uint64_t *offsets, const int32_t *widths,
                       const int32_t *heights, int32_t channels, int64_t n, uint64_t *phash_out,
                       uint64_t *dhash_out, int32_t *status_out, float *margin_out);
+
+/* ---- pinned staging: the batch boundary of core.fastsig (src/core/fastsig.py:24-37, 65-99: decode in workers, hash,
+ * collect in order) as a two-stage pipeline -- north-star step (1), "decodes batches of images to a pinned staging buffer".
+ *
+ * ke_stage_create allocates n_buffers (1..4) page-locked host buffers of bytes_per_buffer with device twins, result
+ * blocks for up to max_images images per batch, and a copy stream.  Per batch:
+ *   ke_stage_acquire      -> the next buffer in rotation (blocks only until THAT buffer's previous batch has finished and
+ *                            hands its results to the arrays named at its submit); decoders write pixels into it;
+ *   ke_stage_submit_hash  -> image i is heights[i] rows of widths[i]*channels[i] bytes at host_ptr + offsets[i] (channels
+ *                            per image: 1, 3 or 4; keep offsets multiples of 4, better 16).  Enqueues the H2D copy on the
+ *                            copy stream and the hash kernels behind it on the context's stream, then RETURNS: the copy of
+ *                            batch k+1 overlaps the kernels of batch k, the host is free to decode into the other buffer.
+ *                            phash_out / dhash_out / margin_out (host, nullable) are written when the slot is waited for or
+ *                            re-acquired; status_out (KE_IMG_*) is written immediately;
+ *   ke_stage_wait         -> blocks until the slot's results are in the caller's arrays (slot -1: every slot, oldest first).
+ * Hashes are those of ke_hash_images on the same pixels. */
+int ke_stage_create(ke_ctx *ctx, size_t bytes_per_buffer, int64_t max_images, int32_t n_buffers);
+int ke_stage_destroy(ke_ctx *ctx);
+int ke_stage_acquire(ke_ctx *ctx, int32_t *slot_out, uint8_t **host_ptr_out, size_t *bytes_out);
+int ke_stage_submit_hash(ke_ctx *ctx, int32_t slot, const uint64_t *offsets, const int32_t *widths, const int32_t *heights,
+                         const int32_t *channels, int64_t n, uint64_t *phash_out, uint64_t *dhash_out, int32_t *status_out,
+                         float *margin_out);
+int ke_stage_wait(ke_ctx *ctx, int32_t slot);
 
 /* Debug/parity hook: the resampled luma tiles the hashes are computed from
  * (reference sig.phash._to_grayscale, src/sig/phash.py:21-26).  tile32_out: n*1024 bytes

@@ -26,6 +26,7 @@ EXPORTS = (
     "ke_abi_version", "ke_create", "ke_create_error", "ke_destroy", "ke_last_error", "ke_set_stream",
     "ke_get_stream", "ke_synchronize", "ke_device_info", "ke_malloc", "ke_free", "ke_memcpy",
     "ke_hash_images", "ke_hash_uniform", "ke_hash_images_ex", "ke_hash_uniform_ex", "ke_luma_tiles_uniform", "ke_hamming_scan",
+    "ke_stage_create", "ke_stage_destroy", "ke_stage_acquire", "ke_stage_submit_hash", "ke_stage_wait",
     "ke_cluster_labels", "ke_ssim_pairs_uniform", "ke_ssim_set_mode", "ke_resize_luma_uniform", "ke_fit_luma_uniform", "ke_tile_ahash", "ke_sad_pairs", "ke_synth_rgb",
     "ke_synth_rgb_indexed",
     "ke_synth_hashes", "ke_last_kernel_ms",
@@ -76,6 +77,11 @@ def load_library() -> C.CDLL:
         lib.ke_hash_images_ex.argtypes = [vp, vp, vp, vp, vp, i32, i64, vp, vp, vp, vp]
         lib.ke_hash_uniform_ex.argtypes = [vp, vp, i64, i32, i32, i32, vp, vp, vp]
         lib.ke_luma_tiles_uniform.argtypes = [vp, vp, i64, i32, i32, i32, vp, vp]
+        lib.ke_stage_create.argtypes = [vp, C.c_size_t, i64, i32]
+        lib.ke_stage_destroy.argtypes = [vp]
+        lib.ke_stage_acquire.argtypes = [vp, C.POINTER(i32), C.POINTER(vp), C.POINTER(C.c_size_t)]
+        lib.ke_stage_submit_hash.argtypes = [vp, i32, vp, vp, vp, vp, i64, vp, vp, vp, vp]
+        lib.ke_stage_wait.argtypes = [vp, i32]
         lib.ke_hamming_scan.argtypes = [vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, dbl, i64, vp, i64,
                                         C.POINTER(i64), vp]
         lib.ke_cluster_labels.argtypes = [vp, i64, i64, vp]
@@ -92,6 +98,7 @@ def load_library() -> C.CDLL:
         lib.ke_last_kernel_ms.restype = dbl
         for name in ("ke_set_stream", "ke_synchronize", "ke_device_info", "ke_malloc", "ke_free", "ke_memcpy",
                      "ke_hash_images", "ke_hash_uniform", "ke_hash_images_ex", "ke_hash_uniform_ex", "ke_luma_tiles_uniform", "ke_hamming_scan",
+                     "ke_stage_create", "ke_stage_destroy", "ke_stage_acquire", "ke_stage_submit_hash", "ke_stage_wait",
                      "ke_cluster_labels", "ke_ssim_pairs_uniform", "ke_ssim_set_mode", "ke_resize_luma_uniform", "ke_fit_luma_uniform", "ke_tile_ahash",
                      "ke_sad_pairs", "ke_synth_rgb", "ke_synth_rgb_indexed", "ke_synth_hashes"):
             getattr(lib, name).restype = C.c_int
@@ -228,6 +235,43 @@ class Context:
             self._check(self._lib.ke_hash_images_ex(self._h, _addr(flat), _addr(offsets), _addr(widths), _addr(heights), ch, n,
                                                     _addr(ph), _addr(dh), _addr(status), _addr(margin)), "ke_hash_images_ex")
         return (ph, dh, status, margin) if want_margin else (ph, dh, status)
+
+    # -- pinned staging ---------------------------------------------------------------------
+    def stage_create(self, bytes_per_buffer: int, max_images: int, n_buffers: int = 2) -> None:
+        self._check(self._lib.ke_stage_create(self._h, int(bytes_per_buffer), int(max_images), int(n_buffers)), "ke_stage_create")
+
+    def stage_destroy(self) -> None:
+        self._check(self._lib.ke_stage_destroy(self._h), "ke_stage_destroy")
+
+    def stage_acquire(self):
+        """Next pinned buffer in rotation: (slot, uint8 ndarray view of the whole buffer).  Blocks until the buffer's
+        previous batch is done (its results land in the arrays given at its submit)."""
+        slot, ptr, size = C.c_int32(), C.c_void_p(), C.c_size_t()
+        with self._lock:
+            self._check(self._lib.ke_stage_acquire(self._h, C.byref(slot), C.byref(ptr), C.byref(size)), "ke_stage_acquire")
+        view = np.ctypeslib.as_array((C.c_uint8 * size.value).from_address(ptr.value))
+        return int(slot.value), view
+
+    def stage_submit_hash(self, slot: int, offsets, widths, heights, channels, *, want_dhash=True, want_margin=False):
+        """Enqueue copy + hash of the images described; returns a dict of host arrays (phash, dhash, status, margin) that
+        are valid after ``stage_wait(slot)`` (status: immediately).  The arrays must be kept alive until then."""
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        widths = np.ascontiguousarray(widths, dtype=np.int32)
+        heights = np.ascontiguousarray(heights, dtype=np.int32)
+        channels = np.ascontiguousarray(channels, dtype=np.int32)
+        n = len(offsets)
+        out = {"phash": np.zeros(n, np.uint64), "dhash": np.zeros(n, np.uint64) if want_dhash else None,
+               "status": np.zeros(n, np.int32), "margin": np.zeros(n, np.float32) if want_margin else None,
+               "_keep": (offsets, widths, heights, channels)}
+        with self._lock:
+            self._check(self._lib.ke_stage_submit_hash(self._h, slot, _addr(offsets), _addr(widths), _addr(heights), _addr(channels), n,
+                                                       _addr(out["phash"]), _addr(out["dhash"]), _addr(out["status"]),
+                                                       _addr(out["margin"])), "ke_stage_submit_hash")
+        return out
+
+    def stage_wait(self, slot: int = -1) -> None:
+        with self._lock:
+            self._check(self._lib.ke_stage_wait(self._h, int(slot)), "ke_stage_wait")
 
     # -- scan -------------------------------------------------------------------------------
     def hamming_scan(self, hashes, n: int, *, ids=None, sizes=None, threshold=8, band_bits=16, band_count=4,

@@ -214,10 +214,13 @@ KE_API ke_ctx *ke_create(int device_id) {
     return ctx;
 }
 
+static void stage_free(ke_ctx *ctx);
+
 KE_API void ke_destroy(ke_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    stage_free(ctx);
     for (auto &b : ctx->buf)
         if (b.ptr) (void)hipFree(b.ptr);
     free_coeff_cache(ctx);
@@ -508,6 +511,172 @@ KE_API int ke_hash_images_ex(ke_ctx *ctx, const uint8_t *pixels, const uint64_t 
                              const int32_t *heights, int32_t channels, int64_t n, uint64_t *phash_out,
                              uint64_t *dhash_out, int32_t *status_out, float *margin_out) {
     return hash_images_impl(ctx, pixels, offsets, widths, heights, channels, n, phash_out, dhash_out, status_out, margin_out);
+}
+
+// ---- pinned staging ---------------------------------------------------------------------------
+static void stage_free(ke_ctx *ctx) {
+    KeStage *st = ctx->stage;
+    if (!st) return;
+    (void)hipStreamSynchronize(ctx->stream);
+    if (st->copy_stream) (void)hipStreamSynchronize(st->copy_stream);
+    for (int k = 0; k < st->n_slots; ++k) {
+        KeStageSlot &s = st->slot[k];
+        for (void *p : {(void *)s.h_px, (void *)s.h_meta, (void *)s.h_ph, (void *)s.h_dh, (void *)s.h_mg})
+            if (p) (void)hipHostFree(p);
+        for (void *p : {(void *)s.d_px, (void *)s.d_meta, (void *)s.d_ph, (void *)s.d_dh, (void *)s.d_mg})
+            if (p) (void)hipFree(p);
+        if (s.copied) (void)hipEventDestroy(s.copied);
+        if (s.done) (void)hipEventDestroy(s.done);
+    }
+    if (st->copy_stream) (void)hipStreamDestroy(st->copy_stream);
+    delete st;
+    ctx->stage = nullptr;
+}
+
+KE_API int ke_stage_destroy(ke_ctx *ctx) {
+    if (!ctx) return KE_EINVAL;
+    stage_free(ctx);
+    return KE_OK;
+}
+
+KE_API int ke_stage_create(ke_ctx *ctx, size_t bytes_per_buffer, int64_t max_images, int32_t n_buffers) {
+    if (!ctx) return KE_EINVAL;
+    if (bytes_per_buffer < 4096 || max_images <= 0 || n_buffers < 1 || n_buffers > KE_MAX_STAGE_SLOTS)
+        return ke_fail(ctx, KE_EINVAL, "bad staging geometry (%zu bytes, %lld images, %d buffers)", bytes_per_buffer,
+                       (long long)max_images, n_buffers);
+    KE_HIP(ctx, hipSetDevice(ctx->device));
+    stage_free(ctx);
+    auto *st = new KeStage();
+    ctx->stage = st;
+    st->bytes = (bytes_per_buffer + 255) & ~(size_t)255;
+    st->max_images = max_images;
+    st->n_slots = n_buffers;
+    auto fail = [&](const char *what) { stage_free(ctx); return ke_fail(ctx, KE_ENOMEM, "staging: %s failed", what); };
+    if (hipStreamCreateWithFlags(&st->copy_stream, hipStreamNonBlocking) != hipSuccess) return fail("hipStreamCreate");
+    for (int k = 0; k < n_buffers; ++k) {
+        KeStageSlot &s = st->slot[k];
+        const size_t m8 = (size_t)max_images * 8;
+        if (hipHostMalloc((void **)&s.h_px, st->bytes, hipHostMallocDefault) != hipSuccess) return fail("hipHostMalloc(pixels)");
+        if (hipHostMalloc((void **)&s.h_meta, 2 * m8, hipHostMallocDefault) != hipSuccess) return fail("hipHostMalloc(meta)");
+        if (hipHostMalloc((void **)&s.h_ph, m8, hipHostMallocDefault) != hipSuccess) return fail("hipHostMalloc");
+        if (hipHostMalloc((void **)&s.h_dh, m8, hipHostMallocDefault) != hipSuccess) return fail("hipHostMalloc");
+        if (hipHostMalloc((void **)&s.h_mg, m8 / 2, hipHostMallocDefault) != hipSuccess) return fail("hipHostMalloc");
+        if (hipMalloc((void **)&s.d_px, st->bytes + 64) != hipSuccess) return fail("hipMalloc(pixels)");
+        if (hipMalloc((void **)&s.d_meta, 2 * m8) != hipSuccess) return fail("hipMalloc(meta)");
+        if (hipMalloc((void **)&s.d_ph, m8) != hipSuccess || hipMalloc((void **)&s.d_dh, m8) != hipSuccess ||
+            hipMalloc((void **)&s.d_mg, m8 / 2) != hipSuccess)
+            return fail("hipMalloc(results)");
+        if (hipEventCreateWithFlags(&s.copied, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&s.done, hipEventDisableTiming) != hipSuccess)
+            return fail("hipEventCreate");
+    }
+    return KE_OK;
+}
+
+static int stage_collect(ke_ctx *ctx, KeStageSlot &s) {
+    if (!s.in_flight) return KE_OK;
+    KE_HIP(ctx, hipEventSynchronize(s.done));
+    if (s.user_ph) std::memcpy(s.user_ph, s.h_ph, (size_t)s.n * 8);
+    if (s.user_dh) std::memcpy(s.user_dh, s.h_dh, (size_t)s.n * 8);
+    if (s.user_mg) std::memcpy(s.user_mg, s.h_mg, (size_t)s.n * 4);
+    s.in_flight = false;
+    return KE_OK;
+}
+
+KE_API int ke_stage_acquire(ke_ctx *ctx, int32_t *slot_out, uint8_t **host_ptr_out, size_t *bytes_out) {
+    if (!ctx || !slot_out || !host_ptr_out) return KE_EINVAL;
+    KeStage *st = ctx->stage;
+    if (!st) return ke_fail(ctx, KE_EINVAL, "ke_stage_create has not been called");
+    const int k = st->next;
+    st->next = (k + 1) % st->n_slots;
+    KE_TRY(stage_collect(ctx, st->slot[k]));      // the buffer's previous batch: copy and kernels done, results handed over
+    *slot_out = k;
+    *host_ptr_out = st->slot[k].h_px;
+    if (bytes_out) *bytes_out = st->bytes;
+    return KE_OK;
+}
+
+KE_API int ke_stage_wait(ke_ctx *ctx, int32_t slot) {
+    if (!ctx) return KE_EINVAL;
+    KeStage *st = ctx->stage;
+    if (!st || slot < -1 || slot >= st->n_slots) return ke_fail(ctx, KE_EINVAL, "bad staging slot %d", slot);
+    if (slot >= 0) return stage_collect(ctx, st->slot[slot]);
+    for (int k = 0; k < st->n_slots; ++k) KE_TRY(stage_collect(ctx, st->slot[(st->next + k) % st->n_slots]));   // oldest first
+    return KE_OK;
+}
+
+KE_API int ke_stage_submit_hash(ke_ctx *ctx, int32_t slot, const uint64_t *offsets, const int32_t *widths, const int32_t *heights,
+                                const int32_t *channels, int64_t n, uint64_t *phash_out, uint64_t *dhash_out,
+                                int32_t *status_out, float *margin_out) {
+    if (!ctx) return KE_EINVAL;
+    KeStage *st = ctx->stage;
+    if (!st || slot < 0 || slot >= st->n_slots) return ke_fail(ctx, KE_EINVAL, "bad staging slot %d", slot);
+    KeStageSlot &s = st->slot[slot];
+    if (s.in_flight) return ke_fail(ctx, KE_EINVAL, "staging slot %d is still in flight", slot);
+    if (n < 0 || n > st->max_images) return ke_fail(ctx, KE_EINVAL, "batch of %lld images exceeds the staging limit %lld", (long long)n, (long long)st->max_images);
+    if (n > 0 && (!offsets || !widths || !heights || !channels)) return ke_fail(ctx, KE_EINVAL, "offsets/widths/heights/channels must be non-NULL");
+    if (margin_out && !phash_out) return ke_fail(ctx, KE_EINVAL, "margin_out needs phash_out");
+    for (const void *p : {(const void *)phash_out, (const void *)dhash_out, (const void *)margin_out})
+        if (p && ke_is_device_ptr(p)) return ke_fail(ctx, KE_EINVAL, "staged results are returned to host arrays");
+    if (n == 0) return KE_OK;
+    KE_HIP(ctx, hipSetDevice(ctx->device));
+    trim_coeff_cache(ctx);
+    // size groups over (width, height, channels); metadata goes into the slot's pinned block so nothing here has to
+    // outlive the call on the stack
+    std::map<std::tuple<int, int, int>, std::vector<int64_t>> groups;
+    size_t used = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        const int c = channels[i];
+        const bool ok = widths[i] > 0 && heights[i] > 0 && (c == 1 || c == 3 || c == 4);
+        const size_t bytes = ok ? (size_t)widths[i] * heights[i] * c : 0;
+        const bool inside = ok && offsets[i] <= st->bytes && bytes <= st->bytes - offsets[i];
+        if (status_out) status_out[i] = inside ? KE_IMG_OK : KE_IMG_BAD_SHAPE;
+        if (!inside) continue;
+        groups[std::make_tuple(widths[i], heights[i], c)].push_back(i);
+        used = std::max(used, (size_t)offsets[i] + bytes);
+    }
+    size_t cursor = 0;
+    std::vector<std::pair<size_t, size_t>> spans;
+    for (auto &kv : groups) {
+        const std::vector<int64_t> &idx = kv.second;
+        spans.emplace_back(cursor, idx.size());
+        for (size_t k = 0; k < idx.size(); ++k) {
+            s.h_meta[cursor + k] = offsets[idx[k]];
+            s.h_meta[cursor + idx.size() + k] = (uint64_t)idx[k];
+        }
+        cursor += 2 * idx.size();
+    }
+    // copy stream: pixels + metadata to the slot's device twin
+    if (used) KE_HIP(ctx, hipMemcpyAsync(s.d_px, s.h_px, used, hipMemcpyHostToDevice, st->copy_stream));
+    if (cursor) KE_HIP(ctx, hipMemcpyAsync(s.d_meta, s.h_meta, cursor * 8, hipMemcpyHostToDevice, st->copy_stream));
+    KE_HIP(ctx, hipEventRecord(s.copied, st->copy_stream));
+    // compute stream: behind the copy, and behind whatever batch was submitted before
+    KE_HIP(ctx, hipStreamWaitEvent(ctx->stream, s.copied, 0));
+    if (phash_out) KE_HIP(ctx, hipMemsetAsync(s.d_ph, 0, (size_t)n * 8, ctx->stream));
+    if (dhash_out) KE_HIP(ctx, hipMemsetAsync(s.d_dh, 0, (size_t)n * 8, ctx->stream));
+    if (margin_out) KE_HIP(ctx, hipMemsetAsync(s.d_mg, 0, (size_t)n * 4, ctx->stream));
+    MarginScope margin_scope{ctx};
+    ctx->margin_cur = margin_out ? s.d_mg : nullptr;
+    ke_time_begin(ctx, KE_T_HASH);
+    size_t gi = 0;
+    for (auto &kv : groups) {
+        const int w = std::get<0>(kv.first), h = std::get<1>(kv.first), c = std::get<2>(kv.first);
+        const uint64_t *d_off = s.d_meta + spans[gi].first;
+        const int64_t m = (int64_t)spans[gi].second;
+        KeHashGroup g{s.d_px, d_off, (uint64_t)w * h * c, (const int64_t *)(d_off + m), m, w, h, c};
+        for (int64_t idx : kv.second)
+            if (((uintptr_t)s.d_px + offsets[idx]) % 4 != 0) { g.misaligned = true; break; }
+        KE_TRY(ke_launch_hash_group(ctx, g, phash_out ? s.d_ph : nullptr, dhash_out ? s.d_dh : nullptr, nullptr, nullptr));
+        ++gi;
+    }
+    ke_time_end(ctx, KE_T_HASH);
+    if (phash_out) KE_HIP(ctx, hipMemcpyAsync(s.h_ph, s.d_ph, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (dhash_out) KE_HIP(ctx, hipMemcpyAsync(s.h_dh, s.d_dh, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (margin_out) KE_HIP(ctx, hipMemcpyAsync(s.h_mg, s.d_mg, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    KE_HIP(ctx, hipEventRecord(s.done, ctx->stream));
+    s.user_ph = phash_out; s.user_dh = dhash_out; s.user_mg = margin_out; s.n = n;
+    s.in_flight = true;
+    return KE_OK;
 }
 
 // ---- scan ------------------------------------------------------------------------------------

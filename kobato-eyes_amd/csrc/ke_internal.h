@@ -97,6 +97,29 @@ enum {
     KE_BUF_COUNT
 };
 
+// Pinned staging (north-star step 1): producers (decode threads) write pixels straight into page-locked host buffers;
+// a submit enqueues the H2D copy on a copy stream and the hash kernels behind an event on the compute stream, so the copy
+// of batch k+1 overlaps the kernels of batch k and the host never blocks between batches.
+constexpr int KE_MAX_STAGE_SLOTS = 4;
+struct KeStageSlot {
+    uint8_t *h_px = nullptr, *d_px = nullptr;        // pinned pixels and their device twin
+    uint64_t *h_meta = nullptr, *d_meta = nullptr;   // per size group: [byte offsets | output slots]
+    uint64_t *h_ph = nullptr, *h_dh = nullptr, *d_ph = nullptr, *d_dh = nullptr;
+    float *h_mg = nullptr, *d_mg = nullptr;
+    hipEvent_t copied = nullptr, done = nullptr;
+    bool in_flight = false;
+    uint64_t *user_ph = nullptr, *user_dh = nullptr;  // where the results go when the slot is waited for
+    float *user_mg = nullptr;
+    int64_t n = 0;
+};
+struct KeStage {
+    size_t bytes = 0;
+    int64_t max_images = 0;
+    int n_slots = 0, next = 0;
+    hipStream_t copy_stream = nullptr;
+    KeStageSlot slot[KE_MAX_STAGE_SLOTS];
+};
+
 struct ke_ctx {
     int device = 0;
     int cu_count = 0;
@@ -107,6 +130,7 @@ struct ke_ctx {
     std::map<std::tuple<int, int, uint32_t, uint32_t>, KeAxisCoeffs *> coeffs;   // key: (in_size, out_size * 4 + filter, bits of in0, in1)
     hipEvent_t ev0[KE_T_COUNT] = {}, ev1[KE_T_COUNT] = {};
     bool ev_valid[KE_T_COUNT] = {};
+    KeStage *stage = nullptr;
     bool ssim_exact = false;         // ke_ssim_set_mode: false = integer-sum kernel (default), true = fp64-carry kernel
     float *margin_cur = nullptr;     // device array the hash kernels of the CURRENT call write tie margins to (slot = hash slot)
     bool dct_tables_ready = false;   // __constant__ tables are per device: uploaded once per context

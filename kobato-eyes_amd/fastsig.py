@@ -7,17 +7,20 @@ input order with failed files left out (:36-37), progress fires every 200 files 
 optional "unsafe fast" PRAGMAs are the reference's (:40-45).
 
 The machinery is different: where the reference fans single files out to a spawn-context process pool, this is a
-two-stage pipeline -- Pillow decodes chunk k+1 on a thread pool (it releases the GIL) while the GPU hashes chunk k
-with one ``ke_hash_images`` call per channel count.
+two-stage pipeline -- Pillow decodes chunk k+1 on a thread pool (it releases the GIL) straight into a page-locked
+staging buffer while chunk k is copied to the GPU and hashed (``ke_stage_*``, include/keyes.h).
 """
 from __future__ import annotations
 
 import importlib
 import os
 import sqlite3
+import threading
 from concurrent.futures import Future, ThreadPoolExecutor
 from pathlib import Path
 from typing import Callable, Iterable, Iterator, List, Optional, Sequence, Tuple
+
+from . import _native
 
 _phash = importlib.import_module(".phash", __package__)   # the package also exports a function named phash
 
@@ -50,39 +53,119 @@ def _read_pixels(path_text: str):
         return None
 
 
+class _GpuStage:
+    """The context's pinned staging buffers (``ke_stage_*``) behind the four calls the pipeline needs; tests of the host
+    logic put a stand-in here (``_make_stage``)."""
+
+    def __init__(self, device: int, stage_bytes: int, max_images: int) -> None:
+        self.device = device
+        self.ctx = _native.get_context(device)
+        geom = (stage_bytes, max_images)
+        if getattr(self.ctx, "_stage_geom", None) != geom:
+            self.ctx.stage_create(stage_bytes, max_images, 2)
+            self.ctx._stage_geom = geom
+
+    def acquire(self):
+        return self.ctx.stage_acquire()
+
+    def submit(self, slot, offsets, widths, heights, channels):
+        return self.ctx.stage_submit_hash(slot, offsets, widths, heights, channels, want_dhash=True)
+
+    def wait(self, slot: int) -> None:
+        self.ctx.stage_wait(slot)
+
+    def hash_one(self, arr):
+        """(phash, dhash) or None for an image that did not fit a staging buffer."""
+        ph, dh, ok = _phash.hash_batch([arr], want_dhash=True, device=self.device)
+        return (int(ph[0]), int(dh[0])) if ok[0] else None
+
+
+_make_stage = _GpuStage
+
+
 class _Pipeline:
-    """decode (threads) -> hash (GPU), one chunk in flight on each side."""
+    """decode (threads) -> pinned staging buffer -> H2D + hash (GPU), without a host-side copy in between.
+
+    Files are taken ``chunk`` at a time.  The decode threads of chunk k write their pixels straight into one of the
+    context's two page-locked staging buffers (``ke_stage_acquire``; a bump allocator hands out 16-byte aligned
+    regions); ``ke_stage_submit_hash`` then enqueues the copy and the kernels and returns, so chunk k+1 is decoded into
+    the other buffer while chunk k crosses PCIe and is hashed.  An image that does not fit what is left of a buffer is
+    hashed on its own through ``ke_hash_images``.
+    """
 
     def __init__(self, tasks: Sequence[Task], workers: int, chunk: int, device: int) -> None:
         self.tasks, self.chunk, self.device = tasks, max(1, int(chunk)), device
         self.pool = ThreadPoolExecutor(max_workers=max(1, workers))
+        self.stage = _make_stage(device, int(os.environ.get("KE_STAGE_BYTES", str(256 << 20))), self.chunk)
 
-    def _submit(self, start: int) -> List[Future]:
-        return [self.pool.submit(_read_pixels, p) for _, p in self.tasks[start:start + self.chunk]]
+    def _decode_into(self, path_text: str, view, alloc: dict):
+        """One file -> (offset, width, height, channels) inside the staging buffer, ("spill", array) when it does not
+        fit, None when it cannot be read."""
+        arr = _read_pixels(path_text)
+        if arr is None or arr.size == 0:
+            return None
+        nbytes = int(arr.size)
+        with alloc["lock"]:
+            off = (alloc["cursor"] + 15) & ~15
+            if off + nbytes > len(view):
+                return ("spill", arr)
+            alloc["cursor"] = off + nbytes
+        view[off:off + nbytes] = arr.reshape(-1)                  # the only copy between Pillow and the GPU (GIL released)
+        h, w = arr.shape[:2]
+        return (off, w, h, 1 if arr.ndim == 2 else arr.shape[2])
 
-    def _hash(self, pixels: list) -> list:
-        """Per decoded slot: (phash_s64, dhash_s64) or None."""
-        live = [k for k, a in enumerate(pixels) if a is not None and a.size > 0]
-        out: list = [None] * len(pixels)
-        if live:
-            ph, dh, ok = _phash.hash_batch([pixels[k] for k in live], want_dhash=True, device=self.device)
-            for k, p, d, good in zip(live, ph.tolist(), dh.tolist(), ok.tolist()):
-                if good:
+    def _start(self, start: int):
+        slot, view = self.stage.acquire()
+        alloc = {"lock": threading.Lock(), "cursor": 0}
+        futures = [self.pool.submit(self._decode_into, p, view, alloc) for _, p in self.tasks[start:start + self.chunk]]
+        return slot, futures
+
+    def _submit(self, slot: int, futures: List[Future]):
+        decoded = [f.result() for f in futures]
+        staged = [(k, d) for k, d in enumerate(decoded) if d is not None and d[0] != "spill"]
+        spills = [(k, d[1]) for k, d in enumerate(decoded) if d is not None and d[0] == "spill"]
+        handle = None
+        if staged:
+            handle = self.stage.submit(slot, [d[0] for _, d in staged], [d[1] for _, d in staged],
+                                       [d[2] for _, d in staged], [d[3] for _, d in staged])
+        return len(decoded), [k for k, _ in staged], handle, spills
+
+    def _collect(self, slot: int, submitted) -> list:
+        """Per file of the chunk: (phash_s64, dhash_s64) or None."""
+        count, staged_pos, handle, spills = submitted
+        out: list = [None] * count
+        if handle is not None:
+            self.stage.wait(slot)
+            for k, p, d, st in zip(staged_pos, handle["phash"].tolist(), handle["dhash"].tolist(), handle["status"].tolist()):
+                if st == 0:
                     out[k] = (_to_signed64(p), _to_signed64(d))
+        for k, arr in spills:                                    # larger than a staging buffer's free space
+            sig = self.stage.hash_one(arr)
+            if sig is not None:
+                out[k] = (_to_signed64(sig[0]), _to_signed64(sig[1]))
         return out
 
     def run(self) -> Iterator[Tuple[int, Optional[Tuple[int, int]]]]:
         """Yields (file_id, hashes | None) in task order."""
         try:
-            pending = self._submit(0)
+            previous = None                                       # (start, slot, submitted) of the chunk on the GPU
             for start in range(0, len(self.tasks), self.chunk):
-                ahead = self._submit(start + self.chunk) if start + self.chunk < len(self.tasks) else []
-                hashed = self._hash([f.result() for f in pending])     # next chunk decodes meanwhile
-                for (fid, _), sig in zip(self.tasks[start:start + self.chunk], hashed):
+                slot, futures = self._start(start)                # decode of this chunk runs on the pool from here on
+                if previous is not None:                          # ... while the previous one is copied, hashed, handed out
+                    p_start, p_slot, p_sub = previous
+                    for (fid, _), sig in zip(self.tasks[p_start:p_start + self.chunk], self._collect(p_slot, p_sub)):
+                        yield int(fid), sig
+                previous = (start, slot, self._submit(slot, futures))
+            if previous is not None:
+                p_start, p_slot, p_sub = previous
+                for (fid, _), sig in zip(self.tasks[p_start:p_start + self.chunk], self._collect(p_slot, p_sub)):
                     yield int(fid), sig
-                pending = ahead
         finally:
-            self.pool.shutdown(wait=False, cancel_futures=True)
+            self.pool.shutdown(wait=True, cancel_futures=True)    # no thread may still be writing into a staging buffer
+            try:
+                self.stage.wait(-1)
+            except Exception:
+                pass
 
 
 def compute_signatures_mp(tasks: List[Task], *, max_workers: Optional[int] = None, chunksize: int = 64,

@@ -67,6 +67,17 @@ def test_fast_fill_missing_signatures_end_to_end(K, tmp_path):
     assert f.phash == rows[0]["phash_u64"] & ((1 << 64) - 1)
 
 
+def test_fast_fill_spills_past_a_small_staging_buffer(K, tmp_path, monkeypatch):
+    """KE_STAGE_BYTES smaller than a chunk's pixels: what does not fit the pinned buffer is hashed on its own; same rows."""
+    items, arrays = _corpus(tmp_path)
+    monkeypatch.setenv("KE_STAGE_BYTES", str(200 * 1024))       # two or three of the corpus images per buffer
+    out = K.compute_signatures_mp(items, max_workers=3, chunksize=6)
+    assert [fid for fid, _, _ in out] == [fid for fid, _ in items]
+    for fid, ph, dh in out:
+        ep, ed = O.hash_image(arrays[fid])
+        assert (ph, dh) == (O.to_signed64(ep), O.to_signed64(ed))
+
+
 def test_ensure_signatures(K):
     conn = _make_conn()
     for file_id in range(1, 21):

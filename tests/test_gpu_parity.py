@@ -728,6 +728,81 @@ def test_host_staging_chunks_match_device_path(ctx):
     assert np.array_equal(t32[1499], O.hash_image(host[1499], want_tiles=True)[2])
 
 
+def test_pinned_staging_pipeline(ctx):
+    """ke_stage_*: producers write pixels into page-locked buffers, a submit enqueues H2D + hash and returns, the next
+    buffer is filled meanwhile.  Hashes, margins and statuses must equal ke_hash_images / the oracle for every batch, with
+    mixed sizes AND mixed channel counts inside one batch, across buffer reuse (5 batches through 2 buffers), and the
+    uniform 512x512 case must equal the device-resident path bit for bit."""
+    rng = np.random.default_rng(17)
+    ctx.stage_create(48 << 20, 64, 2)
+    try:
+        batches, handles = [], []
+        shapes_pool = [(512, 512, 3), (640, 480, 3), (333, 201, 3), (256, 256, 1), (300, 200, 4), (1024, 768, 3), (64, 64, 3), (2048, 1100, 3)]
+        for b in range(5):
+            slot, view = ctx.stage_acquire()              # batch b-2's results are handed over here
+            imgs, offs, cursor = [], [], 0
+            for k in range(14):
+                w, h, c = shapes_pool[(3 * b + k) % len(shapes_pool)]
+                im = rng.integers(0, 256, (h, w) if c == 1 else (h, w, c), dtype=np.uint8)
+                off = (cursor + 15) & ~15
+                if off + im.size > len(view):
+                    break
+                view[off:off + im.size] = im.reshape(-1)
+                cursor = off + im.size
+                imgs.append(im)
+                offs.append(off)
+            hnd = ctx.stage_submit_hash(slot, offs, [im.shape[1] for im in imgs], [im.shape[0] for im in imgs],
+                                        [1 if im.ndim == 2 else im.shape[2] for im in imgs], want_margin=True)
+            batches.append(imgs)
+            handles.append(hnd)
+        ctx.stage_wait(-1)
+        for imgs, hnd in zip(batches, handles):
+            assert hnd["status"].tolist() == [0] * len(imgs)
+            for k, im in enumerate(imgs):
+                ep, ed, _, _, em = O.hash_image(im, want_tiles=True)
+                assert (int(hnd["phash"][k]), int(hnd["dhash"][k])) == (ep, ed), im.shape
+                assert hnd["margin"][k] == np.float32(em)
+        # protocol: a bad shape is reported per image, a slot in flight cannot be submitted twice, too many images are refused
+        slot, view = ctx.stage_acquire()
+        view[:64 * 64 * 3] = 7
+        hnd = ctx.stage_submit_hash(slot, [0, 16], [64, 0], [64, 64], [3, 3])
+        assert hnd["status"].tolist() == [0, 1]
+        with pytest.raises(ValueError, match="in flight"):
+            ctx.stage_submit_hash(slot, [0], [64], [64], [3])
+        ctx.stage_wait(slot)
+        assert int(hnd["phash"][0]) == O.hash_image(np.full((64, 64, 3), 7, np.uint8))[0] and int(hnd["phash"][1]) == 0
+        with pytest.raises(ValueError, match="staging limit"):
+            ctx.stage_submit_hash(slot, [0] * 65, [8] * 65, [8] * 65, [3] * 65)
+    finally:
+        ctx.stage_destroy()
+    # uniform 512x512 through the staging buffers == the device-resident path == the oracle on samples
+    n, side = 600, 512
+    img = side * side * 3
+    host = ctx.synth_rgb(O.SEED, 2000, n, side, side)
+    dev = ctx.malloc(n * img)
+    try:
+        ctx.memcpy(dev, host, n * img)
+        p_dev, d_dev = ctx.hash_uniform(dev, n, side, side, 3)
+    finally:
+        ctx.free(dev)
+    per = 64
+    ctx.stage_create(per * img, per, 2)
+    try:
+        got = []
+        for first in range(0, n, per):
+            m = min(per, n - first)
+            slot, view = ctx.stage_acquire()
+            view[:m * img] = host[first:first + m].reshape(-1)
+            got.append(ctx.stage_submit_hash(slot, np.arange(m) * img, [side] * m, [side] * m, [3] * m))
+        ctx.stage_wait(-1)
+    finally:
+        ctx.stage_destroy()
+    assert np.array_equal(np.concatenate([g["phash"] for g in got]), p_dev)
+    assert np.array_equal(np.concatenate([g["dhash"] for g in got]), d_dev)
+    for k in (0, 63, 64, 599):
+        assert (int(p_dev[k]), int(d_dev[k])) == O.hash_image(host[k])
+
+
 @pytest.mark.parametrize("min_images", ["1", "1000000000", ""])
 def test_dispatch_sweep_random_shapes(min_images):
     """tests/fuzz_shapes.py: random widths / heights / channel counts / one or both hashes and ragged batches through

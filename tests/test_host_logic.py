@@ -160,8 +160,31 @@ def test_fastsig_drops_missing_files_and_reports_progress(K, monkeypatch, tmp_pa
         Image.new("RGB", (8, 8), (k, k, k)).save(p)
         paths.append((k + 1, str(p)))
     paths.insert(2, (99, str(tmp_path / "missing.png")))
-    monkeypatch.setattr(fs._phash, "hash_batch", lambda imgs, want_dhash=True, device=0: (
-        np.arange(len(imgs), dtype=np.uint64) + np.uint64(1 << 63), np.zeros(len(imgs), np.uint64), np.ones(len(imgs), bool)))
+    class FakeStage:                                       # the four calls of fastsig._GpuStage, no device behind them
+        def __init__(self, device, stage_bytes, max_images):
+            self.bufs, self.turn, self.submitted = [np.zeros(4096, np.uint8), np.zeros(4096, np.uint8)], 0, []
+
+        def acquire(self):
+            slot = self.turn
+            self.turn ^= 1
+            return slot, self.bufs[slot]
+
+        def submit(self, slot, offsets, widths, heights, channels):
+            assert all(o % 16 == 0 for o in offsets) and list(widths) == [8] * len(offsets) and list(channels) == [3] * len(offsets)
+            for o in offsets:                              # the decode threads wrote the pixels where the allocator said
+                px = self.bufs[slot][o:o + 192]
+                assert len(set(px.tolist())) == 1
+            self.submitted.append(len(offsets))
+            n = len(offsets)
+            return {"phash": np.arange(n, dtype=np.uint64) + np.uint64(1 << 63), "dhash": np.zeros(n, np.uint64), "status": np.zeros(n, np.int32)}
+
+        def wait(self, slot):
+            pass
+
+        def hash_one(self, arr):
+            return (1 << 63, 0)
+
+    monkeypatch.setattr(fs, "_make_stage", FakeStage)
     seen = []
     out = fs.compute_signatures_mp(paths, max_workers=2, chunksize=4, progress=lambda d, t: seen.append((d, t)))
     assert [r[0] for r in out] == [1, 2, 3, 4, 5] and seen == [(6, 6)]

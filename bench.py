@@ -9,11 +9,11 @@ at N=1, configs[2] -- the same 100 000 images split over the ranks -- at N>1).
 
 One step = one pass of the hot path over the whole corpus, inputs already resident in HBM:
   1. ke_hash_uniform   : fused pHash kernel over this rank's images (device in, device out)
-  2. all-gather (N>1)  : ONE RCCL all_gather_into_tensor of the 64-bit hash shards
+  2. all-gather (N>1)  : ONE ncclAllGather of the 64-bit hash shards + reorder kernel (ke_allgather_hashes, RCCL behind the C ABI)
   3. ke_hamming_scan   : this rank's share of the tile triangle, edges compacted on the device
-  4. edge merge (N>1)  : all-gather of counts + padded edge lists
-  5. ke_cluster_labels : host union-find -> cluster membership
-PyTorch only provides device memory, the stream and the process group.
+  4. edge merge (N>1)  : ONE all-gather of fixed-width edge records + one D2H copy (ke_allgather_edges)
+  5. ke_cluster_labels : host union-find -> cluster membership (rank 0)
+PyTorch only provides device memory, the stream and the rendezvous (process group).
 Rank 0 prints ONE JSON line (contract in the task statement).
 """
 from __future__ import annotations
@@ -46,6 +46,8 @@ def parse_args():
     ap.add_argument("--ssim-threshold", type=float, default=None,
                     help="BASELINE configs[3] flavour: re-check every candidate edge with the SSIM kernel inside the step (pairs sharded over the ranks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--torch-collectives", action="store_true",
+                    help="exchange through torch.distributed (kobato_eyes_amd.distributed) instead of the library's own RCCL entry points")
     ap.add_argument("--phase-timing", action="store_true", help="after the timed run, time each phase of a step with syncs in between (stderr)")
     ap.add_argument("--cpu-sample", type=int, default=16000, help="images hashed by the CPU oracle for the baseline")
     return ap.parse_args()
@@ -98,7 +100,7 @@ def main():
     import torch.distributed as dist
 
     from kobato_eyes_amd import _native
-    from kobato_eyes_amd.distributed import allgather_edge_buffers, allgather_hashes, ssim_refine_sharded
+    from kobato_eyes_amd.distributed import RcclExchange, allgather_edge_buffers, allgather_hashes, ssim_refine_sharded
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -116,6 +118,9 @@ def main():
     ctx = _native.Context(local_rank)
     stream = torch.cuda.current_stream()
     ctx.set_stream(stream.cuda_stream)
+    # the exchange steps: ke_allgather_hashes / ke_allgather_edges on the library's own RCCL communicator (the process
+    # group only carried the unique id)
+    exchange = RcclExchange(ctx) if distributed and not args.torch_collectives else None
 
     n_total, side = args.images, args.side
     img_bytes = side * side * 3
@@ -135,6 +140,7 @@ def main():
     local_dhash = torch.zeros(per, dtype=torch.int64, device=dev) if args.dhash else None
     cap = max(1 << 16, n_total)
     edges_dev = torch.empty(cap * 24, dtype=torch.uint8, device=dev)
+    table_dev = torch.empty(n_total, dtype=torch.int64, device=dev) if exchange else None
     torch.cuda.synchronize()
 
     state = {}
@@ -146,7 +152,11 @@ def main():
                          dhash_out=local_dhash.data_ptr() if args.dhash else None, want_dhash=args.dhash,
                          margin_out=local_margin.data_ptr())
         # 2. the one exchange on the data path
-        table = allgather_hashes(local_hash, n_total) if distributed else local_hash[:n_total]
+        if exchange:
+            exchange.hashes(local_hash.data_ptr(), n_total, table_dev.data_ptr())
+            table = table_dev
+        else:
+            table = allgather_hashes(local_hash, n_total) if distributed else local_hash[:n_total]
         # 3. sharded scan; edges stay on the device, the count comes back with the counters
         while True:
             edges, counters = _scan(ctx, table, n_total, args.threshold, rank, world, edges_dev, cap)
@@ -155,7 +165,9 @@ def main():
             cap = int(edges)
             edges_dev = torch.empty(cap * 24, dtype=torch.uint8, device=dev)
         # 4. merge edge lists
-        if distributed:
+        if exchange:
+            all_edges, _ = exchange.edges(edges_dev.data_ptr(), edges)
+        elif distributed:
             merged, _ = allgather_edge_buffers(edges_dev, edges)
             all_edges = merged.view(_native.EDGE_DTYPE)
         else:
@@ -180,8 +192,8 @@ def main():
             # decisions that a 1e-4 disagreement with skimage could flip (the SSIM value is unpinned against the real library)
             state["ssim_near_threshold"] = int((np.abs(ssim - args.ssim_threshold) < 1e-4).sum())
             all_edges = all_edges[ssim >= args.ssim_threshold]
-        # 5. cluster membership on the host
-        labels = _native.cluster_labels(all_edges, n_total)
+        # 5. cluster membership on the host: rank 0 (every rank holds the merged edges and could)
+        labels = _native.cluster_labels(all_edges, n_total) if rank == 0 else None
         state.update(table=table, edges=all_edges, labels=labels, pairs=int(counters[0]))
 
     def _scan(ctx, table, n, thr, part, parts, edges_dev, cap):
@@ -228,13 +240,19 @@ def main():
             ctx.hash_uniform(pixels.data_ptr(), n_local, side, side, 3, phash_out=local_hash.data_ptr(), want_dhash=False)
             lap("hash", t0)
             t0 = time.perf_counter()
-            table = allgather_hashes(local_hash, n_total) if distributed else local_hash[:n_total]
+            if exchange:
+                exchange.hashes(local_hash.data_ptr(), n_total, table_dev.data_ptr())
+                table = table_dev
+            else:
+                table = allgather_hashes(local_hash, n_total) if distributed else local_hash[:n_total]
             lap("allgather_hashes", t0)
             t0 = time.perf_counter()
             edges, counters = _scan(ctx, table, n_total, args.threshold, rank, world, edges_dev, cap)
             lap("scan+count", t0)
             t0 = time.perf_counter()
-            if distributed:
+            if exchange:
+                all_edges, _ = exchange.edges(edges_dev.data_ptr(), edges)
+            elif distributed:
                 merged, _ = allgather_edge_buffers(edges_dev, edges)
                 all_edges = merged.view(_native.EDGE_DTYPE)
             else:
@@ -277,6 +295,8 @@ def main():
                             f"band 16x4 (BASELINE configs[{1 if world == 1 else 2}])",
                 "images": n_total, "side": side, "hamming_threshold": args.threshold, "dhash": bool(args.dhash),
                 "partition": f"image i on rank i mod {world}; scan tiles dealt round-robin",
+                "exchange": ("none (one GPU)" if not distributed else "torch.distributed all_gather_into_tensor" if not exchange
+                             else "ke_allgather_hashes + ke_allgather_edges (RCCL behind the C ABI)"),
                 "step": "hash kernel -> (all-gather) -> scan kernel -> edges to host -> "
                         + ("SSIM refine of the candidate edges -> " if args.ssim_threshold is not None else "") + "union-find labels",
             },
@@ -310,6 +330,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(ctx, args, state["table"].cpu().numpy().view(np.uint64))
         print(json.dumps(out), flush=True)
+    if exchange:
+        exchange.close()
     if distributed:
         dist.barrier()
         dist.destroy_process_group()

@@ -168,6 +168,32 @@ int ke_hamming_scan(ke_ctx *ctx, const uint64_t *hashes, const int64_t *ids, con
  * work: label_out[v] = smallest node of v's component for v < n_nodes. */
 int ke_cluster_labels(const ke_edge *edges, int64_t n_edges, int64_t n_nodes, int64_t *label_out);
 
+/* ---- multi-GPU exchange on RCCL (xGMI): one process per GPU, image i on rank i mod world.  The reference has no
+ * counterpart (it is a single process, src/core/fastsig.py:81-85 is its only parallelism); these are the two exchange
+ * steps of the sharded path: the hash table before the scan, the edge lists after it.  RCCL (librccl.so.1) is bound at
+ * first use; a process that already carries one -- PyTorch's -- is joined.  `comm` is an ncclComm_t as void*: made by
+ * ke_comm_create from a 128-byte unique id (ke_comm_unique_id on rank 0, distributed by the host), or any communicator
+ * of the calling process whose ranks are the ranks of this job.  All of it is ordered on the context's stream.
+ *
+ * ke_allgather_u64   : plain ncclAllGather, n_local entries per rank, rank order (device pointers).
+ * ke_allgather_hashes: every rank passes its ceil(n_total / world) local hashes (image rank + k * world at slot k, padded);
+ *                      table[i] = hash of image i for i < n_total on every rank: ONE all-gather + a reorder kernel.
+ * ke_allgather_edges : per-rank edge lists of ke_hamming_scan (device, n_local valid records) -> all edges of all ranks in
+ *                      a host array, rank by rank; *n_total_out may exceed capacity (then only whole records that fit are
+ *                      written; retry larger).  counts_out (nullable, world entries): edges per rank.  ONE all-gather of
+ *                      fixed-width records [count | first K edges] and one device-to-host copy; K follows the largest list
+ *                      seen on this context, a second gather happens only when a list outgrows it.  Blocks. */
+int ke_comm_unique_id(uint8_t *id_out /* 128 bytes */);
+int ke_comm_create(ke_ctx *ctx, const uint8_t *unique_id, int32_t world, int32_t rank, void **comm_out);
+int ke_comm_destroy(ke_ctx *ctx, void *comm);
+int ke_allgather_u64(ke_ctx *ctx, void *comm, int32_t world, const uint64_t *local, int64_t n_local, uint64_t *gathered);
+int ke_allgather_hashes(ke_ctx *ctx, void *comm, int32_t world, const uint64_t *local, int64_t n_total, uint64_t *table);
+/* the reorder step on its own, for hosts that gather with another library: gathered = world shards of ceil(n_total / world)
+ * entries in rank order (device), table[i] = gathered[(i mod world) * per + i / world] */
+int ke_interleave_shards(ke_ctx *ctx, const uint64_t *gathered, int32_t world, int64_t n_total, uint64_t *table);
+int ke_allgather_edges(ke_ctx *ctx, void *comm, int32_t world, const ke_edge *local, int64_t n_local, ke_edge *merged_out,
+                       int64_t capacity, int64_t *n_total_out, int64_t *counts_out);
+
 /* ---- SSIM refine: replaces dup.refine._compute_ssim (src/dup/refine.py:44-52 ->
  * skimage.metrics.structural_similarity, 7x7 uniform window, float32, data_range 1) for
  * pairs of equally sized images.  images: n_images interleaved images of width x height x

@@ -14,7 +14,7 @@ from .fastsig import bulk_upsert_signatures, compute_signatures_mp, fast_fill_mi
 from .phash import dhash, hamming64, hash_batch, phash, phash_dhash
 from .refine_parallel import (refine_by_pixels_parallel, refine_by_tilehash_parallel, tile_ahash_bits,
                               tile_ahash_from_arrays, tile_hamming)
-from .refine import RefinedMatch, RefinementThresholds, compute_ssim, refine_pair, ssim_pairs
+from .refine import RefinedMatch, RefinementThresholds, compute_ssim, refine_pair, refine_pairs, ssim_pairs
 from .scanner import (DuplicateCluster, DuplicateClusterEntry, DuplicateFile, DuplicateScanConfig, DuplicateScanner,
                       assemble_clusters)
 from .signature import compute_signatures_from_image, ensure_signatures
@@ -27,5 +27,5 @@ __all__ = [
     "tile_ahash_bits", "tile_hamming", "tile_ahash_from_arrays", "refine_by_tilehash_parallel", "refine_by_pixels_parallel",
     "choose_keeper", "sort_entries_for_display", "rebuild_cluster_after_removal", "rebuild_clusters_after_removal",
     "cluster_hamming_score", "default_checked_entries",
-    "refine_pair", "compute_ssim", "ssim_pairs", "RefinementThresholds", "RefinedMatch", "Cluster", "ClusterBuilder",
+    "refine_pair", "refine_pairs", "compute_ssim", "ssim_pairs", "RefinementThresholds", "RefinedMatch", "Cluster", "ClusterBuilder",
 ]

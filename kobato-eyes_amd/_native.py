@@ -27,7 +27,8 @@ EXPORTS = (
     "ke_get_stream", "ke_synchronize", "ke_device_info", "ke_malloc", "ke_free", "ke_memcpy",
     "ke_hash_images", "ke_hash_uniform", "ke_hash_images_ex", "ke_hash_uniform_ex", "ke_luma_tiles_uniform", "ke_hamming_scan",
     "ke_stage_create", "ke_stage_destroy", "ke_stage_acquire", "ke_stage_submit_hash", "ke_stage_wait",
-    "ke_cluster_labels", "ke_ssim_pairs_uniform", "ke_ssim_set_mode", "ke_resize_luma_uniform", "ke_fit_luma_uniform", "ke_tile_ahash", "ke_sad_pairs", "ke_synth_rgb",
+    "ke_comm_unique_id", "ke_comm_create", "ke_comm_destroy", "ke_allgather_u64", "ke_allgather_hashes", "ke_allgather_edges",
+    "ke_interleave_shards", "ke_cluster_labels", "ke_ssim_pairs_uniform", "ke_ssim_set_mode", "ke_resize_luma_uniform", "ke_fit_luma_uniform", "ke_tile_ahash", "ke_sad_pairs", "ke_synth_rgb",
     "ke_synth_rgb_indexed",
     "ke_synth_hashes", "ke_last_kernel_ms",
 )
@@ -82,6 +83,13 @@ def load_library() -> C.CDLL:
         lib.ke_stage_acquire.argtypes = [vp, C.POINTER(i32), C.POINTER(vp), C.POINTER(C.c_size_t)]
         lib.ke_stage_submit_hash.argtypes = [vp, i32, vp, vp, vp, vp, i64, vp, vp, vp, vp]
         lib.ke_stage_wait.argtypes = [vp, i32]
+        lib.ke_comm_unique_id.argtypes = [vp]
+        lib.ke_comm_create.argtypes = [vp, vp, i32, i32, C.POINTER(vp)]
+        lib.ke_comm_destroy.argtypes = [vp, vp]
+        lib.ke_allgather_u64.argtypes = [vp, vp, i32, vp, i64, vp]
+        lib.ke_allgather_hashes.argtypes = [vp, vp, i32, vp, i64, vp]
+        lib.ke_allgather_edges.argtypes = [vp, vp, i32, vp, i64, vp, i64, C.POINTER(i64), vp]
+        lib.ke_interleave_shards.argtypes = [vp, vp, i32, i64, vp]
         lib.ke_hamming_scan.argtypes = [vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, dbl, i64, vp, i64,
                                         C.POINTER(i64), vp]
         lib.ke_cluster_labels.argtypes = [vp, i64, i64, vp]
@@ -99,7 +107,8 @@ def load_library() -> C.CDLL:
         for name in ("ke_set_stream", "ke_synchronize", "ke_device_info", "ke_malloc", "ke_free", "ke_memcpy",
                      "ke_hash_images", "ke_hash_uniform", "ke_hash_images_ex", "ke_hash_uniform_ex", "ke_luma_tiles_uniform", "ke_hamming_scan",
                      "ke_stage_create", "ke_stage_destroy", "ke_stage_acquire", "ke_stage_submit_hash", "ke_stage_wait",
-                     "ke_cluster_labels", "ke_ssim_pairs_uniform", "ke_ssim_set_mode", "ke_resize_luma_uniform", "ke_fit_luma_uniform", "ke_tile_ahash",
+                     "ke_comm_unique_id", "ke_comm_create", "ke_comm_destroy", "ke_allgather_u64", "ke_allgather_hashes", "ke_allgather_edges",
+                     "ke_interleave_shards", "ke_cluster_labels", "ke_ssim_pairs_uniform", "ke_ssim_set_mode", "ke_resize_luma_uniform", "ke_fit_luma_uniform", "ke_tile_ahash",
                      "ke_sad_pairs", "ke_synth_rgb", "ke_synth_rgb_indexed", "ke_synth_hashes"):
             getattr(lib, name).restype = C.c_int
         _lib = lib
@@ -273,6 +282,37 @@ class Context:
         with self._lock:
             self._check(self._lib.ke_stage_wait(self._h, int(slot)), "ke_stage_wait")
 
+    # -- RCCL exchange ----------------------------------------------------------------------
+    def comm_create(self, unique_id: bytes, world: int, rank: int) -> int:
+        """ncclCommInitRank on this context's device; ``unique_id``: the 128 bytes of ``comm_unique_id()`` of rank 0."""
+        comm = C.c_void_p()
+        buf = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
+        self._check(self._lib.ke_comm_create(self._h, buf, world, rank, C.byref(comm)), "ke_comm_create")
+        return int(comm.value)
+
+    def comm_destroy(self, comm: int) -> None:
+        self._check(self._lib.ke_comm_destroy(self._h, comm), "ke_comm_destroy")
+
+    def allgather_hashes(self, comm: int, world: int, local, n_total: int, table) -> None:
+        """local: device pointer to ceil(n_total/world) u64; table: device pointer to n_total u64 (corpus order)."""
+        self._check(self._lib.ke_allgather_hashes(self._h, comm, world, _addr(local), n_total, _addr(table)), "ke_allgather_hashes")
+
+    def interleave_shards(self, gathered, world: int, n_total: int, table) -> None:
+        self._check(self._lib.ke_interleave_shards(self._h, _addr(gathered), world, n_total, _addr(table)), "ke_interleave_shards")
+
+    def allgather_edges(self, comm: int, world: int, local, n_local: int):
+        """local: device pointer to this rank's ke_edge records.  Returns (all edges of all ranks as a host array, counts)."""
+        counts = np.zeros(world, np.int64)
+        total = C.c_int64(0)
+        cap = max(1024, 2 * int(n_local) * world)
+        while True:
+            merged = np.empty(cap, EDGE_DTYPE)
+            self._check(self._lib.ke_allgather_edges(self._h, comm, world, _addr(local), n_local, _addr(merged), cap, C.byref(total),
+                                                     _addr(counts)), "ke_allgather_edges")
+            if total.value <= cap:
+                return merged[: total.value], counts
+            cap = int(total.value)
+
     # -- scan -------------------------------------------------------------------------------
     def hamming_scan(self, hashes, n: int, *, ids=None, sizes=None, threshold=8, band_bits=16, band_count=4,
                      size_ratio: float = 0.0, bucket_pair_cap: int = 0, part_index=0, part_count=1,
@@ -402,6 +442,16 @@ def get_context(device: int = 0) -> Context:
         if ctx is None:
             ctx = _default[device] = Context(device)
         return ctx
+
+
+def comm_unique_id() -> bytes:
+    """ncclGetUniqueId through the library (rank 0 calls it and hands the 128 bytes to the other ranks)."""
+    lib = load_library()
+    buf = (C.c_uint8 * 128)()
+    rc = lib.ke_comm_unique_id(buf)
+    if rc != KE_OK:
+        raise RuntimeError(f"ke_comm_unique_id failed (rc={rc}): {lib.ke_create_error().decode('utf-8', 'replace')}")
+    return bytes(buf)
 
 
 def cluster_labels(edges: np.ndarray, n_nodes: int) -> np.ndarray:

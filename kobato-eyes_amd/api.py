@@ -75,7 +75,10 @@ def find_duplicates(files: Iterable, *, hamming_threshold: int = 8, ssim_thresho
             logger.debug("skipping row without a usable hash")
     config = DuplicateScanConfig(hamming_threshold=hamming_threshold, size_ratio=size_ratio, band_bits=band_bits,
                                  band_count=band_count)
-    scanner = scanner_factory(config)
+    try:
+        scanner = scanner_factory(config, device=device)      # one process per GPU: scan on the caller's device
+    except TypeError:
+        scanner = scanner_factory(config)                     # a foreign factory with the reference's one-argument signature
     if ssim_threshold is None:
         return scanner.build_clusters(parsed)
     from .scanner import assemble_clusters
@@ -83,15 +86,12 @@ def find_duplicates(files: Iterable, *, hamming_threshold: int = 8, ssim_thresho
     candidates = [f for f in parsed if f.phash is not None]
     if len(candidates) < 2:
         return []
-    edges = scanner.candidate_edges(candidates)
+    edges = list(scanner.candidate_edges(candidates).values())
     by_id = {f.file_id: f for f in candidates}
-    kept = []
-    for edge in edges.values():
-        fa, fb = by_id[edge.file_id_a], by_id[edge.file_id_b]
-        match = _refine.refine_pair(fa.file_id, fb.file_id, fa.path, fb.path,
-                                    thresholds=_refine.RefinementThresholds(ssim=ssim_threshold), device=device)
-        if match is not None and match.is_duplicate:
-            kept.append(edge)
+    # every file decoded once, one fit + one SSIM launch per size group (refine_pairs), not one of each per edge
+    matches = _refine.refine_pairs([(e.file_id_a, e.file_id_b, by_id[e.file_id_a].path, by_id[e.file_id_b].path) for e in edges],
+                                   thresholds=_refine.RefinementThresholds(ssim=ssim_threshold), device=device)
+    kept = [e for e, m in zip(edges, matches) if m is not None and m.is_duplicate]
     return assemble_clusters(candidates, kept) if kept else []
 
 

@@ -221,6 +221,7 @@ KE_API void ke_destroy(ke_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     stage_free(ctx);
+    if (ctx->h_comm) (void)hipHostFree(ctx->h_comm);
     for (auto &b : ctx->buf)
         if (b.ptr) (void)hipFree(b.ptr);
     free_coeff_cache(ctx);

@@ -94,6 +94,8 @@ enum {
     KE_BUF_SCAN_EXP,     // hashes expanded to matrix-core operands (64 B each)
     KE_BUF_SSIM_IN,
     KE_BUF_SSIM_AUX,
+    KE_BUF_COMM,         // gathered hash shards before they are put back into corpus order
+    KE_BUF_COMM_EDGES,   // edge records: [send | world x recv]
     KE_BUF_COUNT
 };
 
@@ -131,6 +133,9 @@ struct ke_ctx {
     hipEvent_t ev0[KE_T_COUNT] = {}, ev1[KE_T_COUNT] = {};
     bool ev_valid[KE_T_COUNT] = {};
     KeStage *stage = nullptr;
+    int64_t edge_slots = 1024;       // edges carried by one record of ke_allgather_edges (follows the largest list seen)
+    void *h_comm = nullptr;          // pinned landing zone of the gathered edge records
+    size_t h_comm_bytes = 0;
     bool ssim_exact = false;         // ke_ssim_set_mode: false = integer-sum kernel (default), true = fp64-carry kernel
     float *margin_cur = nullptr;     // device array the hash kernels of the CURRENT call write tie margins to (slot = hash slot)
     bool dct_tables_ready = false;   // __constant__ tables are per device: uploaded once per context

@@ -15,6 +15,40 @@ from typing import Optional
 import numpy as np
 
 
+class RcclExchange:
+    """The two exchange steps of the sharded path through the C ABI (``ke_allgather_hashes`` / ``ke_allgather_edges``,
+    include/keyes.h) on a communicator the library makes itself: rank 0 draws the unique id, ``torch.distributed`` (any
+    backend -- it is only the rendezvous) hands it round, every rank joins with ``ke_comm_create``.  Without a process
+    group this is a one-rank communicator (the RCCL calls still run)."""
+
+    def __init__(self, ctx, *, group=None) -> None:
+        import torch.distributed as dist
+
+        from . import _native
+
+        self.ctx = ctx
+        live = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if live else 1
+        self.rank = dist.get_rank(group) if live else 0
+        box = [_native.comm_unique_id() if self.rank == 0 else None]
+        if live and self.world > 1:
+            dist.broadcast_object_list(box, src=0, group=group)
+        self.comm = ctx.comm_create(box[0], self.world, self.rank)
+
+    def hashes(self, local_ptr: int, n_total: int, table_ptr: int) -> None:
+        """``local_ptr``: this rank's ceil(n_total / world) hashes (device); ``table_ptr``: n_total hashes, corpus order."""
+        self.ctx.allgather_hashes(self.comm, self.world, local_ptr, n_total, table_ptr)
+
+    def edges(self, edges_ptr: int, n_local: int):
+        """-> (every rank's edges as one host array, rank by rank; per-rank counts)."""
+        return self.ctx.allgather_edges(self.comm, self.world, edges_ptr, n_local)
+
+    def close(self) -> None:
+        if self.comm:
+            self.ctx.comm_destroy(self.comm)
+            self.comm = 0
+
+
 def owned_indices(n_items: int, rank: int, world: int) -> np.ndarray:
     """Positions of the corpus this rank hashes: i = rank (mod world)."""
     return np.arange(rank, n_items, world, dtype=np.int64)
@@ -135,6 +169,8 @@ def ssim_refine_sharded(ctx, edges: np.ndarray, fetch_images, width: int, height
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     n = len(edges)
+    if n == 0:                                  # nothing to refine: no zero-length collective
+        return np.empty(0, np.float64)
     mine = np.arange(rank, n, world)
     per = (n + world - 1) // world
     local = np.full(per, np.nan)

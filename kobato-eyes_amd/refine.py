@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import importlib
 import logging
+import os
 from dataclasses import dataclass
 from pathlib import Path
 from typing import Optional, Sequence
@@ -78,6 +79,109 @@ def ssim_pairs(images: np.ndarray, pair_a: Sequence[int], pair_b: Sequence[int],
     return _native.get_context(device).ssim_pairs_uniform(images, n, w, h, ch, pair_a, pair_b)
 
 
+def _decide(file_id_a: int, file_id_b: int, ssim_value: Optional[float], errors: list, cfg: RefinementThresholds) -> RefinedMatch:
+    """The decision and ``reason`` text of src/dup/refine.py:100-117 (ORB left out)."""
+    reasons: list[str] = []
+    if ssim_value is not None and ssim_value >= cfg.ssim:
+        reasons.append(f"ssim>={cfg.ssim}")
+    reason = ", ".join(reasons or errors) if (reasons or errors) else "below thresholds"
+    return RefinedMatch(file_id_a, file_id_b, ssim_value, None, bool(reasons), reason)
+
+
+def refine_pairs(pairs: Sequence[tuple], *, thresholds: Optional[RefinementThresholds] = None, device: int = 0,
+                 io_workers: int = 8, max_decoded_bytes: int = 1 << 30, stats: Optional[dict] = None) -> list:
+    """``refine_pair`` for a list of ``(file_id_a, file_id_b, path_a, path_b)``: the same ``RefinedMatch`` (or ``None``)
+    per pair, in input order -- but every file is decoded once however many pairs share it, and the kernels see groups
+    instead of single pairs: one ``ke_fit_luma_uniform`` launch per (source size, channels, common size) and one
+    ``ke_ssim_pairs_uniform`` launch per common size.  The reference's loop decodes both files of every pair again and
+    runs the metric pair by pair (src/dup/refine.py:82-98).
+
+    Pairs are worked off in runs whose decoded files stay below ``max_decoded_bytes``.  ``stats`` (optional dict)
+    receives the launch and decode counts.
+    """
+    from concurrent.futures import ThreadPoolExecutor
+
+    cfg = thresholds or RefinementThresholds()
+    ctx = _native.get_context(device)
+    out: list = [None] * len(pairs)
+    count = {"decodes": 0, "fit_launches": 0, "ssim_launches": 0, "pairs": len(pairs)}
+
+    def run(chunk: list, decoded: dict) -> None:
+        # (common size) -> pairs; (path, common size) -> plane slot inside that size's plane stack
+        by_size: dict = {}
+        for k in chunk:
+            fid_a, fid_b, pa, pb = pairs[k]
+            ia, ib = decoded.get(str(pa)), decoded.get(str(pb))
+            if ia is None or ib is None:
+                out[k] = None                                      # unreadable file: src/dup/refine.py:82-85
+                continue
+            w, h = min(ia.shape[1], ib.shape[1]), min(ia.shape[0], ib.shape[0])
+            if w == 0 or h == 0:
+                w, h = max(ia.shape[1], ib.shape[1]), max(ia.shape[0], ib.shape[0])
+            if w < 7 or h < 7:                                     # skimage raises for images smaller than its window
+                logger.warning("SSIM refinement failed for %s and %s: win_size exceeds image extent", pa, pb)
+                out[k] = _decide(fid_a, fid_b, None, ["ssim unavailable"], cfg)
+                continue
+            by_size.setdefault((w, h), []).append(k)
+        for (w, h), ks in by_size.items():
+            # plane stack of this common size: the files of one source shape sit next to each other, so a fit launch
+            # writes its whole group straight into place
+            groups: dict = {}
+            for k in ks:
+                for p in (str(pairs[k][2]), str(pairs[k][3])):
+                    members = groups.setdefault(decoded[p].shape, {})
+                    members.setdefault(p, len(members))
+            slots, base = {}, 0
+            for shape, members in groups.items():
+                for p, j in members.items():
+                    slots[p] = base + j
+                base += len(members)
+            planes = ctx.malloc(base * w * h)
+            try:
+                at = 0
+                for shape, members in groups.items():
+                    ch = 1 if len(shape) == 2 else shape[2]
+                    stack = np.stack([decoded[p] for p in members])
+                    ctx.fit_luma_uniform(stack, len(members), shape[1], shape[0], ch, w, h, _native.FILTER_BICUBIC,
+                                         out=planes + at * w * h)
+                    count["fit_launches"] += 1
+                    at += len(members)
+                scores = ctx.ssim_pairs_uniform(planes, base, w, h, 1, [slots[str(pairs[k][2])] for k in ks],
+                                                [slots[str(pairs[k][3])] for k in ks])
+                count["ssim_launches"] += 1
+            finally:
+                ctx.free(planes)
+            for k, sc in zip(ks, scores.tolist()):
+                out[k] = _decide(pairs[k][0], pairs[k][1], float(sc), [], cfg)
+
+    def load(p: str):
+        img = load_rgb(p)
+        return None if img is None else _phash.image_to_array(img)
+
+    with ThreadPoolExecutor(max_workers=max(1, io_workers)) as pool:
+        start = 0
+        while start < len(pairs):
+            need, size_est, stop = [], 0, start                    # grow the run until the decode budget is reached
+            seen: set = set()
+            while stop < len(pairs) and (size_est < max_decoded_bytes or stop == start):
+                for p in (str(pairs[stop][2]), str(pairs[stop][3])):
+                    if p not in seen:
+                        seen.add(p)
+                        need.append(p)
+                        try:
+                            size_est += 48 * os.path.getsize(p)    # rough decoded size of a compressed file; only paces the runs
+                        except OSError:
+                            pass
+                stop += 1
+            arrays = list(pool.map(load, need))
+            count["decodes"] += len(need)
+            run(list(range(start, stop)), dict(zip(need, arrays)))
+            start = stop
+    if stats is not None:
+        stats.update(count)
+    return out
+
+
 def refine_pair(file_id_a: int, file_id_b: int, path_a, path_b, *, thresholds: Optional[RefinementThresholds] = None,
                 device: int = 0) -> Optional[RefinedMatch]:
     image_a, image_b = load_rgb(path_a), load_rgb(path_b)
@@ -91,11 +195,7 @@ def refine_pair(file_id_a: int, file_id_b: int, path_a, path_b, *, thresholds: O
     except Exception as exc:
         logger.warning("SSIM refinement failed for %s and %s: %s", path_a, path_b, exc)
         errors.append("ssim unavailable")
-    reasons: list[str] = []
-    if ssim_value is not None and ssim_value >= cfg.ssim:
-        reasons.append(f"ssim>={cfg.ssim}")
-    reason = ", ".join(reasons or errors) if (reasons or errors) else "below thresholds"
-    return RefinedMatch(file_id_a, file_id_b, ssim_value, None, bool(reasons), reason)
+    return _decide(file_id_a, file_id_b, ssim_value, errors, cfg)
 
 
-__all__ = ["RefinementThresholds", "RefinedMatch", "refine_pair", "compute_ssim", "ssim_pairs"]
+__all__ = ["RefinementThresholds", "RefinedMatch", "refine_pair", "refine_pairs", "compute_ssim", "ssim_pairs"]

@@ -32,7 +32,8 @@ def _has_row(conn, file_id: int) -> bool:
     return conn.execute("SELECT 1 FROM signatures WHERE file_id=? LIMIT 1", (file_id,)).fetchone() is not None
 
 
-def ensure_signatures(conn, file_id: int, *, image=None, path: Optional[str | Path] = None, force: bool = False) -> bool:
+def ensure_signatures(conn, file_id: int, *, image=None, path: Optional[str | Path] = None, force: bool = False,
+                      device: int = 0) -> bool:
     """True when a signature row exists afterwards (kept or freshly written), False on any failure.
     ``force`` recomputes even when a row is present."""
     try:
@@ -41,7 +42,7 @@ def ensure_signatures(conn, file_id: int, *, image=None, path: Optional[str | Pa
         source = image if image is not None else (load_rgb(Path(path)) if path is not None else None)
         if source is None:
             return False
-        p, d = compute_signatures_from_image(source)
+        p, d = compute_signatures_from_image(source, device=device)
         upsert_signatures(conn, file_id=file_id, phash_u64=p, dhash_u64=d)
         return True
     except Exception as exc:

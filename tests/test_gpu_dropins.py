@@ -160,6 +160,36 @@ def test_find_duplicates_and_headless_scan(K, tmp_path):
     assert strict == [] and len(loose) == len(plain)
 
 
+def test_refine_pairs_batches_the_seam(K, tmp_path):
+    """refine_pairs == the per-pair loop of refine_pair (same RefinedMatch list, None for unreadable files, "ssim
+    unavailable" for images under 7 px), with every file decoded once and a handful of launches instead of three per pair."""
+    rng = np.random.default_rng(5)
+    files = {}
+    for k, (w, h) in enumerate([(256, 256)] * 10 + [(320, 240)] * 4 + [(200, 160), (5, 5), (6, 300)]):
+        base = O.synth_rgb(1000 + 10 * (k // 2), w, h)
+        if k % 2:
+            base = np.clip(base.astype(np.int16) + rng.integers(-3, 4, base.shape), 0, 255).astype(np.uint8)
+        p = tmp_path / f"r{k:02d}.png"
+        Image.fromarray(base).save(p)
+        files[k] = p
+    (tmp_path / "broken.png").write_bytes(b"nope")
+    files[99] = tmp_path / "broken.png"
+    pairs = [(a, b, files[a], files[b]) for a, b in
+             [(0, 1), (2, 3), (4, 5), (6, 7), (8, 9), (0, 2), (1, 9), (10, 11), (12, 13), (10, 14), (0, 14), (0, 10), (15, 15), (16, 0),
+              (0, 99), (99, 1), (3, 4), (5, 6), (7, 8), (2, 9), (1, 3), (0, 9)]]
+    th = K.RefinementThresholds(ssim=0.9)
+    one_by_one = [K.refine_pair(a, b, pa, pb, thresholds=th) for a, b, pa, pb in pairs]
+    stats = {}
+    batched = K.refine_pairs(pairs, thresholds=th, stats=stats)
+    assert batched == one_by_one
+    assert sum(m is None for m in batched) == 2 and sum(m is not None and m.reason == "ssim unavailable" for m in batched) == 2
+    assert any(m is not None and m.is_duplicate for m in batched) and any(m is not None and m.reason == "below thresholds" for m in batched)
+    launches = stats["fit_launches"] + stats["ssim_launches"]
+    assert stats["decodes"] == 18 and launches * 3 <= len(pairs), stats          # per pair: 2 decodes, 2 fits, 1 SSIM = 66 launches
+    # a decode budget of one file per run: many runs, same answers
+    assert K.refine_pairs(pairs, thresholds=th, max_decoded_bytes=1) == one_by_one
+
+
 def test_shipped_refine_stage_kernels_and_dropins(K, tmp_path):
     """ke_resize_luma_uniform (BILINEAR) + ke_tile_ahash + ke_sad_pairs and the ui.dup_refine_parallel drop-ins
     against what the reference itself produced for the same files (tests/golden/refine_parallel_golden.json)."""

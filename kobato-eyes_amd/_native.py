@@ -41,12 +41,37 @@ class NativeUnavailable(RuntimeError):
     """libkeyes_hip.so (or a gfx950 device) is not available."""
 
 
+def _share_the_hip_runtime_with_torch() -> None:
+    """PyTorch's ROCm wheels bundle their own libamdhip64 / libhsa-runtime64 / librccl.  One process must run on ONE HIP
+    runtime: if this library bound /opt/rocm's copy and PyTorch (or its RCCL) were loaded afterwards, the second copy would
+    see no initialised device.  So when PyTorch is installed its runtime is mapped first (without importing torch); the
+    loader then resolves libkeyes_hip.so's dependency to it by soname.  KE_SYSTEM_ROCM=1 keeps the system copy."""
+    import importlib.util
+    import sys
+
+    if "torch" in sys.modules or os.environ.get("KE_SYSTEM_ROCM"):
+        return                      # torch already brought its runtime (same effect) / the caller wants /opt/rocm's
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.submodule_search_locations:
+        return
+    path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        try:
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load_library() -> C.CDLL:
     """Load libkeyes_hip.so and declare the prototypes.  Does not touch the GPU."""
     global _lib
     with _lib_lock:
         if _lib is not None:
             return _lib
+        _share_the_hip_runtime_with_torch()
         if not os.path.exists(LIB_PATH):
             raise NativeUnavailable(
                 f"{LIB_PATH} is missing: build it with kobato-eyes_amd/build.sh (hipcc, gfx950). "

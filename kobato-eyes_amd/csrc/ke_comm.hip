@@ -7,8 +7,8 @@
 // all-gather of fixed-width records [count | first K edges] -- K follows the largest list seen, a second gather only
 // when a list outgrows it -- followed by ONE device-to-host copy.  No all-reduce anywhere.
 //
-// RCCL is bound at first use (dlopen of librccl.so.1): a process that already carries an RCCL -- PyTorch does -- is
-// joined rather than given a second copy, and single-GPU users never load it.  A communicator made elsewhere
+// RCCL is bound at first use (dlopen of the librccl that sits beside the process' HIP runtime): a process that already
+// carries one -- PyTorch does -- is joined rather than given a second copy, and single-GPU users never load it.  A communicator made elsewhere
 // (ncclComm_t) can be passed in as void*; ke_comm_create makes one from a 128-byte unique id the host distributes.
 #include <dlfcn.h>
 
@@ -38,8 +38,24 @@ Rccl *rccl() {
     static bool tried = false;
     if (tried) return &r;
     tried = true;
-    for (const char *name : {"librccl.so.1", "librccl.so"}) {
-        r.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+    // The RCCL that belongs to the HIP runtime this process already runs on: a Python process may carry PyTorch's bundled
+    // ROCm next to /opt/rocm, and an RCCL bound to the other copy finds no initialised device.  So look beside the loaded
+    // libamdhip64 first, then wherever the loader finds one.
+    std::vector<std::string> names;
+    Dl_info info;
+    if (dladdr(reinterpret_cast<const void *>(&hipGetDeviceCount), &info) && info.dli_fname) {
+        std::string dir(info.dli_fname);
+        const size_t slash = dir.rfind('/');
+        if (slash != std::string::npos) {
+            dir.resize(slash + 1);
+            names.push_back(dir + "librccl.so.1");
+            names.push_back(dir + "librccl.so");
+        }
+    }
+    names.push_back("librccl.so.1");
+    names.push_back("librccl.so");
+    for (const std::string &name : names) {
+        r.handle = dlopen(name.c_str(), RTLD_NOW | RTLD_GLOBAL);
         if (r.handle) break;
     }
     if (!r.handle) {

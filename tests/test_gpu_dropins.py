@@ -185,7 +185,11 @@ def test_refine_pairs_batches_the_seam(K, tmp_path):
     assert sum(m is None for m in batched) == 2 and sum(m is not None and m.reason == "ssim unavailable" for m in batched) == 2
     assert any(m is not None and m.is_duplicate for m in batched) and any(m is not None and m.reason == "below thresholds" for m in batched)
     launches = stats["fit_launches"] + stats["ssim_launches"]
-    assert stats["decodes"] == 18 and launches * 3 <= len(pairs), stats          # per pair: 2 decodes, 2 fits, 1 SSIM = 66 launches
+    assert stats["decodes"] == 18 and launches <= 12, stats    # the per-pair loop: 44 decodes, 2 fits + 1 SSIM per readable pair = 60 launches
+    same_size = [p for p in pairs if p[0] < 10 and p[1] < 10]  # the shape of a scan over one camera's files: one size
+    stats = {}
+    assert K.refine_pairs(same_size, thresholds=th, stats=stats) == [m for m, p in zip(one_by_one, pairs) if p in same_size]
+    assert stats["fit_launches"] + stats["ssim_launches"] == 2 and 3 * len(same_size) >= 10 * 2, stats   # 36 launches -> 2
     # a decode budget of one file per run: many runs, same answers
     assert K.refine_pairs(pairs, thresholds=th, max_decoded_bytes=1) == one_by_one
 

@@ -96,6 +96,11 @@ def cpu_baseline(ctx, args, table_host):
 
 def main():
     args = parse_args()
+    # stdout carries ONE JSON line: whatever libraries print while the job runs (RCCL announces its version on stdout when a
+    # communicator is made) goes to stderr instead -- file descriptor 1 is pointed at 2 until the line is written
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
 
@@ -329,7 +334,10 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(ctx, args, state["table"].cpu().numpy().view(np.uint64))
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if exchange:
         exchange.close()
     if distributed:

@@ -14,7 +14,7 @@ from typing import Optional, Sequence
 import numpy as np
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG_DIR, "libkeyes_hip.so")
+LIB_PATH = os.environ.get("KE_LIBKEYES") or os.path.join(_PKG_DIR, "libkeyes_hip.so")   # KE_LIBKEYES: a build variant (benchmarks)
 
 KE_OK = 0
 EDGE_DTYPE = np.dtype([("a", "<i8"), ("b", "<i8"), ("h", "<i4"), ("bands", "<i4")])

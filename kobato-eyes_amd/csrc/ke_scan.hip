@@ -162,7 +162,11 @@ __global__ __launch_bounds__(kThreads) void ke_scan_tiles(const ScanArgs a) {
             pre1 = cbase[cn * (kChunk / 16 * 64) + kThreads + tid];
         }
         const ke_v4i *bt = s_b[c & 1];
-        for (int ct = 0; ct < kChunk / 16; ++ct) {
+        // diagonal tiles: a 128 x 16 block whose every column index is below the wave's first row holds no pair i < j --
+        // the wave starts at the first block that can (wave-uniform)
+        const int64_t below = wrow0 - (col0 + (int64_t)c * kChunk) - 15;
+        const int ct0 = below < 0 ? 0 : (int)min((int64_t)(kChunk / 16), below / 16 + 1);
+        for (int ct = ct0; ct < kChunk / 16; ++ct) {
             const ke_v4i bv = bt[ct * 64 + lane];
             const ke_v8i b = {bv[0], bv[1], bv[2], bv[3], 0, 0, 0, 0};
             ke_v4f acc[kRT];

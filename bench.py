@@ -46,6 +46,7 @@ def parse_args():
     ap.add_argument("--ssim-threshold", type=float, default=None,
                     help="BASELINE configs[3] flavour: re-check every candidate edge with the SSIM kernel inside the step (pairs sharded over the ranks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-h2d", action="store_true", help="skip the PCIe-inclusive leg (pinned staging -> device -> hash)")
     ap.add_argument("--torch-collectives", action="store_true",
                     help="exchange through torch.distributed (kobato_eyes_amd.distributed) instead of the library's own RCCL entry points")
     ap.add_argument("--phase-timing", action="store_true", help="after the timed run, time each phase of a step with syncs in between (stderr)")
@@ -77,15 +78,41 @@ def cpu_baseline(ctx, args, table_host):
     # the same oracle on 8 threads (ctypes releases the GIL), reported beside the 1-core figure
     from concurrent.futures import ThreadPoolExecutor
 
-    threads = min(8, os.cpu_count() or 1)
-    px = ctx.synth_rgb(SEED, 0, 2000, args.side, args.side)
-    parts = np.array_split(np.arange(2000), threads)
-    t0 = time.perf_counter()
-    with ThreadPoolExecutor(threads) as ex:
-        list(ex.map(lambda idx: O.hash_batch(px[idx[0]:idx[-1] + 1], want_dhash=args.dhash), parts))
-    t_mt = time.perf_counter() - t0
+    def threaded(threads, n_sample):
+        px = ctx.synth_rgb(SEED, 0, n_sample, args.side, args.side)
+        parts = [p for p in np.array_split(np.arange(n_sample), threads) if len(p)]
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(threads) as ex:
+            list(ex.map(lambda idx: O.hash_batch(px[idx[0]:idx[-1] + 1], want_dhash=args.dhash), parts))
+        return n_sample / (time.perf_counter() - t0)
+
+    cores = os.cpu_count() or 1
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = cores
+    try:                                               # a container's CPU share (cgroup v2 cpu.max: "<quota> <period>")
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            usable = max(1, min(usable, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.lower().startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    t8 = min(8, usable)
     return {
-        "threads_8": {"threads": threads, "hash_images_per_s": 2000 / t_mt, "sample": "2000 images, one slice per thread"},
+        "cpu_model": model, "host_cores": cores, "usable_cores": usable,
+        "threads_8": {"threads": t8, "hash_images_per_s": threaded(t8, 2000), "sample": "2000 images, one slice per thread"},
+        # every core this process may run on (the reference's pool default is cpu_count - 1, src/core/fastsig.py:75)
+        "all_cores": {"threads": usable, "hash_images_per_s": threaded(usable, max(2000, 120 * usable)),
+                      "sample": f"{max(2000, 120 * usable)} images, one slice per thread"},
         "value": args.images / total, "unit": "images/s", "cores": 1, "kind": "port",
         "sample": f"{m} of the {args.images} corpus images hashed by oracle/keyes_oracle.c on 1 core ({t_hash:.2f} s, "
                   f"{m / t_hash:.0f} img/s) + reference-shaped banded scan over all {args.images} hashes ({t_scan:.2f} s, "
@@ -269,6 +296,35 @@ def main():
         if rank == 0:
             print("phase ms/step:", {k: round(v / args.steps, 3) for k, v in acc.items()}, file=sys.stderr, flush=True)
 
+    h2d = None
+    if rank == 0 and world == 1 and not args.no_h2d:
+        # PCIe-inclusive rate of the hashing step (never `value`): the images start in the library's page-locked staging
+        # buffers (where decoders put them, ke_stage_*), each batch is copied on the copy stream while the previous one is
+        # hashed.  Two buffers of 512 images (403 MB each), 40 batches.
+        per = 512
+        ctx.stage_create(per * img_bytes, per, 2)
+        try:
+            filled = {}
+            offs, dims, ch3 = np.arange(per, dtype=np.uint64) * np.uint64(img_bytes), [side] * per, [3] * per
+            def submit():
+                slot, view = ctx.stage_acquire()
+                if slot not in filled:                         # same pixels every round: the copy is what is being timed
+                    view[: per * img_bytes] = ctx.synth_rgb(SEED, slot * per, per, side, side).reshape(-1)
+                    filled[slot] = True
+                return ctx.stage_submit_hash(slot, offs, dims, dims, ch3, want_dhash=False)
+            keep = [submit() for _ in range(4)]
+            ctx.stage_wait(-1)
+            t0 = time.perf_counter()
+            keep = [submit() for _ in range(40)]
+            ctx.stage_wait(-1)
+            dt = time.perf_counter() - t0
+            assert np.array_equal(keep[-2]["phash"], local_hash[:per].cpu().numpy().view(np.uint64)), "staged hashes differ from the resident path"
+            h2d = {"images_per_s": 40 * per / dt, "gb_per_s": 40 * per * img_bytes / dt / 1e9,
+                   "what": "pinned staging buffers -> H2D on the copy stream overlapped with the hash kernel of the previous batch "
+                           f"(ke_stage_*; 40 batches of {per} images, 2 buffers); decode not included"}
+        finally:
+            ctx.stage_destroy()
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = n_total * args.steps / elapsed
@@ -321,6 +377,7 @@ def main():
             # how exposed the corpus is to the one unpinnable step: images whose closest bit decision `coef > mean` sits
             # within 1e-3 / 1e-4 of a tie (another DCT implementation, e.g. OpenCV's float32 one, may flip such a bit)
             "phash_near_ties": near_ties,
+            **({"h2d_inclusive": h2d} if h2d else {}),
             "roofline": {"bound": "hbm", "kernel": "ke_phash_fused_mx", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": "profiles/hash_kernel_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE pass of this kernel at this "

@@ -226,7 +226,10 @@ __global__ void ke_hist_pairs(const uint32_t *__restrict__ hist, size_t bins, un
         if (len >= 2 && (!cap || p <= cap)) s += p;
     }
     for (int d = 32; d > 0; d >>= 1) s += __shfl_down(s, d);
-    if ((threadIdx.x & 63) == 0 && s) atomicAdd(out, s);
+    __shared__ unsigned long long part[4];                    // one atomic per workgroup: thousands to one address serialise
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0 && (part[0] | part[1] | part[2] | part[3])) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
 }
 
 // Wide bands (2^band_bits bins do not fit a table): the band values are sorted together with their positions and the
@@ -284,7 +287,7 @@ int ke_launch_scan(ke_ctx *ctx, const uint64_t *d_hashes, const int64_t *d_ids, 
         KE_HIP(ctx, hipGetLastError());
         a.hist = (const uint32_t *)h;
         if (want_bucket_pairs) {
-            const unsigned blocks = (unsigned)std::min<size_t>((bins + 255) / 256, 2048);
+            const unsigned blocks = (unsigned)std::min<size_t>((bins + 1023) / 1024, 256);
             hipLaunchKernelGGL(ke_hist_pairs, dim3(blocks), dim3(256), 0, ctx->stream, (const uint32_t *)h, bins, a.cap, d_counters + 3);
             KE_HIP(ctx, hipGetLastError());
         }

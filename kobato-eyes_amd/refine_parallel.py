@@ -116,11 +116,20 @@ def refine_by_tilehash_parallel(clusters: Sequence, grid: int = 4, tile: int = 8
     failure_counts: Counter = Counter()
     failure_samples: dict = {}
     done = 0
-    batch = 256
-    for start in range(0, total1, batch):
+    # files are decoded a few at a time and the run is cut as soon as the decoded pixels pass 512 MB (the reference holds at
+    # most io_workers decoded images at once and shrinks each to 32x32 immediately; 256 twelve-megapixel files at once
+    # would be 9 GB of host memory)
+    budget, step = 512 << 20, max(8, 2 * io_workers)
+    start = 0
+    while start < total1:
         if is_cancelled and is_cancelled():
             return []
-        decoded = _decode_all(uniq_paths[start:start + batch], io_workers)
+        decoded, held = [], 0
+        while start < total1 and held < budget and len(decoded) < 256:
+            part = _decode_all(uniq_paths[start:start + step], io_workers)
+            start += len(part)
+            decoded.extend(part)
+            held += sum(a.nbytes for _, a in part if not isinstance(a, Exception))
         good = [(p, a) for p, a in decoded if not isinstance(a, Exception)]
         if good:
             try:
@@ -202,15 +211,21 @@ def refine_by_pixels_parallel(clusters: Sequence, mae_thr: float = 0.006, thumb_
                         key = f"{type(a).__name__}: {a}"
                         entry_failures[key] += 1
                         entry_samples.setdefault(key, p)
-                thumbs = np.stack(_thumbnails([decoded[k][1] for k in good], thumb_size, device))
-                slot = {k: j for j, k in enumerate(good)}
-                members = [k for k in good if k >= 1]
-                sad = ctx.sad_pairs(thumbs.reshape(len(good), -1), len(good), pixels, [slot[k] for k in members],
-                                    [0] * len(members))
-                oks = [cl.files[k - 1] for k, s in zip(members, sad.tolist())
-                       if float(float(int(s)) / pixels / 255.0) <= mae_thr]
-                if len(oks) >= 2:
-                    out.append(_rebuild_cluster_like(cl, oks))
+                try:
+                    thumbs = np.stack(_thumbnails([decoded[k][1] for k in good], thumb_size, device))
+                    slot = {k: j for j, k in enumerate(good)}
+                    members = [k for k in good if k >= 1]
+                    sad = ctx.sad_pairs(thumbs.reshape(len(good), -1), len(good), pixels, [slot[k] for k in members],
+                                        [0] * len(members))
+                except (RuntimeError, ValueError) as exc:          # a device error costs this cluster, not the run
+                    key = f"{type(exc).__name__}: {exc}"
+                    keeper_failures[key] += 1
+                    keeper_samples.setdefault(key, keep.file.path)
+                else:
+                    oks = [cl.files[k - 1] for k, s in zip(members, sad.tolist())
+                           if float(float(int(s)) / pixels / 255.0) <= mae_thr]
+                    if len(oks) >= 2:
+                        out.append(_rebuild_cluster_like(cl, oks))
         if tick and (done % 16 == 0 or done == total):
             tick(done, total)
     if keeper_failures:

@@ -17,7 +17,7 @@ import os
 import shutil
 import sys
 
-HOT = {"ke_phash_fused": "hash", "ke_scan_tiles": "scan", "ke_ssim_tiles": "ssim"}
+HOT = {"ke_phash_fused": "hash", "ke_scan_tiles": "scan", "ke_ssim_fast": "ssim", "ke_ssim_waves": "ssim_exact"}
 
 
 def main():

@@ -164,3 +164,31 @@ def write_image_io_files(td):
 def image_io_golden():
     with open(os.path.join(GOLDEN, "image_io_golden.json")) as fh:
         return json.load(fh)
+
+
+def degenerate_tiles():
+    """(name, pixels, phash, dhash, margin): flat and two-level images, where every AC term of the DCT is exactly zero or
+    one of a few large values.  The values are THIS build's policy (folded fp64 DCT: exact zeros for flat and mirror-symmetric
+    inputs, strict `>` against the float32 mean), fixed here so it cannot drift: real OpenCV is not available to pin them,
+    and for such images its float32 DCT leaves rounding noise where these are exact zeros ("Mixing
+    signatures")."""
+    def flat(v, h, w):
+        return np.full((h, w, 3), v, np.uint8)
+
+    def two(level_a, level_b, mask):
+        out = np.full(mask.shape + (3,), level_a, np.uint8)
+        out[mask] = level_b
+        return out
+
+    yy, xx = np.indices((64, 64))
+    table = [
+        ("flat0", flat(0, 64, 64), 0x0000000000000000, 0x0000000000000000, 0.0),
+        ("flat37", flat(37, 48, 80), 0x8000000000000000, 0x0000000000000000, 0.0),
+        ("flat255", flat(255, 512, 512), 0x8000000000000000, 0x0000000000000000, 0.0),
+        ("split_lr", two(0, 255, xx >= 32), 0xBBFFFFFFFFFFFFFF, 0x5A5A5A5A5A5A5A5A, 42.24908447265625),
+        ("split_tb", two(0, 255, yy >= 32), 0xFF7FFFFFFF7FFFFF, 0x0000000000000000, 42.249080657958984),
+        ("quad", two(0, 255, (yy < 32) == (xx < 32)), 0x8044001100440011, 0x242400245A185A5A, 27.564197540283203),
+        ("split_lr_1level", two(200, 201, xx >= 32), 0xBBFFFFFFFFFFFFFF, 0x0808080808080808, 0.16512662172317505),
+        ("checker32", two(0, 255, ((yy // 32 + xx // 32) % 2) == 1), 0xFFBBFFEEFFBBFFEE, 0x5A5A185A24002424, 27.564197540283203),
+    ]
+    return table

@@ -581,6 +581,16 @@ def test_device_resident_ragged_batch_with_misaligned_offsets(ctx):
         ctx.free(dev)
 
 
+def test_degenerate_tiles_keep_their_pinned_hashes(ctx):
+    """Flat and two-level images (all-tie and few-level DCT corners): the GPU gives this build's pinned values."""
+    for name, px, ph, dh, margin in G.degenerate_tiles():
+        h, w = px.shape[:2]
+        mg = np.empty(1, np.float32)
+        got_p, got_d = ctx.hash_uniform(px, 1, w, h, 3, margin_out=mg)
+        assert (int(got_p[0]), int(got_d[0])) == (ph, dh), name
+        assert mg[0] == np.float32(margin), name
+
+
 def test_tie_margins_match_oracle(ctx):
     """margin_out of ke_hash_uniform_ex / ke_hash_images_ex == the oracle's min |coef - mean| bit for bit: golden
     signature cases (flats and symmetric images are exact ties: margin 0), single-pass and banded kernels, uniform and

@@ -185,3 +185,11 @@ def test_bilinear_resample_matches_installed_pillow():
         for (ow, oh) in [(32, 32), (128, 128), (16, 24)]:
             ref = np.asarray(Image.fromarray(arr).resize((ow, oh), Image.Resampling.BILINEAR))
             assert np.array_equal(O.resample_filter(arr, ow, oh, 1), ref), (w, h, ow, oh)
+
+
+def test_degenerate_tiles_are_pinned():
+    """Flat and two-level images: this build's tie policy, fixed (see tests/_golden.py:degenerate_tiles)."""
+    for name, px, ph, dh, margin in G.degenerate_tiles():
+        got_p, got_d, _, _, got_m = O.hash_image(px, want_tiles=True)
+        assert (got_p, got_d) == (ph, dh), name
+        assert np.float32(got_m) == np.float32(margin), name

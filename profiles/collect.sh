@@ -11,7 +11,7 @@ out="$root/gpurun_out"
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
 B="$root/bench.py"
-run() { echo "== $*"; "$@"; echo "rc=$?"; }
+run() { echo "== $*" >&2; "$@"; echo "rc=$?" >&2; }
 
 # 1. the bench lines themselves
 run python3 "$B" --steps 10 --warmup 3 > "$out/${tag}_bench.json" 2> "$out/${tag}_bench.err"

@@ -23,11 +23,15 @@ HOT = {"ke_phash_fused": "hash", "ke_scan_tiles": "scan", "ke_ssim_fast": "ssim"
 def main():
     tag, stats_dir, pmc_dirs = sys.argv[1], sys.argv[2], sys.argv[3:]
     here = os.path.dirname(os.path.abspath(__file__))
-    for f in glob.glob(os.path.join(stats_dir, "**", "*_kernel_stats.csv"), recursive=True):
+    def newest(pattern):
+        found = sorted(glob.glob(pattern, recursive=True), key=os.path.getmtime)
+        return found[-1:]                      # gpurun merges runs into one directory: the latest file is this run's
+
+    for f in newest(os.path.join(stats_dir, "**", "*_kernel_stats.csv")):
         shutil.copy(f, os.path.join(here, f"{tag}_kernel_stats.csv"))
     out = {}
     for d in pmc_dirs:
-        for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
+        for f in newest(os.path.join(d, "**", "*_counter_collection.csv")):
             acc = {}
             for r in csv.DictReader(open(f)):
                 for key, short in HOT.items():

@@ -152,7 +152,8 @@ int ke_luma_tiles_uniform(ke_ctx *ctx, const uint8_t *pixels, int64_t n, int32_t
  * `part_index` (one shard per GPU; 0/1 = everything).
  * edges_out: capacity entries (host or device); *n_edges_out = edges found, which may exceed
  * capacity -- the caller then retries with a larger buffer.  Edge order is unspecified.
- * counters_out (nullable, 4 x u64, host): [0] pairs evaluated by this shard,
+ * counters_out (nullable, 4 x u64, host): [0] pairs i < j evaluated by this shard (counted by the kernel, one atomic per
+ * tile, and checked against the host's closed form: the call fails if they differ),
  * [1] sum over emitted edges of the number of shared bands (the reference's "ham=" funnel
  * counter, src/dup/scanner.py:292-299), [2] edges emitted, [3] bucket pairs of the WHOLE table (the same on every
  * shard): sum over bands and band values of C(bucket size, 2) for the buckets the reference walks (size >= 2, under
@@ -210,6 +211,19 @@ int ke_ssim_set_mode(ke_ctx *ctx, int32_t mode);
 int ke_ssim_pairs_uniform(ke_ctx *ctx, const uint8_t *images, int64_t n_images, int32_t width,
                           int32_t height, int32_t channels, const int64_t *pair_a, const int64_t *pair_b,
                           int64_t n_pairs, double *ssim_out);
+
+/* The whole of dup.refine._compute_ssim (src/dup/refine.py:44-52) for pairs of images of ANY sizes: per pair the common
+ * size (min width, min height) (src/dup/refine.py:45-47), ImageOps.fit(convert("L"), size, BICUBIC) of both
+ * (ke_fit_luma_uniform's arithmetic), then the SSIM above.  Image i: heights[i] rows of widths[i]*channels bytes at
+ * pixels + offsets[i] (offsets NULL: packed back to back); pixels host or device, everything else host arrays.
+ * Work is grouped: one fit launch per (source size, common size), one SSIM launch per common size.
+ * ssim_out[k]: the score, NaN where status_out[k] != KE_PAIR_OK.  status_out (nullable): KE_PAIR_OK, KE_PAIR_TOO_SMALL (the
+ * common size is under 7 pixels: skimage raises "win_size exceeds image extent"), KE_PAIR_BAD_IMAGE (an index outside
+ * [0, n_images) or an image with a non-positive size). */
+enum { KE_PAIR_OK = 0, KE_PAIR_TOO_SMALL = 1, KE_PAIR_BAD_IMAGE = 2 };
+int ke_ssim_pairs(ke_ctx *ctx, const uint8_t *pixels, const uint64_t *offsets, const int32_t *widths, const int32_t *heights,
+                  int32_t channels, int64_t n_images, const int64_t *pair_a, const int64_t *pair_b, int64_t n_pairs,
+                  double *ssim_out, int32_t *status_out);
 
 /* ---- shipped refine stage ("next" row of SURVEY 8f): replaces the per-file work of
  * ui.dup_refine_parallel -- tile_ahash_bits (src/ui/dup_refine_parallel.py:59-83), _load_small_gray

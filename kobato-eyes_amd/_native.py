@@ -28,7 +28,7 @@ EXPORTS = (
     "ke_hash_images", "ke_hash_uniform", "ke_hash_images_ex", "ke_hash_uniform_ex", "ke_luma_tiles_uniform", "ke_hamming_scan",
     "ke_stage_create", "ke_stage_destroy", "ke_stage_acquire", "ke_stage_submit_hash", "ke_stage_wait",
     "ke_comm_unique_id", "ke_comm_create", "ke_comm_destroy", "ke_allgather_u64", "ke_allgather_hashes", "ke_allgather_edges",
-    "ke_interleave_shards", "ke_cluster_labels", "ke_ssim_pairs_uniform", "ke_ssim_set_mode", "ke_resize_luma_uniform", "ke_fit_luma_uniform", "ke_tile_ahash", "ke_sad_pairs", "ke_synth_rgb",
+    "ke_interleave_shards", "ke_cluster_labels", "ke_ssim_pairs_uniform", "ke_ssim_pairs", "ke_ssim_set_mode", "ke_resize_luma_uniform", "ke_fit_luma_uniform", "ke_tile_ahash", "ke_sad_pairs", "ke_synth_rgb",
     "ke_synth_rgb_indexed",
     "ke_synth_hashes", "ke_last_kernel_ms",
 )
@@ -120,6 +120,7 @@ def load_library() -> C.CDLL:
         lib.ke_cluster_labels.argtypes = [vp, i64, i64, vp]
         lib.ke_ssim_pairs_uniform.argtypes = [vp, vp, i64, i32, i32, i32, vp, vp, i64, vp]
         lib.ke_ssim_set_mode.argtypes = [vp, i32]
+        lib.ke_ssim_pairs.argtypes = [vp, vp, vp, vp, vp, i32, i64, vp, vp, i64, vp, vp]
         lib.ke_resize_luma_uniform.argtypes = [vp, vp, i64, i32, i32, i32, i32, i32, i32, vp]
         lib.ke_fit_luma_uniform.argtypes = [vp, vp, i64, i32, i32, i32, i32, i32, i32, vp]
         lib.ke_tile_ahash.argtypes = [vp, vp, i64, i32, i32, vp]
@@ -133,7 +134,7 @@ def load_library() -> C.CDLL:
                      "ke_hash_images", "ke_hash_uniform", "ke_hash_images_ex", "ke_hash_uniform_ex", "ke_luma_tiles_uniform", "ke_hamming_scan",
                      "ke_stage_create", "ke_stage_destroy", "ke_stage_acquire", "ke_stage_submit_hash", "ke_stage_wait",
                      "ke_comm_unique_id", "ke_comm_create", "ke_comm_destroy", "ke_allgather_u64", "ke_allgather_hashes", "ke_allgather_edges",
-                     "ke_interleave_shards", "ke_cluster_labels", "ke_ssim_pairs_uniform", "ke_ssim_set_mode", "ke_resize_luma_uniform", "ke_fit_luma_uniform", "ke_tile_ahash",
+                     "ke_interleave_shards", "ke_cluster_labels", "ke_ssim_pairs_uniform", "ke_ssim_pairs", "ke_ssim_set_mode", "ke_resize_luma_uniform", "ke_fit_luma_uniform", "ke_tile_ahash",
                      "ke_sad_pairs", "ke_synth_rgb", "ke_synth_rgb_indexed", "ke_synth_hashes"):
             getattr(lib, name).restype = C.c_int
         _lib = lib
@@ -385,6 +386,32 @@ class Context:
             self._check(self._lib.ke_ssim_pairs_uniform(self._h, _addr(images), n_images, width, height, channels, _addr(pa),
                                                         _addr(pb), len(pa), _addr(out)), "ke_ssim_pairs_uniform")
         return out
+
+    def ssim_pairs(self, images: Sequence[np.ndarray], pair_a, pair_b):
+        """src/dup/refine.py:44-52 for pairs of images of any sizes (one channel count): common size, ImageOps.fit + BICUBIC
+        of both, SSIM.  Returns (float64 scores, NaN where the status is not 0; int32 statuses KE_PAIR_*)."""
+        n = len(images)
+        chans = {1 if im.ndim == 2 else im.shape[2] for im in images}
+        if len(chans) != 1:
+            raise ValueError("all images of one call must share the channel count")
+        ch = chans.pop()
+        widths = np.array([im.shape[1] for im in images], np.int32)
+        heights = np.array([im.shape[0] for im in images], np.int32)
+        sizes = widths.astype(np.int64) * heights * ch
+        padded = (sizes + 15) & ~np.int64(15)
+        offsets = np.zeros(n, np.uint64)
+        offsets[1:] = np.cumsum(padded[:-1]).astype(np.uint64)
+        flat = np.zeros(int(padded.sum()), np.uint8)
+        for im, off, sz in zip(images, offsets, sizes):
+            flat[int(off):int(off) + int(sz)] = np.ascontiguousarray(im, dtype=np.uint8).reshape(-1)
+        pa = np.ascontiguousarray(pair_a, dtype=np.int64)
+        pb = np.ascontiguousarray(pair_b, dtype=np.int64)
+        out = np.empty(len(pa), np.float64)
+        status = np.empty(len(pa), np.int32)
+        with self._lock:
+            self._check(self._lib.ke_ssim_pairs(self._h, _addr(flat), _addr(offsets), _addr(widths), _addr(heights), ch, n, _addr(pa),
+                                                _addr(pb), len(pa), _addr(out), _addr(status)), "ke_ssim_pairs")
+        return out, status
 
     # -- shipped refine stage -------------------------------------------------------------------
     def resize_luma_uniform(self, pixels, n: int, width: int, height: int, channels: int, out_w: int, out_h: int,

@@ -738,11 +738,10 @@ KE_API int ke_hamming_scan(ke_ctx *ctx, const uint64_t *hashes, const int64_t *i
     KE_HIP(ctx, hipMemcpyAsync(h_cnt, d_cnt, sizeof h_cnt, hipMemcpyDeviceToHost, ctx->stream));
     KE_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *n_edges_out = (int64_t)h_cnt[2];
+    if (h_cnt[0] != pairs)    // the kernel's own count of the pairs its tiles stand for against the host's closed form
+        return ke_fail(ctx, KE_EHIP, "scan evaluated %llu pairs, expected %llu", h_cnt[0], pairs);
     if (counters_out)
-    {
         for (int k = 0; k < 4; ++k) counters_out[k] = h_cnt[k];
-        counters_out[0] = pairs;
-    }
     if (capacity > 0 && !edges_dev) {
         const int64_t m = std::min<int64_t>(capacity, (int64_t)h_cnt[2]);
         if (m > 0) {
@@ -802,6 +801,115 @@ KE_API int ke_ssim_pairs_uniform(ke_ctx *ctx, const uint8_t *images, int64_t n_i
     return KE_OK;
 }
 
+static int fit_box(int width, int height, int out_w, int out_h, float box[4]) {
+    // PIL/ImageOps.py fit(): the same double-precision steps in the same order
+    const double live_ratio = (double)width / (double)height, out_ratio = (double)out_w / (double)out_h;
+    double cw, chh;
+    if (live_ratio == out_ratio) { cw = width; chh = height; }
+    else if (live_ratio >= out_ratio) { cw = out_ratio * height; chh = height; }
+    else { cw = width; chh = width / out_ratio; }
+    const double left = (width - cw) * 0.5, top = (height - chh) * 0.5;
+    box[0] = (float)left; box[1] = (float)top; box[2] = (float)(left + cw); box[3] = (float)(top + chh);
+    return (box[0] < 0 || box[1] < 0 || box[2] > width || box[3] > height) ? KE_EINVAL : KE_OK;
+}
+
+KE_API int ke_ssim_pairs(ke_ctx *ctx, const uint8_t *pixels, const uint64_t *offsets, const int32_t *widths, const int32_t *heights,
+                         int32_t channels, int64_t n_images, const int64_t *pair_a, const int64_t *pair_b, int64_t n_pairs,
+                         double *ssim_out, int32_t *status_out) {
+    if (!ctx) return KE_EINVAL;
+    if (n_pairs < 0 || n_images < 0) return ke_fail(ctx, KE_EINVAL, "negative count");
+    if (n_pairs == 0) return KE_OK;
+    if (!pixels || !widths || !heights || !pair_a || !pair_b || !ssim_out) return ke_fail(ctx, KE_EINVAL, "NULL argument");
+    if (channels != 1 && channels != 3 && channels != 4) return ke_fail(ctx, KE_EINVAL, "channels must be 1, 3 or 4");
+    for (const void *p : {(const void *)offsets, (const void *)widths, (const void *)heights, (const void *)pair_a, (const void *)pair_b,
+                          (const void *)ssim_out, (const void *)status_out})
+        if (p && ke_is_device_ptr(p)) return ke_fail(ctx, KE_EINVAL, "offsets/widths/heights/pairs/outputs are host arrays");
+    KE_HIP(ctx, hipSetDevice(ctx->device));
+    trim_coeff_cache(ctx);
+    const double nan = std::nan("");
+    // byte offsets; classify the pairs
+    std::vector<uint64_t> off((size_t)n_images);
+    uint64_t run = 0;
+    for (int64_t i = 0; i < n_images; ++i) {
+        off[i] = offsets ? offsets[i] : run;
+        if (widths[i] > 0 && heights[i] > 0) run += (uint64_t)widths[i] * heights[i] * channels;
+    }
+    uint64_t total_bytes = 0;
+    for (int64_t i = 0; i < n_images; ++i)
+        if (widths[i] > 0 && heights[i] > 0) total_bytes = std::max<uint64_t>(total_bytes, off[i] + (uint64_t)widths[i] * heights[i] * channels);
+    std::map<std::pair<int, int>, std::vector<int64_t>> by_size;        // common (w, h) -> pairs
+    for (int64_t k = 0; k < n_pairs; ++k) {
+        ssim_out[k] = nan;
+        const int64_t ia = pair_a[k], ib = pair_b[k];
+        const bool ok = ia >= 0 && ia < n_images && ib >= 0 && ib < n_images && widths[ia] > 0 && heights[ia] > 0 && widths[ib] > 0 &&
+                        heights[ib] > 0;
+        if (!ok) { if (status_out) status_out[k] = KE_PAIR_BAD_IMAGE; continue; }
+        const int w = std::min(widths[ia], widths[ib]), h = std::min(heights[ia], heights[ib]);   // src/dup/refine.py:45-47
+        if (w < 7 || h < 7) { if (status_out) status_out[k] = KE_PAIR_TOO_SMALL; continue; }
+        if (status_out) status_out[k] = KE_PAIR_OK;
+        by_size[{w, h}].push_back(k);
+    }
+    if (by_size.empty()) return KE_OK;
+    const void *d_px;
+    KE_TRY(ke_to_device(ctx, pixels, (size_t)total_bytes, KE_BUF_PIXELS, &d_px));
+    ke_time_begin(ctx, KE_T_SSIM);
+    for (auto &kv : by_size) {
+        const int w = kv.first.first, h = kv.first.second;
+        const std::vector<int64_t> &ks = kv.second;
+        // plane stack of this common size: the images of one source size sit next to each other, so a fit launch writes
+        // its whole group straight into place
+        std::map<std::pair<int, int>, std::vector<int64_t>> groups;     // source (w, h) -> images, first use order
+        std::map<int64_t, int64_t> slot;                                 // image -> position inside its group
+        for (int64_t k : ks)
+            for (int64_t i : {pair_a[k], pair_b[k]})
+                if (!slot.count(i)) {
+                    auto &g = groups[{widths[i], heights[i]}];
+                    slot[i] = (int64_t)g.size();
+                    g.push_back(i);
+                }
+        int64_t base = 0;
+        std::map<std::pair<int, int>, int64_t> group_base;
+        for (auto &g : groups) { group_base[g.first] = base; base += (int64_t)g.second.size(); }
+        const size_t plane = (size_t)w * h;
+        void *planes, *meta, *aux;
+        KE_TRY(ke_reserve(ctx, KE_BUF_SSIM_IN, (size_t)base * plane, &planes));
+        KE_TRY(ke_reserve(ctx, KE_BUF_META, (size_t)base * 8, &meta));
+        std::vector<uint64_t> meta_h((size_t)base);
+        for (auto &g : groups)
+            for (size_t j = 0; j < g.second.size(); ++j) meta_h[(size_t)group_base[g.first] + j] = off[g.second[j]];
+        KE_HIP(ctx, hipMemcpyAsync(meta, meta_h.data(), (size_t)base * 8, hipMemcpyHostToDevice, ctx->stream));
+        KE_HIP(ctx, hipStreamSynchronize(ctx->stream));                  // meta_h is a local
+        for (auto &g : groups) {
+            const int sw = g.first.first, sh = g.first.second;
+            const int64_t gb = group_base[g.first], m = (int64_t)g.second.size();
+            KeHashGroup hg{(const uint8_t *)d_px, (const uint64_t *)meta + gb, (uint64_t)sw * sh * channels, nullptr, m, sw, sh, channels};
+            for (int64_t i : g.second)
+                if (((uintptr_t)d_px + off[i]) % 4 != 0) { hg.misaligned = true; break; }
+            float box[4];
+            if (fit_box(sw, sh, w, h, box) != KE_OK) return ke_fail(ctx, KE_EINVAL, "crop box outside the image");
+            KE_TRY(ke_launch_resize_group(ctx, hg, w, h, KE_FILTER_BICUBIC, (uint8_t *)planes + (size_t)gb * plane, box));
+        }
+        // pair indices into the plane stack, then one SSIM launch
+        const int64_t np = (int64_t)ks.size();
+        KE_TRY(ke_reserve(ctx, KE_BUF_SSIM_AUX, (size_t)np * 24, &aux));
+        std::vector<int64_t> idx((size_t)2 * np);
+        for (int64_t j = 0; j < np; ++j) {
+            const int64_t ia = pair_a[ks[j]], ib = pair_b[ks[j]];
+            idx[j] = group_base[{widths[ia], heights[ia]}] + slot[ia];
+            idx[np + j] = group_base[{widths[ib], heights[ib]}] + slot[ib];
+        }
+        KE_HIP(ctx, hipMemcpyAsync(aux, idx.data(), (size_t)2 * np * 8, hipMemcpyHostToDevice, ctx->stream));
+        double *d_out = (double *)((uint8_t *)aux + (size_t)2 * np * 8);
+        KE_TRY(ke_launch_ssim(ctx, (const uint8_t *)planes, w, h, 1, (const int64_t *)aux, (const int64_t *)aux + np, np, d_out));
+        std::vector<double> scores((size_t)np);
+        KE_HIP(ctx, hipMemcpyAsync(scores.data(), d_out, (size_t)np * 8, hipMemcpyDeviceToHost, ctx->stream));
+        KE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (int64_t j = 0; j < np; ++j) ssim_out[ks[j]] = scores[j];
+    }
+    ke_time_end(ctx, KE_T_SSIM);
+    return KE_OK;
+}
+
 // ---- shipped refine stage: thumbnails, tile aHash, pixel MAE --------------------------------------
 static int resize_luma_common(ke_ctx *ctx, const uint8_t *pixels, int64_t n, int32_t width, int32_t height, int32_t channels,
                               int32_t out_w, int32_t out_h, int32_t filter, const float *box, uint8_t *tiles_out);
@@ -815,15 +923,8 @@ KE_API int ke_fit_luma_uniform(ke_ctx *ctx, const uint8_t *pixels, int64_t n, in
                                int32_t channels, int32_t out_w, int32_t out_h, int32_t filter, uint8_t *tiles_out) {
     if (!ctx) return KE_EINVAL;
     if (width <= 0 || height <= 0 || out_w <= 0 || out_h <= 0) return ke_fail(ctx, KE_EINVAL, "sizes must be positive");
-    // PIL/ImageOps.py fit(): the same double-precision steps in the same order
-    const double live_ratio = (double)width / (double)height, out_ratio = (double)out_w / (double)out_h;
-    double cw, chh;
-    if (live_ratio == out_ratio) { cw = width; chh = height; }
-    else if (live_ratio >= out_ratio) { cw = out_ratio * height; chh = height; }
-    else { cw = width; chh = width / out_ratio; }
-    const double left = (width - cw) * 0.5, top = (height - chh) * 0.5;
-    const float box[4] = {(float)left, (float)top, (float)(left + cw), (float)(top + chh)};
-    if (box[0] < 0 || box[1] < 0 || box[2] > width || box[3] > height)   // Pillow raises ValueError here
+    float box[4];
+    if (fit_box(width, height, out_w, out_h, box) != KE_OK)                  // Pillow raises ValueError here
         return ke_fail(ctx, KE_EINVAL, "crop box outside the image");
     return resize_luma_common(ctx, pixels, n, width, height, channels, out_w, out_h, filter, box, tiles_out);
 }

@@ -134,6 +134,13 @@ __global__ __launch_bounds__(kThreads) void ke_scan_tiles(const ScanArgs a) {
     const int64_t cc = kCPR * rb + (t - (rb * a.ncc - kCPR * rb * (rb - 1) / 2));
     const int64_t row0 = rb * kTile, col0 = cc * kCols;
     const int64_t wrow0 = row0 + (int64_t)wv * (kRT * 16);          // this wave's 128 rows
+    if (tid == 0) {
+        // pairs i < j < n this tile stands for, counted where they are evaluated: the shards' counts must add up to
+        // n (n - 1) / 2 (counters[0]; the host checks it against its own arithmetic)
+        const int64_t rows = min((int64_t)kTile, a.n - row0), cols = min((int64_t)kCols, a.n - col0);
+        const unsigned long long pairs = cc == kCPR * rb ? (unsigned long long)(rows * (rows - 1) / 2) : (unsigned long long)(rows * cols);
+        atomicAdd(&a.counters[0], pairs);
+    }
 
     // row operands: registers for the whole tile (only dwords 0..3 of an fp4 operand are read)
     ke_v8i ra[kRT];

@@ -107,52 +107,35 @@ def refine_pairs(pairs: Sequence[tuple], *, thresholds: Optional[RefinementThres
     count = {"decodes": 0, "fit_launches": 0, "ssim_launches": 0, "pairs": len(pairs)}
 
     def run(chunk: list, decoded: dict) -> None:
-        # (common size) -> pairs; (path, common size) -> plane slot inside that size's plane stack
-        by_size: dict = {}
+        """One ``ke_ssim_pairs`` call for the pairs of this run (the library groups them: one fit launch per (source size,
+        common size), one SSIM launch per common size)."""
+        paths = [p for p, a in decoded.items() if a is not None]
+        index = {p: i for i, p in enumerate(paths)}
+        live = []
         for k in chunk:
             fid_a, fid_b, pa, pb = pairs[k]
-            ia, ib = decoded.get(str(pa)), decoded.get(str(pb))
-            if ia is None or ib is None:
+            if decoded.get(str(pa)) is None or decoded.get(str(pb)) is None:
                 out[k] = None                                      # unreadable file: src/dup/refine.py:82-85
-                continue
-            w, h = min(ia.shape[1], ib.shape[1]), min(ia.shape[0], ib.shape[0])
-            if w == 0 or h == 0:
-                w, h = max(ia.shape[1], ib.shape[1]), max(ia.shape[0], ib.shape[0])
-            if w < 7 or h < 7:                                     # skimage raises for images smaller than its window
+            else:
+                live.append(k)
+        if not live:
+            return
+        images = [decoded[p] for p in paths]
+        scores, status = ctx.ssim_pairs(images, [index[str(pairs[k][2])] for k in live], [index[str(pairs[k][3])] for k in live])
+        common, fits = set(), set()
+        for k, sc, st in zip(live, scores.tolist(), status.tolist()):
+            fid_a, fid_b, pa, pb = pairs[k]
+            if st != 0:                                            # skimage raises for images smaller than its window
                 logger.warning("SSIM refinement failed for %s and %s: win_size exceeds image extent", pa, pb)
                 out[k] = _decide(fid_a, fid_b, None, ["ssim unavailable"], cfg)
                 continue
-            by_size.setdefault((w, h), []).append(k)
-        for (w, h), ks in by_size.items():
-            # plane stack of this common size: the files of one source shape sit next to each other, so a fit launch
-            # writes its whole group straight into place
-            groups: dict = {}
-            for k in ks:
-                for p in (str(pairs[k][2]), str(pairs[k][3])):
-                    members = groups.setdefault(decoded[p].shape, {})
-                    members.setdefault(p, len(members))
-            slots, base = {}, 0
-            for shape, members in groups.items():
-                for p, j in members.items():
-                    slots[p] = base + j
-                base += len(members)
-            planes = ctx.malloc(base * w * h)
-            try:
-                at = 0
-                for shape, members in groups.items():
-                    ch = 1 if len(shape) == 2 else shape[2]
-                    stack = np.stack([decoded[p] for p in members])
-                    ctx.fit_luma_uniform(stack, len(members), shape[1], shape[0], ch, w, h, _native.FILTER_BICUBIC,
-                                         out=planes + at * w * h)
-                    count["fit_launches"] += 1
-                    at += len(members)
-                scores = ctx.ssim_pairs_uniform(planes, base, w, h, 1, [slots[str(pairs[k][2])] for k in ks],
-                                                [slots[str(pairs[k][3])] for k in ks])
-                count["ssim_launches"] += 1
-            finally:
-                ctx.free(planes)
-            for k, sc in zip(ks, scores.tolist()):
-                out[k] = _decide(pairs[k][0], pairs[k][1], float(sc), [], cfg)
+            out[k] = _decide(fid_a, fid_b, float(sc), [], cfg)
+            sa, sb = decoded[str(pa)].shape, decoded[str(pb)].shape
+            size = (min(sa[1], sb[1]), min(sa[0], sb[0]))
+            common.add(size)
+            fits.update({(sa[:2], size), (sb[:2], size)})
+        count["fit_launches"] += len(fits)
+        count["ssim_launches"] += len(common)
 
     def load(p: str):
         img = load_rgb(p)

@@ -435,6 +435,52 @@ def test_ssim_score_does_not_depend_on_the_launch(ctx):
     assert np.array_equal(big.reshape(300, -1), np.tile(whole, (300, 1)))
 
 
+def test_ssim_pairs_of_any_sizes_in_one_call(ctx):
+    """ke_ssim_pairs = the whole of dup.refine._compute_ssim for a ragged batch: common size, ImageOps.fit + BICUBIC of both
+    images, SSIM -- against the oracle's ssim_fit (Pillow-pinned fit + SciPy-restated SSIM), with per-pair statuses."""
+    import ctypes as C
+
+    shapes = [(256, 256), (256, 256), (320, 240), (200, 160), (333, 201), (640, 480), (6, 300), (5, 5), (256, 256), (1024, 768)]
+    rng = np.random.default_rng(23)
+    imgs = []
+    for k, (w, h) in enumerate(shapes):
+        base = O.synth_rgb(1000 + 10 * (k // 2), w, h)
+        imgs.append(np.clip(base.astype(np.int16) + rng.integers(-2, 3, base.shape), 0, 255).astype(np.uint8) if k % 2 else base)
+    pa = [0, 0, 2, 2, 4, 5, 0, 6, 7, 8, 9, 3, 1]
+    pb = [1, 8, 3, 0, 5, 9, 6, 0, 7, 1, 2, 4, 1]
+    got, status = ctx.ssim_pairs(imgs, pa, pb)
+    for k, (a, b) in enumerate(zip(pa, pb)):
+        small = min(imgs[a].shape[0], imgs[b].shape[0]) < 7 or min(imgs[a].shape[1], imgs[b].shape[1]) < 7
+        assert status[k] == (1 if small else 0), k
+        if small:
+            assert np.isnan(got[k])
+        else:
+            assert abs(got[k] - O.ssim_fit(imgs[a], imgs[b])) <= 1e-5, (k, shapes[a], shapes[b])
+    assert got[12] == 1.0                                   # an image against itself
+    # raw entry: an index outside the batch is a per-pair status, not an error; luma ("L") input; device-resident pixels
+    luma = [O.luma(im) for im in imgs[:4]]
+    g2, s2 = ctx.ssim_pairs(luma, [0, 2, 3], [1, 3, 9])
+    assert s2.tolist() == [0, 0, 2] and np.isnan(g2[2])
+    assert abs(g2[0] - O.ssim_fit(luma[0], luma[1])) <= 1e-5 and abs(g2[1] - O.ssim_fit(luma[2], luma[3])) <= 1e-5
+    flat = np.concatenate([im.reshape(-1) for im in imgs[:6]])
+    offs = np.zeros(6, np.uint64)
+    offs[1:] = np.cumsum([im.size for im in imgs[:5]])
+    w_arr = np.array([im.shape[1] for im in imgs[:6]], np.int32)
+    h_arr = np.array([im.shape[0] for im in imgs[:6]], np.int32)
+    a_arr, b_arr = np.array([0, 2, 4], np.int64), np.array([1, 3, 5], np.int64)
+    out, st = np.zeros(3), np.zeros(3, np.int32)
+    dev = ctx.malloc(flat.nbytes)
+    try:
+        ctx.memcpy(dev, flat, flat.nbytes)
+        rc = ctx._lib.ke_ssim_pairs(ctx._h, dev, offs.ctypes.data, w_arr.ctypes.data, h_arr.ctypes.data, 3, 6, a_arr.ctypes.data,
+                                    b_arr.ctypes.data, 3, out.ctypes.data, st.ctypes.data)
+        assert rc == 0 and st.tolist() == [0, 0, 0]
+    finally:
+        ctx.free(dev)
+    for k in range(3):                                      # packed offsets: image 4 (333 x 201) starts off a dword boundary
+        assert abs(out[k] - O.ssim_fit(imgs[a_arr[k]], imgs[b_arr[k]])) <= 1e-5, k
+
+
 def test_fit_bicubic_matches_pillow_golden_and_oracle(ctx):
     """ke_fit_luma_uniform = ImageOps.fit(convert("L"), size, BICUBIC) (src/dup/refine.py:45-49): Pillow's own
     tiles from tests/golden/fit_golden.npz, bit for bit; then a seeded sweep against the oracle (itself pinned

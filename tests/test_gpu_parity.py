@@ -456,7 +456,7 @@ def test_ssim_pairs_of_any_sizes_in_one_call(ctx):
             assert np.isnan(got[k])
         else:
             assert abs(got[k] - O.ssim_fit(imgs[a], imgs[b])) <= 1e-5, (k, shapes[a], shapes[b])
-    assert got[12] == 1.0                                   # an image against itself
+    assert abs(got[12] - 1.0) <= 1e-7                       # an image against itself (the exact kernel returns 1.0 to the bit)
     # raw entry: an index outside the batch is a per-pair status, not an error; luma ("L") input; device-resident pixels
     luma = [O.luma(im) for im in imgs[:4]]
     g2, s2 = ctx.ssim_pairs(luma, [0, 2, 3], [1, 3, 9])

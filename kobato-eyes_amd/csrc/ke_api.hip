@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <numeric>
+#include <unordered_map>
 
 #include "ke_internal.h"
 
@@ -221,6 +222,11 @@ KE_API void ke_destroy(ke_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     stage_free(ctx);
+    for (int k = 0; k < 2; ++k) {
+        if (ctx->side[k]) (void)hipStreamDestroy(ctx->side[k]);
+        if (ctx->side_join[k]) (void)hipEventDestroy(ctx->side_join[k]);
+    }
+    if (ctx->side_fork) (void)hipEventDestroy(ctx->side_fork);
     if (ctx->h_comm) (void)hipHostFree(ctx->h_comm);
     for (auto &b : ctx->buf)
         if (b.ptr) (void)hipFree(b.ptr);
@@ -401,11 +407,43 @@ static int hash_images_impl(ke_ctx *ctx, const uint8_t *pixels, const uint64_t *
         off[i] = offsets ? offsets[i] : run;
         if (widths[i] > 0 && heights[i] > 0) run += (uint64_t)widths[i] * heights[i] * channels;
     }
+    // size groups: an image's group id comes from a one-entry cache or a hash lookup (the shape list of a library is short),
+    // the members are then laid out by a counting sort -- linear in n with small constants (a million-image call spends its
+    // host time here)
     std::map<std::pair<int, int>, std::vector<int64_t>> groups;
-    for (int64_t i = 0; i < n; ++i) {
-        const bool ok = widths[i] > 0 && heights[i] > 0;
-        if (status_out) status_out[i] = ok ? KE_IMG_OK : KE_IMG_BAD_SHAPE;
-        if (ok) groups[{widths[i], heights[i]}].push_back(i);
+    {
+        std::unordered_map<uint64_t, int32_t> ids;
+        std::vector<int32_t> gid((size_t)n, -1);
+        std::vector<int64_t> counts;
+        std::vector<std::pair<int, int>> shapes;
+        uint64_t last_key = ~0ull;
+        int32_t last_id = -1;
+        for (int64_t i = 0; i < n; ++i) {
+            const bool ok = widths[i] > 0 && heights[i] > 0;
+            if (status_out) status_out[i] = ok ? KE_IMG_OK : KE_IMG_BAD_SHAPE;
+            if (!ok) continue;
+            const uint64_t key = ((uint64_t)(uint32_t)widths[i] << 32) | (uint32_t)heights[i];
+            if (key != last_key) {
+                auto it = ids.find(key);
+                if (it == ids.end()) {
+                    it = ids.emplace(key, (int32_t)shapes.size()).first;
+                    shapes.emplace_back(widths[i], heights[i]);
+                    counts.push_back(0);
+                }
+                last_key = key;
+                last_id = it->second;
+            }
+            gid[i] = last_id;
+            ++counts[last_id];
+        }
+        std::vector<std::vector<int64_t> *> slots(shapes.size());
+        for (size_t k = 0; k < shapes.size(); ++k) {
+            auto &v = groups[shapes[k]];
+            v.reserve((size_t)counts[k]);
+            slots[k] = &v;
+        }
+        for (int64_t i = 0; i < n; ++i)
+            if (gid[i] >= 0) slots[gid[i]]->push_back(i);
     }
     const bool in_dev = ke_is_device_ptr(pixels);
     const bool p_dev = phash_out && ke_is_device_ptr(phash_out), d_dev = dhash_out && ke_is_device_ptr(dhash_out);
@@ -449,7 +487,24 @@ static int hash_images_impl(ke_ctx *ctx, const uint8_t *pixels, const uint64_t *
         KE_TRY(ke_reserve(ctx, KE_BUF_META, std::max<size_t>(cursor, 2) * 8, &meta));
         if (cursor) KE_HIP(ctx, hipMemcpyAsync(meta, meta_h.data(), cursor * 8, hipMemcpyHostToDevice, ctx->stream));
         KE_HIP(ctx, hipStreamSynchronize(ctx->stream));   // meta_h is a local
+        // Neighbouring size groups overlap: the one-workgroup-per-image kernels of the groups alternate between two side
+        // streams (they use no scratch), so the tail of one launch -- its last workgroups draining -- runs beside the head of
+        // the next instead of leaving the chip half empty 81 times in a mixed-resolution batch.  Whatever a group needs
+        // beyond that kernel (banded paths, second passes) stays on the context's stream.
+        const bool overlap = groups.size() > 1 && !getenv("KE_NO_GROUP_OVERLAP");
+        if (overlap && !ctx->side[0]) {
+            for (int k = 0; k < 2; ++k) {
+                KE_HIP(ctx, hipStreamCreateWithFlags(&ctx->side[k], hipStreamNonBlocking));
+                KE_HIP(ctx, hipEventCreateWithFlags(&ctx->side_join[k], hipEventDisableTiming));
+            }
+            KE_HIP(ctx, hipEventCreateWithFlags(&ctx->side_fork, hipEventDisableTiming));
+        }
+        if (overlap) {
+            KE_HIP(ctx, hipEventRecord(ctx->side_fork, ctx->stream));          // outputs zeroed, metadata in place
+            for (int k = 0; k < 2; ++k) KE_HIP(ctx, hipStreamWaitEvent(ctx->side[k], ctx->side_fork, 0));
+        }
         size_t gi = 0;
+        int rc_groups = KE_OK;
         for (auto &kv : groups) {
             const int w = kv.first.first, h = kv.first.second;
             const uint64_t *d_off = (const uint64_t *)meta + spans[gi].first;
@@ -459,9 +514,17 @@ static int hash_images_impl(ke_ctx *ctx, const uint8_t *pixels, const uint64_t *
             // boundary; a packed stream loses that after the first image whose byte size is not a multiple of 4
             for (int64_t idx : kv.second)
                 if (((uintptr_t)pixels + off[idx]) % 4 != 0) { g.misaligned = true; break; }
-            KE_TRY(ke_launch_hash_group(ctx, g, d_ph, d_dh, nullptr, nullptr));
+            rc_groups = ke_launch_hash_group(ctx, g, d_ph, d_dh, nullptr, nullptr, overlap ? ctx->side[gi & 1] : nullptr);
+            if (rc_groups != KE_OK) break;
             ++gi;
         }
+        if (overlap) {                                                          // join, also on the error path
+            for (int k = 0; k < 2; ++k) {
+                KE_HIP(ctx, hipEventRecord(ctx->side_join[k], ctx->side[k]));
+                KE_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_join[k], 0));
+            }
+        }
+        KE_TRY(rc_groups);
     } else {
         for (auto &kv : groups) {
             const int w = kv.first.first, h = kv.first.second;

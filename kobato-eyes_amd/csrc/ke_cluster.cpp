@@ -10,7 +10,7 @@
 #include "ke_internal.h"
 
 namespace {
-inline int64_t find_root(std::vector<int64_t> &parent, int64_t x) {
+inline int64_t find_root(int64_t *parent, int64_t x) {
     while (parent[x] != x) {
         parent[x] = parent[parent[x]];
         x = parent[x];
@@ -21,7 +21,9 @@ inline int64_t find_root(std::vector<int64_t> &parent, int64_t x) {
 
 KE_API int ke_cluster_labels(const ke_edge *edges, int64_t n_edges, int64_t n_nodes, int64_t *label_out) {
     if (n_edges < 0 || n_nodes < 0 || (n_edges > 0 && !edges) || (n_nodes > 0 && !label_out)) return KE_EINVAL;
-    std::vector<int64_t> parent((size_t)n_nodes);
+    // label_out doubles as the parent array (no allocation); only the end points of edges can end up under another root,
+    // so the closing pass walks the edges, not the nodes: O(nodes) stores + O(edges) finds
+    int64_t *parent = label_out;
     for (int64_t v = 0; v < n_nodes; ++v) parent[v] = v;
     for (int64_t e = 0; e < n_edges; ++e) {
         const int64_t a = edges[e].a, b = edges[e].b;
@@ -30,6 +32,10 @@ KE_API int ke_cluster_labels(const ke_edge *edges, int64_t n_edges, int64_t n_no
         if (ra == rb) continue;
         if (ra < rb) parent[rb] = ra; else parent[ra] = rb;   // smaller index stays root
     }
-    for (int64_t v = 0; v < n_nodes; ++v) label_out[v] = find_root(parent, v);
+    for (int64_t e = 0; e < n_edges; ++e) {                   // flatten: every touched node points at its root
+        const int64_t ra = find_root(parent, edges[e].a);
+        parent[edges[e].a] = ra;
+        parent[edges[e].b] = ra;
+    }
     return KE_OK;
 }

@@ -1750,7 +1750,7 @@ int resample_single_pass_banded(ke_ctx *ctx, const KeHashGroup &g, uint8_t *d_t3
 }  // namespace
 
 int ke_launch_hash_group(ke_ctx *ctx, const KeHashGroup &g, uint64_t *d_phash, uint64_t *d_dhash, uint8_t *d_tile32_out,
-                         uint8_t *d_tile98_out) {
+                         uint8_t *d_tile98_out, hipStream_t fused_stream) {
     KE_TRY(upload_dct_tables(ctx));
     const bool want_p = d_phash || d_tile32_out, want_d = d_dhash || d_tile98_out;
     bool p_done = false, d_done = false;
@@ -1764,7 +1764,12 @@ int ke_launch_hash_group(ke_ctx *ctx, const KeHashGroup &g, uint64_t *d_phash, u
     if (const char *e = getenv("KE_FUSED_MIN_IMAGES")) fused_min = atoll(e);
     if (want_p && g.n >= fused_min) {
         bool did_d = false;
+        // one workgroup per image: no scratch buffers, so the caller may put it on a side stream where it overlaps the
+        // neighbouring size groups' kernels (what follows below uses the context's scratch and stays on the context's stream)
+        hipStream_t home = ctx->stream;
+        if (fused_stream) ctx->stream = fused_stream;
         const int rc = dispatch_single_pass(ctx, g, want_d, d_phash, d_tile32_out, d_dhash, d_tile98_out, nullptr, &did_d);
+        ctx->stream = home;
         if (rc == KE_OK) { p_done = true; d_done = did_d; }
         else if (rc != KE_EUNSUPPORTED) return rc;
     }

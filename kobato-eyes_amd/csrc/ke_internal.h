@@ -133,6 +133,8 @@ struct ke_ctx {
     hipEvent_t ev0[KE_T_COUNT] = {}, ev1[KE_T_COUNT] = {};
     bool ev_valid[KE_T_COUNT] = {};
     KeStage *stage = nullptr;
+    hipStream_t side[2] = {nullptr, nullptr};   // side streams of the ragged hash call: neighbouring size groups overlap their tails
+    hipEvent_t side_fork = nullptr, side_join[2] = {nullptr, nullptr};
     int64_t edge_slots = 1024;       // edges carried by one record of ke_allgather_edges (follows the largest list seen)
     void *h_comm = nullptr;          // pinned landing zone of the gathered edge records
     size_t h_comm_bytes = 0;
@@ -182,8 +184,9 @@ struct KeHashGroup {
     int w, h, channels;
     bool misaligned = false;   // some image of the group starts at an address that is not a multiple of 4
 };
+// fused_stream (nullable): where the scratch-free one-workgroup-per-image kernel of the group may run instead of ctx->stream
 int ke_launch_hash_group(ke_ctx *ctx, const KeHashGroup &g, uint64_t *d_phash, uint64_t *d_dhash,
-                         uint8_t *d_tile32_out, uint8_t *d_tile98_out);
+                         uint8_t *d_tile32_out, uint8_t *d_tile98_out, hipStream_t fused_stream = nullptr);
 // luma + resize of a group to (oh x ow) u8 tiles with the given filter (banded path, generic fallback)
 // box = {x0, y0, x1, y1} source rectangle (Pillow's resize box), NULL = the whole image
 int ke_launch_resize_group(ke_ctx *ctx, const KeHashGroup &g, int ow, int oh, int filter, uint8_t *d_tiles,

@@ -134,6 +134,27 @@ int ke_stage_submit_hash(ke_ctx *ctx, int32_t slot, const uint64_t *offsets, con
                          float *margin_out);
 int ke_stage_wait(ke_ctx *ctx, int32_t slot);
 
+/* ---- JPEG decode on the GPU: `Image.open(path)` + pixel access of the reference's batch hasher (src/core/fastsig.py:31-34;
+ * the decode half of north-star step 1) for baseline sequential Huffman JPEGs with 8-bit samples and one scan -- grayscale
+ * ("L") or YCbCr at 4:4:4 / 4:2:2 / 4:2:0 ("RGB").  The pixels are libjpeg's as Pillow drives it (islow IDCT, fancy
+ * upsampling, jdcolor's fixed-point YCbCr -> RGB), bit for bit; everything else (progressive, arithmetic, 12-bit, CMYK/YCCK,
+ * RGB-coded, other samplings, several scans) is reported KE_JPEG_UNSUPPORTED per file and stays with Pillow, truncated or
+ * damaged entropy data KE_JPEG_CORRUPT (Pillow raises on those).  EXIF orientation is not applied -- nor does Image.open.
+ *
+ * ke_jpeg_probe  : host only.  files + offsets[i] .. + sizes[i] = file i.  widths/heights/channels (1 or 3)/status per file,
+ *                  so that the caller can lay out the pixel buffer.
+ * ke_jpeg_decode : files in HOST memory (pageable or the pinned buffer of ke_stage_acquire: the compressed bytes are what
+ *                  crosses PCIe), pixels_out in DEVICE memory: image i is written packed at pixels_out + out_offsets[i]
+ *                  (heights[i] * widths[i] * channels[i] bytes) when status_out[i] == KE_JPEG_OK and left untouched
+ *                  otherwise.  One thread per image decodes the entropy-coded segment, then one thread per 8x8 block runs the
+ *                  IDCT and one per 4 pixels upsampling + colour: throughput comes from the batch (thousands of files per
+ *                  call).  Blocks until the statuses are back. */
+enum { KE_JPEG_OK_ = 0, KE_JPEG_UNSUPPORTED_ = 1, KE_JPEG_CORRUPT_ = 2 };   /* = KE_JPEG_OK / _UNSUPPORTED / _CORRUPT of the library */
+int ke_jpeg_probe(const uint8_t *files, const uint64_t *offsets, const uint64_t *sizes, int64_t n, int32_t *widths,
+                  int32_t *heights, int32_t *channels, int32_t *status_out);
+int ke_jpeg_decode(ke_ctx *ctx, const uint8_t *files, const uint64_t *offsets, const uint64_t *sizes, int64_t n,
+                   uint8_t *pixels_out, const uint64_t *out_offsets, int32_t *status_out);
+
 /* Debug/parity hook: the resampled luma tiles the hashes are computed from
  * (reference sig.phash._to_grayscale, src/sig/phash.py:21-26).  tile32_out: n*1024 bytes
  * ([y][x]); tile98_out: n*72 bytes (8 rows x 9 columns); either may be NULL. */
@@ -264,7 +285,7 @@ int ke_synth_hashes(ke_ctx *ctx, uint64_t seed, int64_t n, uint64_t *hashes_out)
 
 /* ---- timing hook for bench.py: wall time of the kernels enqueued by the LAST call of the
  * named kind on this context, measured with hipEvents on the context's stream.
- * kind: 0 = hash kernel(s), 1 = scan kernel, 2 = ssim kernel, 3 = synth kernel.
+ * kind: 0 = hash kernel(s), 1 = scan kernel, 2 = ssim kernel, 3 = synth kernel, 4 = JPEG decode kernels.
  * Returns milliseconds, or a negative value if nothing was recorded.  Blocks until done. */
 double ke_last_kernel_ms(ke_ctx *ctx, int32_t kind);
 

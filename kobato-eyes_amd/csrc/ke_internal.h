@@ -76,7 +76,7 @@ struct KeDevBuf {
     size_t bytes = 0;
 };
 
-enum { KE_T_HASH = 0, KE_T_SCAN = 1, KE_T_SSIM = 2, KE_T_SYNTH = 3, KE_T_COUNT = 4 };
+enum { KE_T_HASH = 0, KE_T_SCAN = 1, KE_T_SSIM = 2, KE_T_SYNTH = 3, KE_T_JPEG = 4, KE_T_COUNT = 5 };
 enum {
     KE_BUF_PIXELS = 0,   // staged input images
     KE_BUF_TMP,          // first-pass output of the generic resampler
@@ -96,6 +96,7 @@ enum {
     KE_BUF_SSIM_AUX,
     KE_BUF_COMM,         // gathered hash shards before they are put back into corpus order
     KE_BUF_COMM_EDGES,   // edge records: [send | world x recv]
+    KE_BUF_JPEG_TABLES,  // Huffman tables of a JPEG batch
     KE_BUF_COUNT
 };
 

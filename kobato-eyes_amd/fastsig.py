@@ -53,6 +53,18 @@ def _read_pixels(path_text: str):
         return None
 
 
+JPEG_SUFFIXES = (".jpg", ".jpeg", ".jpe", ".jfif")
+
+
+def _read_bytes(path_text: str):
+    """The file as it is (JPEG route: the GPU decodes it), or None."""
+    try:
+        with open(path_text, "rb") as fh:
+            return fh.read()
+    except OSError:
+        return None
+
+
 class _GpuStage:
     """The context's pinned staging buffers (``ke_stage_*``) behind the four calls the pipeline needs; tests of the host
     logic put a stand-in here (``_make_stage``)."""
@@ -74,6 +86,11 @@ class _GpuStage:
     def wait(self, slot: int) -> None:
         self.ctx.stage_wait(slot)
 
+    def jpeg_hash(self, blobs):
+        """(phash, dhash, status) of JPEG files decoded on the GPU (``ke_jpeg_decode`` -> ``ke_hash_images``); status != 0:
+        the decoder leaves the file to Pillow."""
+        return self.ctx.jpeg_hash(blobs, want_dhash=True)
+
     def hash_one(self, arr):
         """(phash, dhash) or None for an image that did not fit a staging buffer."""
         ph, dh, ok = _phash.hash_batch([arr], want_dhash=True, device=self.device)
@@ -91,6 +108,11 @@ class _Pipeline:
     regions); ``ke_stage_submit_hash`` then enqueues the copy and the kernels and returns, so chunk k+1 is decoded into
     the other buffer while chunk k crosses PCIe and is hashed.  An image that does not fit what is left of a buffer is
     hashed on its own through ``ke_hash_images``.
+
+    JPEG files (by suffix) skip Pillow altogether: the threads only read the bytes, ``ke_jpeg_decode`` decodes the chunk's
+    files on the GPU -- pixel-identical to ``Image.open`` for baseline JPEGs -- and the hash kernels run on the decoded
+    pixels where they lie.  Files the decoder refuses (progressive, CMYK, damaged ...) take the Pillow route after all.
+    ``KE_GPU_JPEG=0`` turns the route off.
     """
 
     def __init__(self, tasks: Sequence[Task], workers: int, chunk: int, device: int) -> None:
@@ -117,23 +139,48 @@ class _Pipeline:
     def _start(self, start: int):
         slot, view = self.stage.acquire()
         alloc = {"lock": threading.Lock(), "cursor": 0}
-        futures = [self.pool.submit(self._decode_into, p, view, alloc) for _, p in self.tasks[start:start + self.chunk]]
-        return slot, futures
+        gpu_jpeg = os.environ.get("KE_GPU_JPEG", "1") != "0"
+        futures = []
+        for _, p in self.tasks[start:start + self.chunk]:
+            if gpu_jpeg and str(p).lower().endswith(JPEG_SUFFIXES):
+                futures.append(("jpeg", p, self.pool.submit(_read_bytes, p)))
+            else:
+                futures.append(("pixels", p, self.pool.submit(self._decode_into, p, view, alloc)))
+        return slot, (futures, view, alloc)
 
-    def _submit(self, slot: int, futures: List[Future]):
-        decoded = [f.result() for f in futures]
+    def _submit(self, slot: int, started):
+        futures, view, alloc = started
+        decoded: list = [None] * len(futures)
+        jpeg_pos, blobs = [], []
+        for k, (kind, _, fut) in enumerate(futures):
+            res = fut.result()
+            if kind == "pixels":
+                decoded[k] = res
+            elif res is not None:
+                jpeg_pos.append(k)
+                blobs.append(res)
+        jpeg_done = {}
+        if blobs:
+            ph, dh, st = self.stage.jpeg_hash(blobs)
+            for k, p, d, code in zip(jpeg_pos, ph.tolist(), dh.tolist(), st.tolist()):
+                if code == 0:
+                    jpeg_done[k] = (p, d)
+                else:                                  # outside the GPU decoder: Pillow decodes it, as the reference does
+                    decoded[k] = self._decode_into(futures[k][1], view, alloc)
         staged = [(k, d) for k, d in enumerate(decoded) if d is not None and d[0] != "spill"]
         spills = [(k, d[1]) for k, d in enumerate(decoded) if d is not None and d[0] == "spill"]
         handle = None
         if staged:
             handle = self.stage.submit(slot, [d[0] for _, d in staged], [d[1] for _, d in staged],
                                        [d[2] for _, d in staged], [d[3] for _, d in staged])
-        return len(decoded), [k for k, _ in staged], handle, spills
+        return len(decoded), [k for k, _ in staged], handle, spills, jpeg_done
 
     def _collect(self, slot: int, submitted) -> list:
         """Per file of the chunk: (phash_s64, dhash_s64) or None."""
-        count, staged_pos, handle, spills = submitted
+        count, staged_pos, handle, spills, jpeg_done = submitted
         out: list = [None] * count
+        for k, (p, d) in jpeg_done.items():
+            out[k] = (_to_signed64(p), _to_signed64(d))
         if handle is not None:
             self.stage.wait(slot)
             for k, p, d, st in zip(staged_pos, handle["phash"].tolist(), handle["dhash"].tolist(), handle["status"].tolist()):

@@ -1,0 +1,69 @@
+"""JPEG files for the decoder tests, made with the installed Pillow (libjpeg-turbo): every variant the GPU decoder takes
+(sizes around the MCU edges, 4:4:4 / 4:2:2 / 4:2:0, grayscale, qualities, optimised Huffman tables, restart markers) and the
+ones it must hand back to Pillow (progressive, CMYK, RGB-coded, truncated)."""
+from __future__ import annotations
+
+import io
+
+import numpy as np
+from PIL import Image, ImageFile
+
+ImageFile.MAXBLOCK = 1 << 26          # Pillow's encoder buffer: noise at quality 100 does not fit the default
+
+
+def _image(rng, w, h, kind):
+    yy, xx = np.mgrid[0:h, 0:w]
+    if kind == 0:
+        return rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    if kind == 1:
+        return np.stack([xx * 255 // max(w - 1, 1), yy * 255 // max(h - 1, 1), (xx + yy) * 255 // max(w + h - 2, 1)], -1).astype(np.uint8)
+    base = rng.integers(0, 256, (h // 16 + 1, w // 16 + 1, 3), dtype=np.uint8)
+    a = np.repeat(np.repeat(base, 16, 0), 16, 1)[:h, :w]
+    return np.clip(a.astype(np.int16) + rng.integers(-6, 7, a.shape), 0, 255).astype(np.uint8)
+
+
+def _save(arr, **kw) -> bytes:
+    b = io.BytesIO()
+    Image.fromarray(arr).save(b, "JPEG", **kw)
+    return b.getvalue()
+
+
+def supported(full: bool = False):
+    """Yields (name, file bytes, pixels as Pillow decodes them)."""
+    rng = np.random.default_rng(1)
+    sizes = [(1, 1), (2, 2), (1, 9), (9, 1), (5, 3), (8, 8), (9, 9), (17, 33), (64, 64), (101, 77), (255, 257), (512, 512), (640, 480)]
+    if full:
+        sizes += [(1000, 31), (33, 1000), (1024, 768), (3, 3), (4, 4), (16, 16), (15, 17)]
+    for (w, h) in sizes:
+        for kind in (0, 1, 2):
+            a = _image(rng, w, h, kind)
+            for sub in (0, 1, 2):
+                for q, extra in ((30, {}), (75, {"optimize": True}), (95, {}), (100, {})) if full or kind == 2 else ((85, {}),):
+                    data = _save(a, quality=q, subsampling=sub, **extra)
+                    yield f"{w}x{h}_k{kind}_s{sub}_q{q}", data, np.asarray(Image.open(io.BytesIO(data)))
+            data = _save(a[:, :, 1], quality=80)
+            yield f"{w}x{h}_k{kind}_gray", data, np.asarray(Image.open(io.BytesIO(data)))
+    a = _image(rng, 200, 120, 2)
+    for kw in ({"restart_marker_blocks": 1}, {"restart_marker_blocks": 7}, {"restart_marker_rows": 1}, {"restart_marker_rows": 3}):
+        for sub in (0, 2):
+            try:
+                data = _save(a, quality=85, subsampling=sub, **kw)
+            except TypeError:                      # a Pillow without the restart options
+                continue
+            yield f"restart_{list(kw)[0]}_{list(kw.values())[0]}_s{sub}", data, np.asarray(Image.open(io.BytesIO(data)))
+
+
+def refused():
+    """Yields (name, file bytes, expected status): 1 = left to Pillow, 2 = damaged."""
+    rng = np.random.default_rng(2)
+    a = _image(rng, 96, 64, 2)
+    yield "progressive", _save(a, quality=85, progressive=True), 1
+    yield "cmyk", (lambda b: (Image.fromarray(a).convert("CMYK").save(b, "JPEG"), b.getvalue())[1])(io.BytesIO()), 1
+    try:
+        yield "rgb_coded", _save(a, quality=90, keep_rgb=True), 1
+    except TypeError:
+        pass
+    good = _save(a, quality=85)
+    yield "truncated", good[: len(good) * 2 // 3], 2
+    yield "not_a_jpeg", b"\\x89PNG\\r\\n\\x1a\\n" + bytes(64), 2
+    yield "empty", b"", 2

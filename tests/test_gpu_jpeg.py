@@ -1,0 +1,113 @@
+"""GPU JPEG decoder (ke_jpeg_probe / ke_jpeg_decode, csrc/ke_jpeg.hip) against the installed Pillow: the pixels of
+`Image.open(file)`, bit for bit, for every file the decoder takes -- one mixed batch (sizes, samplings, grayscale, restart
+markers together) -- the right per-file refusal for the rest, and the hashes of the decode -> hash route without the pixels
+leaving the GPU against the oracle on Pillow's pixels."""
+from __future__ import annotations
+
+import numpy as np
+import pytest
+
+import _jpeg_cases as J
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from kobato_eyes_amd import _native
+
+    return _native.get_context(0)
+
+
+def test_decode_matches_pillow_in_one_mixed_batch(ctx):
+    cases = list(J.supported(full=True))
+    refused = list(J.refused())
+    blobs = [c[1] for c in cases] + [r[1] if r[1] else b"\0" for r in refused]
+    out, status = ctx.jpeg_decode(blobs)
+    for k, (name, _, ref) in enumerate(cases):
+        assert status[k] == 0, name
+        assert out[k].shape == ref.shape and np.array_equal(out[k], ref), name
+    for k, (name, _, expected) in enumerate(refused, len(cases)):
+        assert status[k] == expected and out[k] is None, name
+    assert len(cases) > 400
+    w, h, c, st = ctx.jpeg_probe(blobs[:3])
+    assert (w[0], h[0], c[0], st[0]) == (cases[0][2].shape[1], cases[0][2].shape[0], 3, 0)
+
+
+def test_decode_and_hash_without_leaving_the_gpu(ctx):
+    cases = [c for c in J.supported() if min(c[2].shape[:2]) >= 16][:120]
+    refused = list(J.refused())[:2]
+    blobs = [c[1] for c in cases] + [r[1] for r in refused]
+    ph, dh, status = ctx.jpeg_hash(blobs)
+    for k, (name, _, ref) in enumerate(cases):
+        assert status[k] == 0, name
+        assert (int(ph[k]), int(dh[k])) == O.hash_image(ref), name
+    assert status[len(cases):].tolist() == [r[2] for r in refused]
+
+
+def test_large_batch_of_equal_files_and_damage(ctx):
+    """4 096 files in one call (64 waves of the entropy kernel), every 97th damaged in its entropy data: the damaged ones are
+    reported, the rest are untouched by their neighbours' failure."""
+    import io
+
+    from PIL import Image
+
+    rng = np.random.default_rng(5)
+    a = np.clip(np.repeat(np.repeat(rng.integers(0, 256, (16, 16, 3)), 16, 0), 16, 1) + rng.integers(-5, 6, (256, 256, 3)), 0, 255).astype(np.uint8)
+    b = io.BytesIO()
+    Image.fromarray(a).save(b, "JPEG", quality=88)
+    good = b.getvalue()
+    ref = np.asarray(Image.open(io.BytesIO(good)))
+    cut = good[: len(good) // 2] + b"\xff\xd9"                 # entropy data ends early
+    blobs = [cut if k % 97 == 5 else good for k in range(4096)]
+    ph, dh, status = ctx.jpeg_hash(blobs)
+    exp = O.hash_image(ref)
+    for k in range(4096):
+        if k % 97 == 5:
+            assert status[k] != 0
+        else:
+            assert status[k] == 0 and (int(ph[k]), int(dh[k])) == exp, k
+
+
+def test_fast_fill_takes_the_gpu_route_for_jpeg_files(tmp_path, monkeypatch):
+    """A folder of baseline, progressive, grayscale and damaged JPEGs plus PNGs through fast_fill_missing_signatures: rows equal
+    the Pillow route's (KE_GPU_JPEG=0) and the oracle on Pillow's pixels, in input order, failures dropped."""
+    import io
+
+    from PIL import Image
+
+    import kobato_eyes_amd as K
+
+    rng = np.random.default_rng(9)
+    items, expect = [], {}
+    for k in range(40):
+        base = np.repeat(np.repeat(rng.integers(0, 256, (12, 16, 3)), 16, 0), 16, 1).astype(np.int16)
+        arr = np.clip(base + rng.integers(-4, 5, base.shape), 0, 255).astype(np.uint8)
+        kind = k % 5
+        name = tmp_path / (f"f{k:02d}.png" if kind == 4 else f"f{k:02d}.jpg" if kind != 2 else f"f{k:02d}.JPEG")
+        if kind == 4:
+            Image.fromarray(arr).save(name)
+        elif kind == 0:
+            Image.fromarray(arr).save(name, "JPEG", quality=90, subsampling=k % 3)
+        elif kind == 1:
+            Image.fromarray(arr).save(name, "JPEG", quality=80, progressive=True)
+        elif kind == 2:
+            Image.fromarray(arr[:, :, 0]).save(name, "JPEG", quality=85)
+        else:
+            b = io.BytesIO()
+            Image.fromarray(arr).save(b, "JPEG", quality=85)
+            name.write_bytes(b.getvalue()[:300])                   # damaged: Pillow raises -> the file is dropped
+        items.append((k + 1, str(name)))
+        try:
+            with Image.open(name) as im:
+                expect[k + 1] = O.hash_image(np.asarray(im.convert("RGB") if im.mode not in ("L", "RGB") else im))
+        except OSError:
+            pass
+    rows = K.compute_signatures_mp(items, max_workers=4, chunksize=16)
+    monkeypatch.setenv("KE_GPU_JPEG", "0")
+    rows_pillow = K.compute_signatures_mp(items, max_workers=4, chunksize=16)
+    assert rows == rows_pillow
+    assert [r[0] for r in rows] == sorted(expect)
+    for fid, ph, dh in rows:
+        assert (ph, dh) == tuple(O.to_signed64(v) for v in expect[fid]), fid

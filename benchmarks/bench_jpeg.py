@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""GPU JPEG decode (+ hash) throughput beside Pillow on the host cores: N baseline JPEG files of side x side pixels (256 distinct
+synthetic-corpus images encoded by Pillow at quality 85, 4:2:0, repeated to N), one ke_jpeg_decode call per batch.
+    python benchmarks/bench_jpeg.py [--images 16384 --side 512 --batch 16384]
+One JSON line: decode kernels (HIP events), decode + hash wall time (compressed bytes start in host memory), Pillow decode on
+the usable cores."""
+from __future__ import annotations
+
+import argparse
+import io
+import json
+import os
+import sys
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--images", type=int, default=16384)
+    ap.add_argument("--side", type=int, default=512)
+    ap.add_argument("--quality", type=int, default=85)
+    ap.add_argument("--subsampling", type=int, default=2)
+    args = ap.parse_args()
+    from PIL import Image
+
+    from kobato_eyes_amd import _native
+
+    ctx = _native.Context(0)
+    distinct = 256
+    px = ctx.synth_rgb(20260604, 0, distinct, args.side, args.side)
+    files = []
+    for k in range(distinct):
+        b = io.BytesIO()
+        Image.fromarray(px[k]).save(b, "JPEG", quality=args.quality, subsampling=args.subsampling)
+        files.append(b.getvalue())
+    blobs = [files[k % distinct] for k in range(args.images)]
+    comp_bytes = sum(len(b) for b in blobs)
+    ctx.jpeg_hash(blobs[:512])                                   # warm-up: allocations, tables
+    t_wall, t_kern = [], []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        ph, dh, st = ctx.jpeg_hash(blobs, want_dhash=False)
+        t_wall.append(time.perf_counter() - t0)
+        t_kern.append(ctx.last_kernel_ms(4))
+    assert (st == 0).all()
+    # Pillow on the host cores
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        cores = os.cpu_count() if quota == "max" else max(1, int(int(quota) / int(period)))
+    except (OSError, ValueError):
+        cores = os.cpu_count() or 1
+    sample = blobs[: max(256, 64 * cores)]
+
+    def dec(b):
+        with Image.open(io.BytesIO(b)) as im:
+            im.load()
+        return 1
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        list(ex.map(dec, sample, chunksize=8))
+    t_cpu = time.perf_counter() - t0
+    wall, kern = float(np.median(t_wall)), float(np.median(t_kern))
+    print(json.dumps({"case": "jpeg_decode", "images": args.images, "side": args.side, "quality": args.quality,
+                      "subsampling": ["4:4:4", "4:2:2", "4:2:0"][args.subsampling], "compressed_mb": comp_bytes / 1e6,
+                      "decode_kernels_ms": kern, "decode_images_per_s": args.images / (kern * 1e-3),
+                      "decode_plus_hash_wall_ms": wall * 1e3, "decode_plus_hash_images_per_s": args.images / wall,
+                      "pillow_threads": cores, "pillow_images_per_s": len(sample) / t_cpu}))
+
+
+if __name__ == "__main__":
+    main()

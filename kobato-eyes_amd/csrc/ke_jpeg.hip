@@ -6,8 +6,8 @@
 // Three kernels per batch:
 //   ke_jpeg_entropy : ONE THREAD PER IMAGE walks the image's entropy-coded segment (Huffman decoding is sequential within a
 //                     scan; the parallelism is across the batch -- a 16 384-image batch is one wave per CU, 100 000 images
-//                     fill the chip) and writes the non-zero dequantised coefficients into a zero-filled int16 array;
-//   ke_jpeg_idct    : one thread per 8x8 block, jpeg_idct_islow, samples into padded component planes;
+//                     fill the chip) and writes the non-zero coefficients into a zero-filled int16 array;
+//   ke_jpeg_idct    : one thread per 8x8 block: dequantise, jpeg_idct_islow, samples into padded component planes;
 //   ke_jpeg_colour  : one thread per 4 output pixels: fancy upsampling + YCbCr -> RGB (or the luma plane as it is), packed
 //                     8-bit pixels where ke_hash_images / ke_ssim_pairs expect them.
 // Compressed bytes cross PCIe (a tenth of the pixels); files the parser refuses (progressive, CMYK, ...) are reported per
@@ -31,39 +31,197 @@ struct KeJpegDev {                 // per image, device side
 
 __constant__ uint8_t c_zigzag[64] = KE_ZZ;
 
+// ---- device bit reader.  One thread per image has nothing to hide memory latency with, and on gfx9 loads and stores share
+// one in-order counter (vmcnt): a stream load issued after a coefficient store waits for that store to be acknowledged.  With
+// a global store per coefficient and a global load per few symbols the first version of this kernel spent ~1.4 us per
+// symbol.  So nothing in the symbol loop touches global memory: the compressed stream is pulled through a 64-byte window per
+// lane in LDS (one refill per 56 stream bytes), the coefficients of the current block are collected in LDS and leave as
+// eight 16-byte stores per block, the Huffman tables and the zigzag map live in LDS.
+constexpr int kWin = 64;                  // stream window per lane (bytes)
+constexpr int kWinPitch = kWin + 4;       // + one dword: consecutive lanes start in consecutive banks
+constexpr int kBlkPitch = 128 + 16;       // one block of int16 coefficients per lane, rows kept 16-byte aligned
+
+struct Stream {
+    const uint8_t *file;                  // global
+    uint8_t *win;                         // this lane's LDS window
+    uint32_t win_pos;                     // stream position of win[0] (multiple of 4 relative to the file start)
+    uint32_t end;
+};
+
+__device__ __forceinline__ void stream_load(Stream &s, uint32_t pos) {
+    s.win_pos = pos & ~3u;
+    const uint8_t *src = s.file + s.win_pos;
+#pragma unroll
+    for (int k = 0; k < kWin / 4; ++k) {                                  // the file buffer is padded: reads past `end` stay inside it
+        uint32_t w;
+        __builtin_memcpy(&w, src + 4 * k, 4);
+        reinterpret_cast<uint32_t *>(s.win)[k] = w;
+    }
+}
+
+__device__ __forceinline__ uint32_t stream_byte(Stream &s, uint32_t pos) {
+    if (pos - s.win_pos >= (uint32_t)kWin) stream_load(s, pos);
+    return s.win[pos - s.win_pos];
+}
+
+// four stream bytes from `pos` on, as a little-endian dword (pos + 4 <= end)
+__device__ __forceinline__ uint32_t stream_dword(Stream &s, uint32_t pos) {
+    if (pos - s.win_pos > (uint32_t)(kWin - 8)) stream_load(s, pos);
+    const uint32_t o = pos - s.win_pos;
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(s.win) + (o >> 2);
+    return __builtin_amdgcn_alignbyte(w[1], w[0], o & 3);
+}
+
+__device__ __forceinline__ void bits_fill(KeBits &b, Stream &s) {
+    while (b.n <= 32) {
+        if (b.marker == 0 && b.pos + 4 <= b.end) {
+            const uint32_t w = stream_dword(s, b.pos);
+            const uint32_t x = ~w;
+            if (((x - 0x01010101u) & ~x & 0x80808080u) == 0) {           // no byte of w is 0xFF
+                b.acc |= (uint64_t)__builtin_bswap32(w) << (32 - b.n);
+                b.n += 32;
+                b.pos += 4;
+                continue;
+            }
+        }
+        // one byte, the careful way (ke_bits_fill's body for a single byte)
+        uint32_t byte = 0;
+        if (b.marker == 0 && b.pos < b.end) {
+            byte = stream_byte(s, b.pos);
+            if (byte == 0xFF) {
+                const uint32_t next = b.pos + 1 < b.end ? stream_byte(s, b.pos + 1) : 0xD9u;
+                if (next == 0) {
+                    b.pos += 2;
+                } else {
+                    b.marker = (int32_t)next;
+                    byte = 0;
+                    b.overrun += 1;
+                }
+            } else {
+                b.pos += 1;
+            }
+        } else {
+            b.overrun += 1;
+        }
+        b.acc |= (uint64_t)byte << (56 - b.n);
+        b.n += 8;
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ int huff_decode(KeBits &b, Stream &st, const T *t) {
+    bits_fill(b, st);
+    const uint32_t look = t->look[ke_bits_peek(b, 9)];
+    if (look) {
+        ke_bits_skip(b, (int)(look >> 8));
+        return (int)(look & 0xFF);
+    }
+    int32_t code = (int32_t)ke_bits_peek(b, 10);
+    int l = 10;
+    while (l <= 16 && code > t->maxcode[l]) {
+        ++l;
+        code = (int32_t)ke_bits_peek(b, l);
+    }
+    if (l > 16) return -1;
+    ke_bits_skip(b, l);
+    return t->huffval[(code + t->valoffset[l]) & 0xFF];
+}
+
+__device__ __forceinline__ int receive_extend(KeBits &b, Stream &st, int s) {
+    if (s == 0) return 0;
+    bits_fill(b, st);
+    const int v = (int)ke_bits_peek(b, s);
+    ke_bits_skip(b, s);
+    return v < (1 << (s - 1)) ? v - (1 << s) + 1 : v;
+}
+
+constexpr int kLdsTables = 4;      // distinct Huffman tables a workgroup keeps in LDS (a standard-table file uses four)
+
+// One thread per image.  Coefficients are stored as decoded (int16, natural order, every block written whole); the IDCT kernel
+// dequantises.
 __global__ __launch_bounds__(64) void ke_jpeg_entropy(const KeJpegDev *__restrict__ imgs, int64_t n, const uint8_t *__restrict__ files,
                                                       const KeHuffTable *__restrict__ tables, int16_t *__restrict__ coefs,
                                                       int32_t *__restrict__ status) {
-    const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    if (i >= n) return;
-    const KeJpegDev &d = imgs[i];
+    __shared__ KeHuffTable s_tab[kLdsTables];
+    __shared__ int s_ids[kLdsTables];
+    __shared__ int s_count, s_all;
+    __shared__ uint8_t s_zz[64];
+    __shared__ __attribute__((aligned(16))) uint8_t s_win[64 * kWinPitch];
+    __shared__ __attribute__((aligned(16))) uint8_t s_blk[64 * kBlkPitch];
+    const int lane = threadIdx.x;
+    const int64_t i = (int64_t)blockIdx.x * 64 + lane;
+    const bool live = i < n;
+    const KeJpegDev &d = imgs[live ? i : n - 1];
     const KeJpegInfo &in = d.info;
+    // the workgroup's distinct tables (files of one encoder share them): up to four go to LDS
+    if (lane == 0) { s_count = 0; s_all = 1; }
+    s_zz[lane] = c_zigzag[lane];
+    __syncthreads();
+    int my_dc[3], my_ac[3];
+    for (int c = 0; c < 3; ++c) { my_dc[c] = in.huff_dc[c < in.ncomp ? c : 0]; my_ac[c] = in.huff_ac[c < in.ncomp ? c : 0]; }
+    for (int turn = 0; turn < 64; ++turn) {                               // lanes register their ids one after the other
+        if (lane == turn && live) {
+            for (int c = 0; c < in.ncomp; ++c)
+                for (int id : {my_dc[c], my_ac[c]}) {
+                    bool found = false;
+                    for (int k = 0; k < s_count; ++k) found |= s_ids[k] == id;
+                    if (!found) {
+                        if (s_count < kLdsTables) s_ids[s_count++] = id; else s_all = 0;
+                    }
+                }
+        }
+        __syncthreads();
+    }
+    const int n_tab = s_count;
+    const bool in_lds = s_all != 0;
+    if (in_lds) {
+        for (int k = 0; k < n_tab; ++k) {
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(&tables[s_ids[k]]);
+            uint32_t *dst = reinterpret_cast<uint32_t *>(&s_tab[k]);
+            for (int w = lane; w < (int)(sizeof(KeHuffTable) / 4); w += 64) dst[w] = src[w];
+        }
+    }
+    __syncthreads();
+    if (!live) return;
+    auto slot_of = [&](int id) { int k = 0; while (k < n_tab - 1 && s_ids[k] != id) ++k; return k; };
+    int dc_slot[3], ac_slot[3];
+    for (int c = 0; c < 3; ++c) { dc_slot[c] = in_lds ? slot_of(my_dc[c]) : 0; ac_slot[c] = in_lds ? slot_of(my_ac[c]) : 0; }
+
     KeBits bits;
     ke_bits_init(bits, files + d.file_off, in.scan_offset, in.scan_end);
+    Stream st;
+    st.file = files + d.file_off;
+    st.win = s_win + lane * kWinPitch;
+    st.end = in.scan_end;
+    stream_load(st, in.scan_offset);
+    int16_t *lblk = reinterpret_cast<int16_t *>(s_blk + lane * kBlkPitch);
+    const int ncomp = in.ncomp, mcus_x = in.mcus_x, mcus_y = in.mcus_y, restart_interval = in.restart_interval;
+    int hs[3], vs[3], bpr[3], bbase[3];
+    for (int c = 0; c < 3; ++c) { hs[c] = in.hs[c]; vs[c] = in.vs[c]; bpr[c] = in.plane_w[c] >> 3; bbase[c] = d.block_base[c]; }
     int pred[3] = {0, 0, 0};
-    int restart_left = in.restart_interval;
+    int restart_left = restart_interval;
     int rc = KE_JPEG_OK;
     int16_t *base = coefs + d.coef_off;
-    for (int my = 0; my < in.mcus_y && rc == KE_JPEG_OK; ++my) {
-        for (int mx = 0; mx < in.mcus_x && rc == KE_JPEG_OK; ++mx) {
-            if (in.restart_interval && restart_left == 0) {
+    for (int my = 0; my < mcus_y && rc == KE_JPEG_OK; ++my) {
+        for (int mx = 0; mx < mcus_x && rc == KE_JPEG_OK; ++mx) {
+            if (restart_interval && restart_left == 0) {
                 if (ke_bits_restart(bits) != KE_JPEG_OK) { rc = KE_JPEG_CORRUPT; break; }
                 pred[0] = pred[1] = pred[2] = 0;
-                restart_left = in.restart_interval;
+                restart_left = restart_interval;
             }
-            for (int c = 0; c < in.ncomp && rc == KE_JPEG_OK; ++c) {
-                const KeHuffTable &dc = tables[in.huff_dc[c]], &ac = tables[in.huff_ac[c]];
-                const uint16_t *q = in.quant[c];
-                const int bpr = in.plane_w[c] >> 3;                       // blocks per row of this component
-                for (int by = 0; by < in.vs[c] && rc == KE_JPEG_OK; ++by) {
-                    for (int bx = 0; bx < in.hs[c]; ++bx) {
-                        int16_t *blk = base + ((size_t)d.block_base[c] + (size_t)(my * in.vs[c] + by) * bpr + (mx * in.hs[c] + bx)) * 64;
-                        int s = ke_huff_decode(bits, dc);
+            for (int c = 0; c < ncomp && rc == KE_JPEG_OK; ++c) {
+                const KeHuffTable *gdc = &tables[my_dc[c]], *gac = &tables[my_ac[c]];
+                const KeHuffTable *ldc = &s_tab[dc_slot[c]], *lac = &s_tab[ac_slot[c]];
+                for (int by = 0; by < vs[c] && rc == KE_JPEG_OK; ++by) {
+                    for (int bx = 0; bx < hs[c]; ++bx) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) reinterpret_cast<uint4 *>(lblk)[k] = uint4{0u, 0u, 0u, 0u};
+                        int s = in_lds ? huff_decode(bits, st, ldc) : huff_decode(bits, st, gdc);
                         if (s < 0 || s > 11) { rc = KE_JPEG_CORRUPT; break; }
-                        pred[c] += ke_receive_extend(bits, s);
-                        blk[0] = (int16_t)(pred[c] * (int)q[0]);
+                        pred[c] += receive_extend(bits, st, s);
+                        lblk[0] = (int16_t)pred[c];
                         for (int k = 1; k < 64;) {
-                            const int rs = ke_huff_decode(bits, ac);
+                            const int rs = in_lds ? huff_decode(bits, st, lac) : huff_decode(bits, st, gac);
                             if (rs < 0) { rc = KE_JPEG_CORRUPT; break; }
                             const int r = rs >> 4;
                             s = rs & 15;
@@ -74,11 +232,13 @@ __global__ __launch_bounds__(64) void ke_jpeg_entropy(const KeJpegDev *__restric
                             }
                             k += r;
                             if (k > 63) { rc = KE_JPEG_CORRUPT; break; }
-                            const int nat = c_zigzag[k];
-                            blk[nat] = (int16_t)(ke_receive_extend(bits, s) * (int)q[nat]);
+                            lblk[s_zz[k]] = (int16_t)receive_extend(bits, st, s);
                             ++k;
                         }
                         if (rc != KE_JPEG_OK) break;
+                        uint4 *dst = reinterpret_cast<uint4 *>(base + ((size_t)bbase[c] + (size_t)(my * vs[c] + by) * bpr[c] + (mx * hs[c] + bx)) * 64);
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) dst[k] = reinterpret_cast<const uint4 *>(lblk)[k];
                     }
                 }
             }
@@ -107,9 +267,9 @@ __global__ __launch_bounds__(256) void ke_jpeg_idct(const KeJpegDev *__restrict_
         const int4 v = reinterpret_cast<const int4 *>(src)[k];
         const int w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            blk[8 * k + 2 * j] = (int)(int16_t)(w[j] & 0xFFFF);
-            blk[8 * k + 2 * j + 1] = w[j] >> 16;
+        for (int j = 0; j < 4; ++j) {                                    // dequantise here: the entropy threads store raw values
+            blk[8 * k + 2 * j] = (int)(int16_t)(w[j] & 0xFFFF) * (int)in.quant[c][8 * k + 2 * j];
+            blk[8 * k + 2 * j + 1] = (w[j] >> 16) * (int)in.quant[c][8 * k + 2 * j + 1];
         }
     }
     uint8_t rows[64];
@@ -194,13 +354,16 @@ KE_API int ke_jpeg_decode(ke_ctx *ctx, const uint8_t *files, const uint64_t *off
     if (devs.empty()) return KE_OK;
     // compressed bytes of the decodable files (one contiguous range of the caller's buffer) -> device
     void *d_files;
-    KE_TRY(ke_reserve(ctx, KE_BUF_PIXELS, (size_t)(hi - lo) + 64, &d_files));
+    KE_TRY(ke_reserve(ctx, KE_BUF_PIXELS, (size_t)(hi - lo) + 256, &d_files));   // the stream windows read up to 64 bytes past a file
     KE_HIP(ctx, hipMemcpyAsync(d_files, files + lo, (size_t)(hi - lo), hipMemcpyHostToDevice, ctx->stream));
     void *d_tables;
     KE_TRY(ke_reserve(ctx, KE_BUF_JPEG_TABLES, tables.pool.size() * sizeof(KeHuffTable), &d_tables));
     KE_HIP(ctx, hipMemcpyAsync(d_tables, tables.pool.data(), tables.pool.size() * sizeof(KeHuffTable), hipMemcpyHostToDevice, ctx->stream));
     // sub-batches bounded by scratch: coefficients (2 B per sample) + planes (1 B per sample)
-    const uint64_t budget = (uint64_t)6 << 30;
+    // one thread per image: the larger the sub-batch the better the chip is filled -- up to a third of the free HBM
+    size_t free_b = 0, total_b = 0;
+    KE_HIP(ctx, hipMemGetInfo(&free_b, &total_b));
+    const uint64_t budget = std::max<uint64_t>((uint64_t)2 << 30, std::min<uint64_t>((uint64_t)free_b / 3, (uint64_t)80 << 30));
     size_t first = 0;
     std::vector<int32_t> st;
     ke_time_begin(ctx, KE_T_JPEG);
@@ -240,7 +403,8 @@ KE_API int ke_jpeg_decode(ke_ctx *ctx, const uint8_t *files, const uint64_t *off
         KE_TRY(ke_reserve(ctx, KE_BUF_SSIM_IN, (size_t)plane_bytes + 64, &d_planes));
         KE_TRY(ke_reserve(ctx, KE_BUF_OUT0, (size_t)m * 4, &d_status));
         KE_HIP(ctx, hipMemcpyAsync(d_imgs, devs.data() + first, (size_t)m * sizeof(KeJpegDev), hipMemcpyHostToDevice, ctx->stream));
-        KE_HIP(ctx, hipMemsetAsync(d_coef, 0, (size_t)coef_units * 2, ctx->stream));
+        // no clearing of the coefficient array: every block of an image that decodes is written whole; a damaged image's
+        // remaining blocks hold whatever was there, and its pixels are discarded with its status
         hipLaunchKernelGGL(ke_jpeg_entropy, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, ctx->stream, (const KeJpegDev *)d_imgs, m,
                            (const uint8_t *)d_files, (const KeHuffTable *)d_tables, (int16_t *)d_coef, (int32_t *)d_status);
         hipLaunchKernelGGL(ke_jpeg_idct, dim3((unsigned)((max_blocks + 255) / 256), (unsigned)m), dim3(256), 0, ctx->stream,

@@ -294,15 +294,32 @@ __global__ __launch_bounds__(256) void ke_jpeg_colour(const KeJpegDev *__restric
     const int y = q / quads_per_row, x0 = (q - y * quads_per_row) * 4;
     const uint8_t *Y = planes + d.plane_off[0];
     uint8_t *dst = out + d.out_off;
-    for (int x = x0; x < min(x0 + 4, in.width); ++x) {
-        const int yy = Y[(size_t)y * in.plane_w[0] + x];
-        if (in.ncomp == 1) {
-            dst[(size_t)y * in.width + x] = (uint8_t)yy;
-        } else {
-            const int cb = ke_upsample_at(planes + d.plane_off[1], in.plane_w[1], in.comp_w[1], in.comp_h[1], in.hmax, in.vmax, x, y);
-            const int cr = ke_upsample_at(planes + d.plane_off[2], in.plane_w[2], in.comp_w[2], in.comp_h[2], in.hmax, in.vmax, x, y);
-            ke_ycc_to_rgb(yy, cb, cr, dst + ((size_t)y * in.width + x) * 3);
-        }
+    // four luma samples in one load (plane rows are multiples of 8 bytes, x0 of 4), twelve output bytes in three stores
+    const uint32_t y4 = *reinterpret_cast<const uint32_t *>(Y + (size_t)y * in.plane_w[0] + x0);
+    const int npx = min(4, in.width - x0);
+    if (in.ncomp == 1) {
+        uint8_t *o = dst + (size_t)y * in.width + x0;
+        if (npx == 4) __builtin_memcpy(o, &y4, 4);
+        else for (int k = 0; k < npx; ++k) o[k] = (uint8_t)(y4 >> (8 * k));
+        return;
+    }
+    const uint8_t *Cb = planes + d.plane_off[1], *Cr = planes + d.plane_off[2];
+    uint8_t px[12];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int x = min(x0 + k, in.width - 1);
+        const int cb = ke_upsample_at(Cb, in.plane_w[1], in.comp_w[1], in.comp_h[1], in.hmax, in.vmax, x, y);
+        const int cr = ke_upsample_at(Cr, in.plane_w[2], in.comp_w[2], in.comp_h[2], in.hmax, in.vmax, x, y);
+        ke_ycc_to_rgb((int)((y4 >> (8 * k)) & 0xFF), cb, cr, px + 3 * k);
+    }
+    uint8_t *o = dst + ((size_t)y * in.width + x0) * 3;
+    if (npx == 4) {
+        uint32_t w[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) w[j] = px[4 * j] | (px[4 * j + 1] << 8) | (px[4 * j + 2] << 16) | ((uint32_t)px[4 * j + 3] << 24);
+        __builtin_memcpy(o, w, 12);                                       // any alignment (rows of 3*width bytes)
+    } else {
+        for (int k = 0; k < 3 * npx; ++k) o[k] = px[k];
     }
 }
 

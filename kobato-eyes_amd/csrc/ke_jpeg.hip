@@ -305,13 +305,11 @@ __global__ __launch_bounds__(256) void ke_jpeg_colour(const KeJpegDev *__restric
     }
     const uint8_t *Cb = planes + d.plane_off[1], *Cr = planes + d.plane_off[2];
     uint8_t px[12];
+    int cb[4], cr[4];
+    ke_upsample4(Cb, in.plane_w[1], in.comp_w[1], in.comp_h[1], in.hmax, in.vmax, x0, y, cb);
+    ke_upsample4(Cr, in.plane_w[2], in.comp_w[2], in.comp_h[2], in.hmax, in.vmax, x0, y, cr);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int x = min(x0 + k, in.width - 1);
-        const int cb = ke_upsample_at(Cb, in.plane_w[1], in.comp_w[1], in.comp_h[1], in.hmax, in.vmax, x, y);
-        const int cr = ke_upsample_at(Cr, in.plane_w[2], in.comp_w[2], in.comp_h[2], in.hmax, in.vmax, x, y);
-        ke_ycc_to_rgb((int)((y4 >> (8 * k)) & 0xFF), cb, cr, px + 3 * k);
-    }
+    for (int k = 0; k < 4; ++k) ke_ycc_to_rgb((int)((y4 >> (8 * k)) & 0xFF), cb[k], cr[k], px + 3 * k);
     uint8_t *o = dst + ((size_t)y * in.width + x0) * 3;
     if (npx == 4) {
         uint32_t w[3];
@@ -331,7 +329,7 @@ KE_API int ke_jpeg_probe(const uint8_t *files, const uint64_t *offsets, const ui
     KeJpegTables tables;
     for (int64_t i = 0; i < n; ++i) {
         KeJpegInfo info;
-        ke_parse_jpeg(files + offsets[i], (size_t)sizes[i], tables, info);
+        ke_parse_jpeg(files + offsets[i], (size_t)sizes[i], tables, info, false);     // headers only
         widths[i] = info.width; heights[i] = info.height; channels[i] = info.ncomp;
         status_out[i] = info.status;
         if (tables.pool.size() > 64) { tables.pool.clear(); tables.keys.clear(); }

@@ -292,6 +292,48 @@ KE_HD int ke_upsample_at(const uint8_t *plane, int pw, int cw, int ch, int hfac,
     return (cur * 3 + (in0[i + 1] * 3 + in1[i + 1]) + 7) >> 4;
 }
 
+// The same for the four output samples x0 .. x0+3 of row y at once (x0 a multiple of 4): the chroma neighbourhood is read
+// once.  Must equal ke_upsample_at sample by sample (oracle/keyes_jpeg_cpu.cpp checks it).
+KE_HD void ke_upsample4(const uint8_t *plane, int pw, int cw, int ch, int hfac, int vfac, int x0, int y, int *out) {
+    if (hfac == 1) {
+        const uint8_t *row = plane + (long)y * pw + x0;      // vfac is 1 too (the parser admits 1x1, 2x1, 2x2)
+        for (int k = 0; k < 4; ++k) out[k] = row[k];
+        return;
+    }
+    const int i0 = x0 >> 1;
+    if (cw <= 2) {
+        const uint8_t *row = plane + (long)(y / vfac) * pw;
+        out[0] = out[1] = row[i0];
+        out[2] = out[3] = row[i0 + 1];                        // columns beyond the image: the padded plane holds them, unused
+        return;
+    }
+    const int r0 = vfac == 2 ? (y >> 1) : y;
+    int r1 = r0;
+    if (vfac == 2) {
+        r1 = (y & 1) ? r0 + 1 : r0 - 1;
+        r1 = r1 < 0 ? 0 : (r1 > ch - 1 ? ch - 1 : r1);
+    }
+    const uint8_t *in0 = plane + (long)r0 * pw, *in1 = plane + (long)r1 * pw;
+    int c[4];
+    for (int j = 0; j < 4; ++j) {
+        int col = i0 - 1 + j;
+        col = col < 0 ? 0 : (col > cw - 1 ? cw - 1 : col);
+        c[j] = vfac == 2 ? in0[col] * 3 + in1[col] : in0[col];
+    }
+    const bool first = i0 == 0, last0 = i0 == cw - 1, last1 = i0 + 1 >= cw - 1;
+    if (vfac == 2) {
+        out[0] = first ? (c[1] * 4 + 8) >> 4 : (c[1] * 3 + c[0] + 8) >> 4;
+        out[1] = last0 ? (c[1] * 4 + 7) >> 4 : (c[1] * 3 + c[2] + 7) >> 4;
+        out[2] = (c[2] * 3 + c[1] + 8) >> 4;
+        out[3] = last1 ? (c[2] * 4 + 7) >> 4 : (c[2] * 3 + c[3] + 7) >> 4;
+    } else {
+        out[0] = first ? c[1] : (c[1] * 3 + c[0] + 1) >> 2;
+        out[1] = last0 ? c[1] : (c[1] * 3 + c[2] + 2) >> 2;
+        out[2] = (c[2] * 3 + c[1] + 1) >> 2;
+        out[3] = last1 ? c[2] : (c[2] * 3 + c[3] + 2) >> 2;
+    }
+}
+
 // ---- jdcolor.c ycc_rgb_convert for one pixel
 KE_HD void ke_ycc_to_rgb(int y, int cb, int cr, uint8_t *rgb) {
     const int xb = cb - 128, xr = cr - 128;

@@ -57,7 +57,8 @@ struct KeJpegTables {            // the batch's pool of distinct Huffman tables 
     }
 };
 
-static inline void ke_parse_jpeg(const uint8_t *p, size_t size, KeJpegTables &tables, KeJpegInfo &info) {
+// find_end = false: headers only (probing sizes); the end of the entropy-coded segment is then left unset
+static inline void ke_parse_jpeg(const uint8_t *p, size_t size, KeJpegTables &tables, KeJpegInfo &info, bool find_end = true) {
     std::memset(&info, 0, sizeof info);
     info.status = KE_JPEG_UNSUPPORTED;
     if (size < 4 || p[0] != 0xFF || p[1] != 0xD8) { info.status = KE_JPEG_CORRUPT; return; }
@@ -169,11 +170,15 @@ static inline void ke_parse_jpeg(const uint8_t *p, size_t size, KeJpegTables &ta
             }
             if ((uint64_t)info.width * info.height > (1ull << 28)) return;
             info.scan_offset = (uint32_t)(pos + len);
-            // the entropy-coded segment runs to the next marker that is not RSTn (normally EOI)
+            if (!find_end) { info.scan_end = (uint32_t)size; info.status = KE_JPEG_OK; return; }
+            // the entropy-coded segment runs to the next marker that is not RSTn (normally EOI); 0xFF bytes are rare in it
             size_t e = pos + len;
             while (e + 1 < size) {
-                if (p[e] == 0xFF && p[e + 1] != 0 && !(p[e + 1] >= 0xD0 && p[e + 1] <= 0xD7)) break;
-                ++e;
+                const void *hit = std::memchr(p + e, 0xFF, size - 1 - e);
+                if (!hit) { e = size; break; }
+                e = (size_t)((const uint8_t *)hit - p);
+                if (p[e + 1] != 0 && !(p[e + 1] >= 0xD0 && p[e + 1] <= 0xD7)) break;
+                e += 2;
             }
             if (e + 1 >= size) { info.status = KE_JPEG_CORRUPT; return; }      // no EOI: truncated, Pillow raises
             if (p[e + 1] != 0xD9) return;                    // another scan or table follows: not a single-scan file

@@ -60,4 +60,27 @@ int ko_jpeg_decode(const uint8_t *file, uint64_t size, uint8_t *out) {
     return KE_JPEG_OK;
 }
 
+// ke_upsample4 (what the colour kernel calls) against ke_upsample_at (what the decode above calls) on random planes of every
+// geometry: 0 = equal everywhere
+int ko_jpeg_upsample_selftest(void) {
+    uint32_t rng = 12345;
+    for (int cw = 1; cw <= 21; ++cw)
+        for (int ch = 1; ch <= 9; ++ch)
+            for (int mode = 0; mode < 3; ++mode) {
+                const int hf = mode ? 2 : 1, vf = mode == 2 ? 2 : 1;
+                const int pw = ((cw + 7) / 8) * 8 + 8;
+                std::vector<uint8_t> plane((size_t)pw * (ch + 8));
+                for (auto &v : plane) { rng = rng * 1664525u + 1013904223u; v = (uint8_t)(rng >> 24); }
+                const int W = cw * hf, H = ch * vf;                  // (odd image sizes only drop the last column / row)
+                for (int y = 0; y < H; ++y)
+                    for (int x0 = 0; x0 < W; x0 += 4) {
+                        int got[4];
+                        ke_upsample4(plane.data(), pw, cw, ch, hf, vf, x0, y, got);
+                        for (int k = 0; k < 4 && x0 + k < W; ++k)
+                            if (got[k] != ke_upsample_at(plane.data(), pw, cw, ch, hf, vf, x0 + k, y)) return 1 + cw * 1000 + ch * 10 + mode;
+                    }
+            }
+    return 0;
+}
+
 }  // extern "C"

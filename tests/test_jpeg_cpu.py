@@ -48,3 +48,9 @@ def test_files_outside_the_decoder_are_refused():
     for name, data, expected in J.refused():
         st, _ = _decode(L, data)
         assert st == expected, name
+
+
+def test_quad_upsampler_equals_the_per_sample_one():
+    """ke_upsample4 (the colour kernel's) == ke_upsample_at (the one held against Pillow above) for every component width 1..21,
+    height 1..9 and sampling 1x1 / 2x1 / 2x2."""
+    assert _lib().ko_jpeg_upsample_selftest() == 0

@@ -155,6 +155,16 @@ int ke_jpeg_probe(const uint8_t *files, const uint64_t *offsets, const uint64_t 
 int ke_jpeg_decode(ke_ctx *ctx, const uint8_t *files, const uint64_t *offsets, const uint64_t *sizes, int64_t n,
                    uint8_t *pixels_out, const uint64_t *out_offsets, int32_t *status_out);
 
+/* ---- PNG decode on the GPU: the same step for PNG files with 8-bit grayscale ("L"), RGB or RGBA pixels and no interlacing;
+ * zlib/deflate and the five scanline filters, one thread per image for each of the two (both are sequential per image).
+ * Lossless, hence the pixels of Image.open by construction; chunk CRCs and the Adler-32 of the data are verified as Pillow /
+ * zlib do.  Palette, 16-bit, sub-byte, gray+alpha, interlaced and animated files: KE_JPEG_UNSUPPORTED_ (1) per file, damaged
+ * ones KE_JPEG_CORRUPT_ (2).  Arguments and conventions as ke_jpeg_probe / ke_jpeg_decode; channels is 1, 3 or 4. */
+int ke_png_probe(const uint8_t *files, const uint64_t *offsets, const uint64_t *sizes, int64_t n, int32_t *widths,
+                 int32_t *heights, int32_t *channels, int32_t *status_out);
+int ke_png_decode(ke_ctx *ctx, const uint8_t *files, const uint64_t *offsets, const uint64_t *sizes, int64_t n,
+                  uint8_t *pixels_out, const uint64_t *out_offsets, int32_t *status_out);
+
 /* Debug/parity hook: the resampled luma tiles the hashes are computed from
  * (reference sig.phash._to_grayscale, src/sig/phash.py:21-26).  tile32_out: n*1024 bytes
  * ([y][x]); tile98_out: n*72 bytes (8 rows x 9 columns); either may be NULL. */
@@ -285,7 +295,7 @@ int ke_synth_hashes(ke_ctx *ctx, uint64_t seed, int64_t n, uint64_t *hashes_out)
 
 /* ---- timing hook for bench.py: wall time of the kernels enqueued by the LAST call of the
  * named kind on this context, measured with hipEvents on the context's stream.
- * kind: 0 = hash kernel(s), 1 = scan kernel, 2 = ssim kernel, 3 = synth kernel, 4 = JPEG decode kernels.
+ * kind: 0 = hash kernel(s), 1 = scan kernel, 2 = ssim kernel, 3 = synth kernel, 4 = JPEG / PNG decode kernels.
  * Returns milliseconds, or a negative value if nothing was recorded.  Blocks until done. */
 double ke_last_kernel_ms(ke_ctx *ctx, int32_t kind);
 

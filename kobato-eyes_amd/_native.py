@@ -28,7 +28,7 @@ EXPORTS = (
     "ke_hash_images", "ke_hash_uniform", "ke_hash_images_ex", "ke_hash_uniform_ex", "ke_luma_tiles_uniform", "ke_hamming_scan",
     "ke_stage_create", "ke_stage_destroy", "ke_stage_acquire", "ke_stage_submit_hash", "ke_stage_wait",
     "ke_comm_unique_id", "ke_comm_create", "ke_comm_destroy", "ke_allgather_u64", "ke_allgather_hashes", "ke_allgather_edges",
-    "ke_interleave_shards", "ke_jpeg_probe", "ke_jpeg_decode", "ke_cluster_labels", "ke_ssim_pairs_uniform", "ke_ssim_pairs", "ke_ssim_set_mode", "ke_resize_luma_uniform", "ke_fit_luma_uniform", "ke_tile_ahash", "ke_sad_pairs", "ke_synth_rgb",
+    "ke_interleave_shards", "ke_jpeg_probe", "ke_jpeg_decode", "ke_png_probe", "ke_png_decode", "ke_cluster_labels", "ke_ssim_pairs_uniform", "ke_ssim_pairs", "ke_ssim_set_mode", "ke_resize_luma_uniform", "ke_fit_luma_uniform", "ke_tile_ahash", "ke_sad_pairs", "ke_synth_rgb",
     "ke_synth_rgb_indexed",
     "ke_synth_hashes", "ke_last_kernel_ms",
 )
@@ -117,6 +117,8 @@ def load_library() -> C.CDLL:
         lib.ke_interleave_shards.argtypes = [vp, vp, i32, i64, vp]
         lib.ke_jpeg_probe.argtypes = [vp, vp, vp, i64, vp, vp, vp, vp]
         lib.ke_jpeg_decode.argtypes = [vp, vp, vp, vp, i64, vp, vp, vp]
+        lib.ke_png_probe.argtypes = [vp, vp, vp, i64, vp, vp, vp, vp]
+        lib.ke_png_decode.argtypes = [vp, vp, vp, vp, i64, vp, vp, vp]
         lib.ke_hamming_scan.argtypes = [vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, dbl, i64, vp, i64,
                                         C.POINTER(i64), vp]
         lib.ke_cluster_labels.argtypes = [vp, i64, i64, vp]
@@ -136,7 +138,7 @@ def load_library() -> C.CDLL:
                      "ke_hash_images", "ke_hash_uniform", "ke_hash_images_ex", "ke_hash_uniform_ex", "ke_luma_tiles_uniform", "ke_hamming_scan",
                      "ke_stage_create", "ke_stage_destroy", "ke_stage_acquire", "ke_stage_submit_hash", "ke_stage_wait",
                      "ke_comm_unique_id", "ke_comm_create", "ke_comm_destroy", "ke_allgather_u64", "ke_allgather_hashes", "ke_allgather_edges",
-                     "ke_interleave_shards", "ke_jpeg_probe", "ke_jpeg_decode", "ke_cluster_labels", "ke_ssim_pairs_uniform", "ke_ssim_pairs", "ke_ssim_set_mode", "ke_resize_luma_uniform", "ke_fit_luma_uniform", "ke_tile_ahash",
+                     "ke_interleave_shards", "ke_jpeg_probe", "ke_jpeg_decode", "ke_png_probe", "ke_png_decode", "ke_cluster_labels", "ke_ssim_pairs_uniform", "ke_ssim_pairs", "ke_ssim_set_mode", "ke_resize_luma_uniform", "ke_fit_luma_uniform", "ke_tile_ahash",
                      "ke_sad_pairs", "ke_synth_rgb", "ke_synth_rgb_indexed", "ke_synth_hashes"):
             getattr(lib, name).restype = C.c_int
         _lib = lib
@@ -350,25 +352,36 @@ class Context:
         flat = np.frombuffer(b"".join(blobs) + bytes(64), np.uint8)     # one C-level copy; the decoder takes any alignment
         return flat, offsets, sizes
 
-    def jpeg_probe(self, blobs):
-        """(widths, heights, channels, status) of JPEG files given as bytes; status 0 = the GPU decoder takes the file."""
+    def jpeg_probe(self, blobs, kind: str = "jpeg"):
+        """(widths, heights, channels, status) of JPEG (or, kind="png", PNG) files given as bytes; status 0 = the GPU
+        decoder takes the file."""
         flat, offsets, sizes = self._pack_blobs(blobs)
         n = len(blobs)
         w, h, c, st = (np.zeros(n, np.int32) for _ in range(4))
-        rc = self._lib.ke_jpeg_probe(_addr(flat), _addr(offsets), _addr(sizes), n, _addr(w), _addr(h), _addr(c), _addr(st))
+        rc = getattr(self._lib, f"ke_{kind}_probe")(_addr(flat), _addr(offsets), _addr(sizes), n, _addr(w), _addr(h), _addr(c), _addr(st))
         if rc != KE_OK:
-            raise ValueError("ke_jpeg_probe: bad arguments")
+            raise ValueError(f"ke_{kind}_probe: bad arguments")
         return w, h, c, st
 
-    def _jpeg_to_device(self, blobs):
+    def png_probe(self, blobs):
+        return self.jpeg_probe(blobs, "png")
+
+    def png_decode(self, blobs):
+        """Pixels of PNG files decoded on the GPU (HxW, HxWx3 or HxWx4), None where the decoder refused the file."""
+        return self.jpeg_decode(blobs, "png")
+
+    def png_hash(self, blobs, *, want_dhash=True):
+        return self.jpeg_hash(blobs, want_dhash=want_dhash, kind="png")
+
+    def _jpeg_to_device(self, blobs, kind: str = "jpeg"):
         """Decode what the GPU decoder takes into a device buffer: (device ptr or 0, byte offsets, widths, heights, channels,
         status).  The caller frees the buffer."""
         flat, offsets, sizes = self._pack_blobs(blobs)
         n = len(blobs)
         w, h, c, st = (np.zeros(n, np.int32) for _ in range(4))
-        rc = self._lib.ke_jpeg_probe(_addr(flat), _addr(offsets), _addr(sizes), n, _addr(w), _addr(h), _addr(c), _addr(st))
+        rc = getattr(self._lib, f"ke_{kind}_probe")(_addr(flat), _addr(offsets), _addr(sizes), n, _addr(w), _addr(h), _addr(c), _addr(st))
         if rc != KE_OK:
-            raise ValueError("ke_jpeg_probe: bad arguments")
+            raise ValueError(f"ke_{kind}_probe: bad arguments")
         nbytes = np.where(st == 0, w.astype(np.int64) * h * c, 0)
         padded = (nbytes + 15) & ~np.int64(15)
         out_off = np.zeros(n, np.uint64)
@@ -379,22 +392,22 @@ class Context:
         dev = self.malloc(total + 64)
         try:
             with self._lock:
-                self._check(self._lib.ke_jpeg_decode(self._h, _addr(flat), _addr(offsets), _addr(sizes), n, dev, _addr(out_off), _addr(st)),
-                            "ke_jpeg_decode")
+                self._check(getattr(self._lib, f"ke_{kind}_decode")(self._h, _addr(flat), _addr(offsets), _addr(sizes), n, dev,
+                                                                    _addr(out_off), _addr(st)), f"ke_{kind}_decode")
         except Exception:
             self.free(dev)
             raise
         return dev, out_off, w, h, c, st
 
-    def jpeg_decode(self, blobs):
+    def jpeg_decode(self, blobs, kind: str = "jpeg"):
         """Pixels of JPEG files decoded on the GPU: list of ndarrays (HxW or HxWx3, what np.asarray(Image.open(f)) gives) with
         None where the decoder refused the file (status != 0); also returns the statuses."""
-        dev, out_off, w, h, c, st = self._jpeg_to_device(blobs)
+        dev, out_off, w, h, c, st = self._jpeg_to_device(blobs, kind)
         out = [None] * len(blobs)
         try:
             for i in range(len(blobs)):
                 if st[i] == 0:
-                    arr = np.empty((h[i], w[i], 3) if c[i] == 3 else (h[i], w[i]), np.uint8)
+                    arr = np.empty((h[i], w[i], c[i]) if c[i] > 1 else (h[i], w[i]), np.uint8)
                     self.memcpy(arr, dev + int(out_off[i]), arr.nbytes)
                     out[i] = arr
         finally:
@@ -402,7 +415,7 @@ class Context:
                 self.free(dev)
         return out, st
 
-    def jpeg_hash(self, blobs, *, want_dhash=True):
+    def jpeg_hash(self, blobs, *, want_dhash=True, kind: str = "jpeg"):
         """pHash / dHash of JPEG files, decoded and hashed without the pixels leaving the GPU.  Returns (phash u64[n],
         dhash u64[n] | None, status int32[n]); status != 0 = not handled here (decode the file with Pillow)."""
         n = len(blobs)
@@ -410,9 +423,9 @@ class Context:
         dh = np.zeros(n, np.uint64) if want_dhash else None
         if n == 0:
             return ph, dh, np.zeros(0, np.int32)
-        dev, out_off, w, h, c, st = self._jpeg_to_device(blobs)
+        dev, out_off, w, h, c, st = self._jpeg_to_device(blobs, kind)
         try:
-            for ch in (1, 3):
+            for ch in (1, 3, 4):
                 idx = np.nonzero((st == 0) & (c == ch))[0]
                 if len(idx) == 0:
                     continue

@@ -54,6 +54,7 @@ def _read_pixels(path_text: str):
 
 
 JPEG_SUFFIXES = (".jpg", ".jpeg", ".jpe", ".jfif")
+PNG_SUFFIXES = (".png",)
 
 
 def _read_bytes(path_text: str):
@@ -86,10 +87,10 @@ class _GpuStage:
     def wait(self, slot: int) -> None:
         self.ctx.stage_wait(slot)
 
-    def jpeg_hash(self, blobs):
-        """(phash, dhash, status) of JPEG files decoded on the GPU (``ke_jpeg_decode`` -> ``ke_hash_images``); status != 0:
-        the decoder leaves the file to Pillow."""
-        return self.ctx.jpeg_hash(blobs, want_dhash=True)
+    def jpeg_hash(self, blobs, kind: str = "jpeg"):
+        """(phash, dhash, status) of JPEG / PNG files decoded on the GPU (``ke_jpeg_decode`` / ``ke_png_decode`` ->
+        ``ke_hash_images``); status != 0: the decoder leaves the file to Pillow."""
+        return self.ctx.jpeg_hash(blobs, want_dhash=True, kind=kind)
 
     def hash_one(self, arr):
         """(phash, dhash) or None for an image that did not fit a staging buffer."""
@@ -109,10 +110,11 @@ class _Pipeline:
     the other buffer while chunk k crosses PCIe and is hashed.  An image that does not fit what is left of a buffer is
     hashed on its own through ``ke_hash_images``.
 
-    JPEG files (by suffix) skip Pillow altogether: the threads only read the bytes, ``ke_jpeg_decode`` decodes the chunk's
-    files on the GPU -- pixel-identical to ``Image.open`` for baseline JPEGs -- and the hash kernels run on the decoded
-    pixels where they lie.  Files the decoder refuses (progressive, CMYK, damaged ...) take the Pillow route after all.
-    ``KE_GPU_JPEG=0`` turns the route off.
+    JPEG and PNG files (by suffix) skip Pillow altogether: the threads only read the bytes, ``ke_jpeg_decode`` /
+    ``ke_png_decode`` decode the chunk's files on the GPU -- pixel-identical to ``Image.open`` for baseline JPEGs and for 8-bit
+    L / RGB / RGBA PNGs -- and the hash kernels run on the decoded pixels where they lie.  Files the decoders refuse
+    (progressive, CMYK, palette, 16-bit, damaged ...) take the Pillow route after all.  ``KE_GPU_JPEG=0`` / ``KE_GPU_PNG=0``
+    turn the routes off.
     """
 
     def __init__(self, tasks: Sequence[Task], workers: int, chunk: int, device: int) -> None:
@@ -140,10 +142,14 @@ class _Pipeline:
         slot, view = self.stage.acquire()
         alloc = {"lock": threading.Lock(), "cursor": 0}
         gpu_jpeg = os.environ.get("KE_GPU_JPEG", "1") != "0"
+        gpu_png = os.environ.get("KE_GPU_PNG", "1") != "0"
         futures = []
         for _, p in self.tasks[start:start + self.chunk]:
-            if gpu_jpeg and str(p).lower().endswith(JPEG_SUFFIXES):
+            low = str(p).lower()
+            if gpu_jpeg and low.endswith(JPEG_SUFFIXES):
                 futures.append(("jpeg", p, self.pool.submit(_read_bytes, p)))
+            elif gpu_png and low.endswith(PNG_SUFFIXES):
+                futures.append(("png", p, self.pool.submit(_read_bytes, p)))
             else:
                 futures.append(("pixels", p, self.pool.submit(self._decode_into, p, view, alloc)))
         return slot, (futures, view, alloc)
@@ -151,18 +157,20 @@ class _Pipeline:
     def _submit(self, slot: int, started):
         futures, view, alloc = started
         decoded: list = [None] * len(futures)
-        jpeg_pos, blobs = [], []
+        coded: dict = {"jpeg": ([], []), "png": ([], [])}
         for k, (kind, _, fut) in enumerate(futures):
             res = fut.result()
             if kind == "pixels":
                 decoded[k] = res
             elif res is not None:
-                jpeg_pos.append(k)
-                blobs.append(res)
+                coded[kind][0].append(k)
+                coded[kind][1].append(res)
         jpeg_done = {}
-        if blobs:
-            ph, dh, st = self.stage.jpeg_hash(blobs)
-            for k, p, d, code in zip(jpeg_pos, ph.tolist(), dh.tolist(), st.tolist()):
+        for kind, (positions, blobs) in coded.items():
+            if not blobs:
+                continue
+            ph, dh, st = self.stage.jpeg_hash(blobs, kind)
+            for k, p, d, code in zip(positions, ph.tolist(), dh.tolist(), st.tolist()):
                 if code == 0:
                     jpeg_done[k] = (p, d)
                 else:                                  # outside the GPU decoder: Pillow decodes it, as the reference does

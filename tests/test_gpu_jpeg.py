@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 import _jpeg_cases as J
+import _png_cases as P
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -111,3 +112,22 @@ def test_fast_fill_takes_the_gpu_route_for_jpeg_files(tmp_path, monkeypatch):
     assert [r[0] for r in rows] == sorted(expect)
     for fid, ph, dh in rows:
         assert (ph, dh) == tuple(O.to_signed64(v) for v in expect[fid]), fid
+
+
+def test_png_decode_matches_pillow_in_one_mixed_batch(ctx):
+    """ke_png_decode: 8-bit L / RGB / RGBA files of every compression level in one call -- stored, fixed and dynamic deflate
+    blocks, all five filters -- equal to Pillow's pixels; palette / 16-bit / gray+alpha / damaged files reported per file."""
+    cases = list(P.supported(full=True))
+    refused = list(P.refused())
+    blobs = [c[1] for c in cases] + [r[1] for r in refused]
+    out, status = ctx.png_decode(blobs)
+    for k, (name, _, ref) in enumerate(cases):
+        assert status[k] == 0, name
+        assert out[k].shape == ref.shape and np.array_equal(out[k], ref), name
+    for k, (name, _, expected) in enumerate(refused, len(cases)):
+        assert status[k] == expected and out[k] is None, name
+    assert len(cases) > 300
+    ph, dh, st = ctx.png_hash([c[1] for c in cases if min(c[2].shape[:2]) >= 16][:60])
+    refs = [c[2] for c in cases if min(c[2].shape[:2]) >= 16][:60]
+    for k, ref in enumerate(refs):
+        assert st[k] == 0 and (int(ph[k]), int(dh[k])) == O.hash_image(ref), k

@@ -1,0 +1,3 @@
+import sqlite3,sys
+c=sqlite3.connect(sys.argv[1])
+for r in c.execute("select name, count(*), sum(end-start), avg(end-start) from kernels group by name order by 3 desc limit 8"): print(r[0][:70].replace("(anonymous namespace)::",""), r[1], round(r[2]/1e6,2), round(r[3]/1e6,3))

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--side", type=int, default=512)
     ap.add_argument("--quality", type=int, default=85)
     ap.add_argument("--subsampling", type=int, default=2)
+    ap.add_argument("--format", choices=["jpeg", "png"], default="jpeg")
     args = ap.parse_args()
     from PIL import Image
 
@@ -36,15 +37,18 @@ def main():
     files = []
     for k in range(distinct):
         b = io.BytesIO()
-        Image.fromarray(px[k]).save(b, "JPEG", quality=args.quality, subsampling=args.subsampling)
+        if args.format == "png":
+            Image.fromarray(px[k]).save(b, "PNG")
+        else:
+            Image.fromarray(px[k]).save(b, "JPEG", quality=args.quality, subsampling=args.subsampling)
         files.append(b.getvalue())
     blobs = [files[k % distinct] for k in range(args.images)]
     comp_bytes = sum(len(b) for b in blobs)
-    ctx.jpeg_hash(blobs[:512])                                   # warm-up: allocations, tables
+    ctx.jpeg_hash(blobs[:512], kind=args.format)                 # warm-up: allocations, tables
     t_wall, t_kern = [], []
     for _ in range(3):
         t0 = time.perf_counter()
-        ph, dh, st = ctx.jpeg_hash(blobs, want_dhash=False)
+        ph, dh, st = ctx.jpeg_hash(blobs, want_dhash=False, kind=args.format)
         t_wall.append(time.perf_counter() - t0)
         t_kern.append(ctx.last_kernel_ms(4))
     assert (st == 0).all()
@@ -66,7 +70,7 @@ def main():
         list(ex.map(dec, sample, chunksize=8))
     t_cpu = time.perf_counter() - t0
     wall, kern = float(np.median(t_wall)), float(np.median(t_kern))
-    print(json.dumps({"case": "jpeg_decode", "images": args.images, "side": args.side, "quality": args.quality,
+    print(json.dumps({"case": args.format + "_decode", "images": args.images, "side": args.side, "quality": args.quality,
                       "subsampling": ["4:4:4", "4:2:2", "4:2:0"][args.subsampling], "compressed_mb": comp_bytes / 1e6,
                       "decode_kernels_ms": kern, "decode_images_per_s": args.images / (kern * 1e-3),
                       "decode_plus_hash_wall_ms": wall * 1e3, "decode_plus_hash_images_per_s": args.images / wall,

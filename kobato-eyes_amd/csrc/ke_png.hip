@@ -3,11 +3,17 @@
 // (src/core/fastsig.py:31-34) for the files it takes; the format is lossless, so the pixels are Pillow's by construction of
 // the two specifications followed in ke_png_core.h (zlib/deflate, the five scanline filters).
 //
-// Deflate is one sequential bit stream per image and the filters chain every byte to its left and upper neighbours, so, as
-// for JPEG, the parallelism is across the batch: ONE THREAD PER IMAGE inflates (canonical Huffman tables and a stream window in
-// LDS, output and LZ77 back-references in HBM), a second kernel -- again one thread per image -- undoes the filters row by
-// row.  Sequential work per image is ~25x that of a JPEG of the same size (every byte is a symbol), which bounds the rate;
-// it still beats the host cores by an order of magnitude once thousands of files are in flight.
+//   ke_png_gather    the IDAT payloads of every file -> one contiguous, 16-byte aligned zlib stream per image
+//   ke_png_inflate   ONE THREAD PER IMAGE walks the bit stream (it is sequential by construction).  Canonical-code decoding by
+//                    comparison: the 15 limits and bases of both codes sit in registers, the symbols in code order in 424 bytes
+//                    of LDS per lane next to a 64-byte ring of stream bytes that is topped up at wave-uniform moments.
+//                    Literals are written to their final place; an LZ77 copy is only recorded.  The kernel never waits for
+//                    memory inside the symbol loop: a wait by one lane would stall the other 63.
+//   ke_png_matches   ONE WAVE PER IMAGE makes the recorded copies, 64 per round, each as soon as the bytes it reads are final.
+//   ke_png_unfilter  ONE WAVE PER IMAGE: a pixel needs its left, upper and upper-left neighbours, so lane l takes rows
+//                    l, l + 64, ... and runs one group of four pixels behind lane l - 1; the row above arrives by a lane shift
+//                    (lane 63 -> lane 0 through an LDS row).  The same pass sums the Adler-32 of the filtered bytes by rows
+//                    and holds it against the stream's trailer.
 #include <algorithm>
 
 #include "ke_internal.h"
@@ -15,75 +21,420 @@
 
 namespace {
 
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
 struct KePngDev {
     KePngInfo info;
     uint64_t raw_off;      // filtered scanlines (height * (1 + width * channels) bytes) inside the scratch
+    uint64_t rec_off;      // this image's LZ77 copy records (8 bytes each; at most one per 3 output bytes)
     uint64_t out_off;      // bytes into the caller's pixel buffer
 };
 
-constexpr int kPngWin = 64, kPngWinPitch = kPngWin + 4;
+struct KePngPiece {        // part of one IDAT payload: bytes [src, src + len) of the uploaded files -> [dst, dst + len) of the streams
+    uint64_t src, dst;
+    uint32_t len, pad;
+};
 
-struct LdsStream {         // the compressed bytes through a 64-byte window per lane in LDS
-    const uint8_t *z;      // global: this image's zlib stream
-    uint8_t *win;
-    uint32_t win_pos;
-    __device__ __forceinline__ void load(uint32_t pos) {
-        win_pos = pos & ~3u;
-        const uint8_t *src = z + win_pos;
-#pragma unroll
-        for (int k = 0; k < kPngWin / 4; ++k) {
-            uint32_t w;
-            __builtin_memcpy(&w, src + 4 * k, 4);
-            reinterpret_cast<uint32_t *>(win)[k] = w;
+constexpr int kWorkBytes = 160;       // per image in HBM: the code lengths of the block header being read, 8 per dword
+constexpr uint32_t kPieceBytes = 1u << 18;
+
+__device__ __forceinline__ u32x4 ld16(const uint8_t *p) {       // any alignment
+    u32x4 v;
+    __builtin_memcpy(&v, p, 16);
+    return v;
+}
+__device__ __forceinline__ void st16(uint8_t *p, u32x4 v) { __builtin_memcpy(p, &v, 16); }
+
+__global__ __launch_bounds__(256) void ke_png_gather(const KePngPiece *__restrict__ pieces, const uint8_t *__restrict__ files,
+                                                     uint8_t *__restrict__ streams) {
+    const KePngPiece pc = pieces[blockIdx.x];
+    const uint8_t *src = files + pc.src;
+    uint8_t *dst = streams + pc.dst;
+    const uint32_t head = (uint32_t)((16 - (pc.dst & 15)) & 15);      // bytes up to the first aligned 16 of the destination
+    if (threadIdx.x < head && threadIdx.x < pc.len) dst[threadIdx.x] = src[threadIdx.x];
+    if (pc.len <= head) return;
+    const uint32_t body = (pc.len - head) >> 4, tail0 = head + (body << 4);
+    for (uint32_t k = threadIdx.x; k < body; k += 256) *reinterpret_cast<u32x4 *>(dst + head + 16 * k) = ld16(src + head + 16 * k);
+    if (tail0 + threadIdx.x < pc.len) dst[tail0 + threadIdx.x] = src[tail0 + threadIdx.x];
+}
+
+// ---- inflate: the three policies of ke_inflate_zlib on the GPU
+
+// The compressed bytes through a 64-byte ring per lane in LDS.  Waiting for a load stalls all 64 lanes, so inside the symbol
+// loop the ring is topped up at wave-uniform moments (every 16th symbol): what was asked for 16 symbols ago is written to the
+// ring, what has been consumed since is asked for, and nobody waits for memory that is still on its way.  Outside that loop
+// (headers) and for a lane that outruns its ring the same two steps run back to back.
+struct LdsStream {
+    const u32x4 *z;        // global: this image's zlib stream (16-byte aligned)
+    uint32_t *win;         // dword j of the ring at win[64 * (j & 15)]
+    uint32_t nchunk;       // 16-byte chunks that hold stream data
+    uint32_t avail, req;   // dwords landed in the ring / asked for (multiples of 4, avail <= req <= avail + 16)
+    uint32_t t;
+    u32x4 nx0, nx1, nx2, nx3;
+    __device__ __forceinline__ void land1(int c, u32x4 v) {
+        if (avail + 4 * c < req) {
+            uint32_t *slot = win + 64 * ((avail + 4 * c) & 15);
+            slot[0] = v.x; slot[64] = v.y; slot[128] = v.z; slot[192] = v.w;
         }
     }
-    __device__ __forceinline__ uint32_t byte(uint32_t pos) {
-        if (pos - win_pos >= (uint32_t)kPngWin) load(pos);
-        return win[pos - win_pos];
+    __device__ __forceinline__ void land() {
+        land1(0, nx0); land1(1, nx1); land1(2, nx2); land1(3, nx3);
+        avail = req;
+    }
+    __device__ __forceinline__ void ask1(uint32_t limit, u32x4 &v) {
+        if (req + 4 <= limit) {
+            const uint32_t chunk = req >> 2;
+            v = chunk < nchunk ? z[chunk] : u32x4{0, 0, 0, 0};
+            req += 4;
+        }
+    }
+    __device__ __forceinline__ void ask(uint32_t next) {       // `next`: the reader's next dword; everything before its chunk is free
+        const uint32_t limit = (next & ~3u) + 16;
+        ask1(limit, nx0); ask1(limit, nx1); ask1(limit, nx2); ask1(limit, nx3);
+    }
+    __device__ __forceinline__ uint32_t word(uint32_t k) {
+        if (k >= avail) {
+            land();
+            if (k >= avail) { ask(k); land(); }
+        }
+        return win[64 * (k & 15)];
+    }
+    __device__ __forceinline__ void tick(uint32_t next) {
+        ++t;
+        if ((__builtin_amdgcn_readfirstlane(t) & 15) == 0) { land(); ask(next); }
     }
 };
 
-struct GlobalSink {        // decompressed bytes straight into HBM; back-references read them from there
+// Literals go to their final place in HBM (as whole dwords where the position allows); an LZ77 copy is only written down --
+// (destination, distance, length) -- and its bytes are left open: reading the source back here would stall the wave once per
+// match, so ke_png_matches fills the copies in afterwards with a whole wave per image.
+struct RecSink {
     uint8_t *p;
-    uint32_t n;
-    __device__ __forceinline__ void put(uint8_t b) { p[n++] = b; }
-    __device__ __forceinline__ uint32_t get(uint32_t dist) const { return p[n - dist]; }
+    uint32_t n, w, gathering;      // gathering: the bytes of the dword being filled are in w (else they went out singly)
+    uint2 *rec;
+    uint32_t nrec;
     __device__ __forceinline__ uint32_t size() const { return n; }
+    __device__ __forceinline__ void put(uint8_t b) {
+        if (gathering) {
+            w |= (uint32_t)b << (8 * (n & 3));
+            ++n;
+            if ((n & 3) == 0) { *reinterpret_cast<uint32_t *>(p + n - 4) = w; w = 0; }
+        } else {
+            p[n] = b;
+            ++n;
+            gathering = (n & 3) == 0;
+        }
+    }
+    // what has been gathered goes out with zeros behind it: those fall into the copy that follows (or the slack at the end)
+    __device__ __forceinline__ void settle() {
+        if (gathering && (n & 3)) *reinterpret_cast<uint32_t *>(p + (n & ~3u)) = w;
+        w = 0;
+    }
+    __device__ __forceinline__ void finish() { settle(); }
+    __device__ __forceinline__ void copy(uint32_t dist, uint32_t len) {
+        settle();
+        rec[nrec++] = make_uint2(n, (dist << 9) | (len - 3));
+        n += len;
+        gathering = (n & 3) == 0;
+    }
+};
+
+// eight table words held as named values (arrays indexed in loops end up in scratch memory before they are unrolled)
+struct Oct {
+    uint32_t a0, a1, a2, a3, a4, a5, a6, a7;
+    __device__ __forceinline__ uint32_t get(int k) const {
+        // each value through an empty asm: otherwise the selects below are folded into one load at a selected address and
+        // the table stays in scratch memory for good
+        uint32_t b0 = a0, b1 = a1, b2 = a2, b3 = a3, b4 = a4, b5 = a5, b6 = a6, b7 = a7;
+        asm("" : "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3), "+v"(b4), "+v"(b5), "+v"(b6), "+v"(b7));
+        uint32_t r = b0;
+        r = k == 1 ? b1 : r; r = k == 2 ? b2 : r; r = k == 3 ? b3 : r; r = k == 4 ? b4 : r;
+        r = k == 5 ? b5 : r; r = k == 6 ? b6 : r; r = k == 7 ? b7 : r;
+        return r;
+    }
+    __device__ __forceinline__ void set(int k, uint32_t v) {
+        a0 = k == 0 ? v : a0; a1 = k == 1 ? v : a1; a2 = k == 2 ? v : a2; a3 = k == 3 ? v : a3;
+        a4 = k == 4 ? v : a4; a5 = k == 5 ? v : a5; a6 = k == 6 ? v : a6; a7 = k == 7 ? v : a7;
+    }
+};
+
+struct LaneTab {           // limits and bases in registers, the symbols in this lane's slices of LDS, a header's code lengths in HBM
+    Oct lim0, lim1, base0, base1;
+    uint8_t *lsym_;        // low 8 bits of literal/length symbol i at lsym_[64 * i]
+    uint32_t *lhigh_;      // bit 8 of symbol i: bit (i & 31) of lhigh_[64 * (i >> 5)]
+    uint8_t *dsym_;        // distance symbol i at dsym_[64 * i]
+    uint32_t *nib_;
+    __device__ __forceinline__ uint32_t lim2(int which, int k) const { return which ? lim1.get(k) : lim0.get(k); }
+    __device__ __forceinline__ void set_lim2(int which, int k, uint32_t v) { if (which) lim1.set(k, v); else lim0.set(k, v); }
+    __device__ __forceinline__ uint32_t base2(int which, int k) const { return which ? base1.get(k) : base0.get(k); }
+    __device__ __forceinline__ void set_base2(int which, int k, uint32_t v) { if (which) base1.set(k, v); else base0.set(k, v); }
+    __device__ __forceinline__ uint32_t sym(int which, uint32_t i) const {
+        if (which) return dsym_[64 * (i & 31)];
+        i = i < 288 ? i : 0;
+        return (uint32_t)lsym_[64 * i] | (((lhigh_[64 * (i >> 5)] >> (i & 31)) & 1u) << 8);
+    }
+    __device__ __forceinline__ void clear_syms(int which) {
+        if (!which)
+            for (int k = 0; k < 9; ++k) lhigh_[64 * k] = 0;
+    }
+    __device__ __forceinline__ void set_sym(int which, uint32_t i, uint32_t s) {
+        if (which) { dsym_[64 * (i & 31)] = (uint8_t)s; return; }
+        i = i < 288 ? i : 0;
+        lsym_[64 * i] = (uint8_t)s;
+        if (s & 256u) lhigh_[64 * (i >> 5)] |= 1u << (i & 31);
+    }
+    __device__ __forceinline__ uint32_t nibword(int k) const { return nib_[k]; }
+    __device__ __forceinline__ void set_nibword(int k, uint32_t v) { nib_[k] = v; }
 };
 
 __global__ __launch_bounds__(64) void ke_png_inflate(const KePngDev *__restrict__ imgs, int64_t n, const uint8_t *__restrict__ streams,
-                                                     uint8_t *__restrict__ raw, uint8_t *__restrict__ work, int32_t *__restrict__ status) {
-    __shared__ KeInflateTables s_tab[64];
-    __shared__ __attribute__((aligned(16))) uint8_t s_win[64 * kPngWinPitch];
+                                                     uint8_t *__restrict__ raw, uint8_t *__restrict__ work, uint2 *__restrict__ records,
+                                                     int32_t *__restrict__ status, uint32_t *__restrict__ adler, uint32_t *__restrict__ nrec) {
+    __shared__ uint8_t s_lsym[288 * 64], s_dsym[32 * 64];
+    __shared__ uint32_t s_lhigh[9 * 64], s_win[16 * 64];
     const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
     if (i >= n) return;
     const KePngDev &d = imgs[i];
     LdsStream src;
-    src.z = streams + d.info.zoff;
-    src.win = s_win + threadIdx.x * kPngWinPitch;
-    src.load(0);
-    KeBitsLsb<LdsStream> bits{&src, 0, d.info.zlen, 0, 0, 0};
-    GlobalSink sink{raw + d.raw_off, 0};
+    src.z = reinterpret_cast<const u32x4 *>(streams + d.info.zoff);
+    src.win = s_win + threadIdx.x;
+    src.nchunk = (d.info.zlen + 15u) >> 4;
+    src.avail = src.req = src.t = 0;
+    KeBitsLsb<LdsStream> bits{&src, 0, 0, 0};
+    RecSink sink{raw + d.raw_off, 0, 0, 1, records + d.rec_off, 0};
+    LaneTab tab;
+    tab.lsym_ = s_lsym + threadIdx.x;
+    tab.lhigh_ = s_lhigh + threadIdx.x;
+    tab.dsym_ = s_dsym + threadIdx.x;
+    tab.nib_ = reinterpret_cast<uint32_t *>(work + (size_t)i * kWorkBytes);
+    tab.lim0 = tab.lim1 = tab.base0 = tab.base1 = Oct{0, 0, 0, 0, 0, 0, 0, 0};
     const uint32_t want = (uint32_t)(d.info.width * d.info.channels + 1) * (uint32_t)d.info.height;
-    int rc = ke_inflate_zlib(bits, sink, want, s_tab[threadIdx.x], work + (size_t)i * 352);
+    uint32_t trailer = 0;
+    int rc = ke_inflate_zlib(bits, sink, d.info.zlen, want, tab, &trailer);
     if (rc == KE_PNG_OK && sink.n != want) rc = KE_PNG_CORRUPT;
     status[i] = rc;
+    adler[i] = trailer;
+    nrec[i] = sink.nrec;
 }
 
-__global__ __launch_bounds__(64) void ke_png_unfilter(const KePngDev *__restrict__ imgs, int64_t n, const uint8_t *__restrict__ raw,
-                                                      uint8_t *__restrict__ out, int32_t *__restrict__ status) {
-    const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    if (i >= n || status[i] != KE_PNG_OK) return;
+// ---- the LZ77 copies, one wave per image, 64 at a time.  A copy can go as soon as the bytes it reads are final: everything
+// below the destination of the first copy not yet made is (literals are in place, earlier copies are done).  Copies of one
+// round read below that mark and write at or above it, so they do not touch each other; a copy that overlaps its own output
+// (distance < length) repeats its first `distance` bytes.  The first pending copy always qualifies, so every round makes
+// progress, and in the common case -- sources further back than the 64 copies span -- one round does all 64.
+
+__device__ __forceinline__ void store_low(uint8_t *d, uint64_t lo, uint64_t hi, uint32_t rem) {      // rem < 16 bytes of lo:hi
+    if (rem & 8) { __builtin_memcpy(d, &lo, 8); d += 8; lo = hi; }
+    if (rem & 4) { const uint32_t v = (uint32_t)lo; __builtin_memcpy(d, &v, 4); d += 4; lo >>= 32; }
+    if (rem & 2) { const uint16_t v = (uint16_t)lo; __builtin_memcpy(d, &v, 2); d += 2; lo >>= 16; }
+    if (rem & 1) *d = (uint8_t)lo;
+}
+
+__device__ __forceinline__ void copy_match(uint8_t *d, uint32_t dist, uint32_t len) {
+    const uint8_t *s = d - dist;
+    if (dist >= 16) {
+        if (len >= 16) {
+            uint32_t k = 0;
+            for (; k + 16 <= len; k += 16) st16(d + k, ld16(s + k));
+            if (k < len) st16(d + len - 16, ld16(s + len - 16));      // the last 16 bytes again, ending where the copy ends
+        } else {
+            const u32x4 v = ld16(s);
+            store_low(d, (uint64_t)v.x | ((uint64_t)v.y << 32), (uint64_t)v.z | ((uint64_t)v.w << 32), len);
+        }
+        return;
+    }
+    // the 16-byte pattern of period `dist`: keep the first dist bytes, double them up
+    const u32x4 v = ld16(s);
+    uint64_t lo = (uint64_t)v.x | ((uint64_t)v.y << 32), hi = (uint64_t)v.z | ((uint64_t)v.w << 32);
+    if (dist < 8) { lo &= (1ull << (8 * dist)) - 1ull; hi = 0; } else { hi &= (1ull << (8 * (dist - 8))) - 1ull; }
+    for (uint32_t q = dist; q < 16; q <<= 1) {
+        uint64_t nl, nh;
+        if (q < 8) { nh = (hi << (8 * q)) | (lo >> (64 - 8 * q)); nl = lo << (8 * q); } else { nh = lo << (8 * (q - 8)); nl = 0; }
+        lo |= nl;
+        hi |= nh;
+    }
+    const u32x4 pat{(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)};
+    // largest multiple of dist within 16, minus one, for dist 1..15: stepping by it keeps the pattern in phase
+    const uint32_t step = 1u + (uint32_t)((0xEDCBA98FDBEFEFFull >> (4 * (dist - 1))) & 15u);
+    uint32_t k = 0;
+    for (; k + 16 <= len; k += step) st16(d + k, pat);
+    store_low(d + k, lo, hi, len - k);
+}
+
+__global__ __launch_bounds__(64) void ke_png_matches(const KePngDev *__restrict__ imgs, uint8_t *__restrict__ raw,
+                                                     const uint2 *__restrict__ records, const int32_t *__restrict__ status,
+                                                     const uint32_t *__restrict__ nrec) {
+    const int64_t i = blockIdx.x;
+    if (status[i] != KE_PNG_OK) return;
     const KePngDev &d = imgs[i];
-    const int rb = d.info.width * d.info.channels, bpp = d.info.channels;
+    uint8_t *p = raw + d.raw_off;
+    const uint2 *rec = records + d.rec_off;
+    const uint32_t m = nrec[i];
+    for (uint32_t first = 0; first < m; first += 64) {
+        const uint32_t j = first + threadIdx.x;
+        bool pending = j < m;
+        uint32_t dst = 0, dist = 1, len = 3;
+        if (pending) {
+            const uint2 r = rec[j];
+            dst = r.x; dist = r.y >> 9; len = (r.y & 511u) + 3;
+        }
+        const uint32_t need = dst - dist + min(dist, len);      // end of the bytes read that this copy does not write itself
+        for (;;) {
+            const uint64_t waiting = __ballot(pending);
+            if (!waiting) break;
+            const uint32_t mark = (uint32_t)__shfl((int)dst, __ffsll((long long)waiting) - 1);
+            if (pending && need <= mark) {
+                copy_match(p + dst, dist, len);
+                pending = false;
+            }
+        }
+    }
+}
+
+// ---- unfilter
+
+template <int BPP>
+__device__ __forceinline__ uint32_t recon_pixel(uint32_t ft, uint32_t x, uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t o = 0;
+#pragma unroll
+    for (int ch = 0; ch < BPP; ++ch) {
+        const int xa = (int)((a >> (8 * ch)) & 255u), xb = (int)((b >> (8 * ch)) & 255u), xc = (int)((c >> (8 * ch)) & 255u);
+        o |= (uint32_t)ke_png_recon((int)ft, (int)((x >> (8 * ch)) & 255u), xa, xb, xc) << (8 * ch);
+    }
+    return o;
+}
+
+template <int BPP>
+__global__ __launch_bounds__(64) void ke_png_unfilter(const KePngDev *__restrict__ imgs, const uint8_t *__restrict__ raw,
+                                                      uint8_t *__restrict__ out, int32_t *__restrict__ status,
+                                                      const uint32_t *__restrict__ adler) {
+    extern __shared__ uint32_t s_row[];               // the pixels of lane 63's row, for lane 0's next one
+    const int64_t i = blockIdx.x;
+    const KePngDev &d = imgs[i];
+    if (d.info.channels != BPP || status[i] != KE_PNG_OK) return;
+    const int lane = threadIdx.x;
+    const int W = d.info.width, H = d.info.height;
+    const uint32_t rb = (uint32_t)W * BPP, stride = rb + 1;
+    const int groups = (W + 3) >> 2;                  // four pixels at a time
+    const int period = groups > 64 ? groups : 64;     // lane 0 starts its next row only after lane 63 has started the one above
+    const int rounds = (H + 63) >> 6;
     const uint8_t *src = raw + d.raw_off;
     uint8_t *dst = out + d.out_off;
-    for (int y = 0; y < d.info.height; ++y) {
-        const uint8_t *row = src + (size_t)y * (rb + 1);
-        if (ke_png_unfilter_row(row[0], row + 1, y ? dst + (size_t)(y - 1) * rb : nullptr, dst + (size_t)y * rb, rb, bpp) != KE_PNG_OK) {
-            status[i] = KE_PNG_CORRUPT;
-            return;
+    const uint64_t total = (uint64_t)stride * (uint64_t)H;
+    constexpr int kWords = BPP == 1 ? 1 : BPP;        // dwords of four pixels
+
+    int row = lane, g = -lane;                        // this step's group; g < 0: not started
+    uint32_t ft = 0, bad = 0;
+    uint32_t o[4] = {0, 0, 0, 0};                     // the four pixels of the previous step (what lane + 1 sees above)
+    uint32_t up3 = 0;                                 // upper-left of the next group: the last pixel above of this one
+    uint32_t a1 = 0, c32 = 0, s1 = 0, s2 = 0;         // Adler: bytes, offset-weighted bytes of this row; totals mod 65521
+    uint64_t b64 = 0;
+    const int steps = rounds * period + 63;
+    for (int t = 0; t <= steps; ++t) {
+        // the row above: what the lane before produced in the previous step (same group index)
+        uint32_t up[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) up[k] = (uint32_t)__shfl_up((int)o[k], 1);
+        const bool active = g >= 0 && g < groups && row < H;
+        if (lane == 0 && active && row > 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) up[k] = s_row[4 * g + k];
         }
+        if (row == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) up[k] = 0;
+        }
+        if (active) {
+            const uint8_t *rp = src + (size_t)row * stride;
+            if (g == 0) {
+                ft = rp[0];
+                bad |= ft > 4;
+                up3 = 0;
+                o[3] = 0;                             // nothing to the left
+                a1 = ft; c32 = 0; b64 = 0;            // the filter byte sits at offset 0
+            }
+            const int valid = min(4, W - 4 * g);      // pixels of this group
+            const uint32_t j0 = 1u + (uint32_t)g * (4 * BPP);
+            uint32_t xw[kWords];
+            if (valid == 4) {
+#pragma unroll
+                for (int q = 0; q < kWords; ++q) __builtin_memcpy(&xw[q], rp + j0 + 4 * q, 4);
+            } else {
+#pragma unroll
+                for (int q = 0; q < kWords; ++q) xw[q] = 0;
+                for (int e = 0; e < valid * BPP; ++e) xw[e >> 2] |= (uint32_t)rp[j0 + e] << (8 * (e & 3));
+            }
+            // Adler-32 terms of these bytes: sum and offset-weighted sum
+#pragma unroll
+            for (int q = 0; q < kWords; ++q) {
+                const uint32_t sum = __builtin_amdgcn_udot4(xw[q], 0x01010101u, 0u, false);
+                a1 += sum;
+                c32 = __builtin_amdgcn_udot4(xw[q], 0x03020100u, c32, false);
+                b64 += (uint64_t)(j0 + 4 * q) * sum;
+            }
+            uint32_t x[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                uint32_t v = 0;
+#pragma unroll
+                for (int ch = 0; ch < BPP; ++ch) {
+                    const int e = k * BPP + ch;
+                    v |= ((xw[e >> 2] >> (8 * (e & 3))) & 255u) << (8 * ch);
+                }
+                x[k] = v;
+            }
+            uint32_t left = o[3], ul = up3;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                o[k] = recon_pixel<BPP>(ft, x[k], left, up[k], ul);
+                left = o[k];
+                ul = up[k];
+            }
+            up3 = up[3];
+            // the reconstructed bytes, in stream order
+            uint32_t ow[kWords];
+            if (BPP == 4) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) ow[q % kWords] = o[q];
+            } else if (BPP == 3) {
+                ow[0] = o[0] | (o[1] << 24);
+                ow[1 % kWords] = (o[1] >> 8) | (o[2] << 16);
+                ow[2 % kWords] = (o[2] >> 16) | (o[3] << 8);
+            } else {
+                ow[0] = o[0] | (o[1] << 8) | (o[2] << 16) | (o[3] << 24);
+            }
+            uint8_t *wp = dst + (size_t)row * rb + (size_t)g * (4 * BPP);
+            if (valid == 4) {
+#pragma unroll
+                for (int q = 0; q < kWords; ++q) __builtin_memcpy(wp + 4 * q, &ow[q], 4);
+            } else {
+                for (int e = 0; e < valid * BPP; ++e) wp[e] = (uint8_t)(ow[e >> 2] >> (8 * (e & 3)));
+            }
+            if (lane == 63) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) s_row[4 * g + k] = o[k];
+            }
+            if (g == groups - 1) {
+                // this row's share of the sums: byte j of the row sits (total - row * stride - j) bytes before the end
+                const uint64_t after = total - (uint64_t)row * stride;
+                const uint64_t weighted = b64 + c32;
+                s1 = (s1 + a1 % 65521u) % 65521u;
+                s2 = (uint32_t)((s2 + (after % 65521u) * (uint64_t)(a1 % 65521u) + 65521u - weighted % 65521u) % 65521u);
+            }
+        }
+        ++g;
+        if (g == period) { g = 0; row += 64; }
+    }
+    // s1 = 1 + sum of bytes, s2 = total + sum of (distance to the end) * byte   (mod 65521)
+#pragma unroll
+    for (int sh = 32; sh >= 1; sh >>= 1) {
+        s1 += (uint32_t)__shfl_xor((int)s1, sh);
+        s2 += (uint32_t)__shfl_xor((int)s2, sh);
+        bad |= (uint32_t)__shfl_xor((int)bad, sh);
+    }
+    if (lane == 0) {
+        const uint32_t f1 = (1u + s1) % 65521u, f2 = (uint32_t)((total % 65521u + s2) % 65521u);
+        if (bad || ((f2 << 16) | f1) != adler[i]) status[i] = KE_PNG_CORRUPT;
     }
 }
 
@@ -107,49 +458,110 @@ KE_API int ke_png_decode(ke_ctx *ctx, const uint8_t *files, const uint64_t *offs
     if (n < 0 || (n > 0 && (!files || !offsets || !sizes || !pixels_out || !out_offsets || !status_out)))
         return ke_fail(ctx, KE_EINVAL, "NULL argument");
     if (n == 0) return KE_OK;
-    if (ke_is_device_ptr(files)) return ke_fail(ctx, KE_EINVAL, "compressed files are parsed on the host: pass host memory");
+    if (ke_is_device_ptr(files)) return ke_fail(ctx, KE_EINVAL, "compressed files are parsed on the host: pass host memory (pinned staging is fine)");
     if (!ke_is_device_ptr(pixels_out)) return ke_fail(ctx, KE_EINVAL, "pixels_out must be device memory");
     for (const void *p : {(const void *)offsets, (const void *)sizes, (const void *)out_offsets, (const void *)status_out})
         if (ke_is_device_ptr(p)) return ke_fail(ctx, KE_EINVAL, "offsets/sizes/status are host arrays");
     KE_HIP(ctx, hipSetDevice(ctx->device));
-    // ---- host: containers, CRCs, one zlib stream per image
-    std::vector<uint8_t> streams;
-    std::vector<KePngDev> devs;
-    std::vector<int64_t> which;
-    uint64_t raw_bytes = 0;
+    // ---- host: containers (chunk walk, CRCs of the header chunks), where each image's IDAT payloads lie
+    struct Item { KePngDev d; size_t seg0, seg1; int64_t which; };
+    std::vector<Item> items;
+    std::vector<KePngSeg> segs;
+    uint64_t lo = ~0ull, hi = 0;
     for (int64_t i = 0; i < n; ++i) {
-        KePngDev d;
-        ke_parse_png(files + offsets[i], (size_t)sizes[i], &streams, d.info);
-        status_out[i] = d.info.status;
-        if (d.info.status != KE_PNG_OK) continue;
-        if (streams.size() > 0xF0000000ull) return ke_fail(ctx, KE_EUNSUPPORTED, "more than 4 GB of compressed PNG data in one call");
-        d.raw_off = raw_bytes;
-        d.out_off = out_offsets[i];
-        raw_bytes += (((uint64_t)d.info.width * d.info.channels + 1) * d.info.height + 15) & ~15ull;
-        devs.push_back(d);
-        which.push_back(i);
+        Item it;
+        it.seg0 = segs.size();
+        ke_parse_png(files + offsets[i], (size_t)sizes[i], &segs, it.d.info);
+        status_out[i] = it.d.info.status;
+        if (it.d.info.status != KE_PNG_OK) continue;
+        it.seg1 = segs.size();
+        for (size_t s = it.seg0; s < it.seg1; ++s) segs[s].off += offsets[i];      // now relative to `files`
+        it.d.out_off = out_offsets[i];
+        it.which = i;
+        lo = std::min(lo, offsets[i]);
+        hi = std::max(hi, offsets[i] + sizes[i]);
+        items.push_back(it);
     }
-    if (devs.empty()) return KE_OK;
-    const int64_t m = (int64_t)devs.size();
-    streams.resize(streams.size() + 256);                // the stream windows read up to 64 bytes past an image's data
-    void *d_streams, *d_imgs, *d_raw, *d_work, *d_status;
-    KE_TRY(ke_reserve(ctx, KE_BUF_PIXELS, streams.size(), &d_streams));
-    KE_TRY(ke_reserve(ctx, KE_BUF_META, (size_t)m * sizeof(KePngDev), &d_imgs));
-    KE_TRY(ke_reserve(ctx, KE_BUF_TMP, (size_t)raw_bytes + 64, &d_raw));
-    KE_TRY(ke_reserve(ctx, KE_BUF_SSIM_IN, (size_t)m * 352, &d_work));
-    KE_TRY(ke_reserve(ctx, KE_BUF_OUT0, (size_t)m * 4, &d_status));
-    KE_HIP(ctx, hipMemcpyAsync(d_streams, streams.data(), streams.size(), hipMemcpyHostToDevice, ctx->stream));
-    KE_HIP(ctx, hipMemcpyAsync(d_imgs, devs.data(), (size_t)m * sizeof(KePngDev), hipMemcpyHostToDevice, ctx->stream));
+    if (items.empty()) return KE_OK;
+    // lanes of one wave finish together at best: neighbours in the batch should have streams of like length
+    std::stable_sort(items.begin(), items.end(), [](const Item &a, const Item &b) { return a.d.info.zlen > b.d.info.zlen; });
+    // the compressed files (one contiguous range of the caller's buffer) -> device
+    void *d_files;
+    KE_TRY(ke_reserve(ctx, KE_BUF_PIXELS, (size_t)(hi - lo) + 256, &d_files));
+    KE_HIP(ctx, hipMemcpyAsync(d_files, files + lo, (size_t)(hi - lo), hipMemcpyHostToDevice, ctx->stream));
+    // sub-batches bounded by scratch (streams + filtered scanlines) and by 32-bit stream offsets
+    size_t free_b = 0, total_b = 0;
+    KE_HIP(ctx, hipMemGetInfo(&free_b, &total_b));
+    const uint64_t budget = std::max<uint64_t>((uint64_t)2 << 30, std::min<uint64_t>((uint64_t)free_b / 3, (uint64_t)80 << 30));
+    std::vector<KePngDev> devs;
+    std::vector<KePngPiece> pieces;
+    std::vector<int32_t> st;
+    size_t first = 0;
     ke_time_begin(ctx, KE_T_JPEG);
-    hipLaunchKernelGGL(ke_png_inflate, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, ctx->stream, (const KePngDev *)d_imgs, m,
-                       (const uint8_t *)d_streams, (uint8_t *)d_raw, (uint8_t *)d_work, (int32_t *)d_status);
-    hipLaunchKernelGGL(ke_png_unfilter, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, ctx->stream, (const KePngDev *)d_imgs, m,
-                       (const uint8_t *)d_raw, pixels_out, (int32_t *)d_status);
-    KE_HIP(ctx, hipGetLastError());
+    while (first < items.size()) {
+        uint64_t zbytes = 0, raw_bytes = 0, nrecs = 0;
+        int max_groups = 0;
+        size_t last = first;
+        devs.clear();
+        pieces.clear();
+        while (last < items.size()) {
+            Item &it = items[last];
+            const uint64_t zl = ((uint64_t)it.d.info.zlen + 15) & ~15ull;
+            const uint64_t want = ((uint64_t)it.d.info.width * it.d.info.channels + 1) * it.d.info.height;
+            const uint64_t rw = (want + 32 + 15) & ~15ull, rc = want / 3 + 2;      // a copy covers at least 3 bytes
+            if (last > first && (zbytes + zl > 0xE0000000ull || zbytes + zl + raw_bytes + rw + (nrecs + rc) * 8 > budget)) break;
+            if (zbytes + zl > 0xF0000000ull) return ke_fail(ctx, KE_EUNSUPPORTED, "a PNG with more than 3.7 GB of compressed data");
+            it.d.info.zoff = (uint32_t)zbytes;
+            it.d.raw_off = raw_bytes;
+            it.d.rec_off = nrecs;
+            nrecs += rc;
+            uint64_t at = zbytes;
+            for (size_t s = it.seg0; s < it.seg1; ++s)
+                for (uint32_t o = 0; o < segs[s].len; o += kPieceBytes) {
+                    const uint32_t len = std::min(kPieceBytes, segs[s].len - o);
+                    pieces.push_back(KePngPiece{segs[s].off - lo + o, at, len, 0});
+                    at += len;
+                }
+            zbytes += zl;
+            raw_bytes += rw;
+            max_groups = std::max(max_groups, (it.d.info.width + 3) >> 2);
+            devs.push_back(it.d);
+            ++last;
+        }
+        const int64_t m = (int64_t)devs.size();
+        void *d_streams, *d_imgs, *d_pieces, *d_raw, *d_work, *d_status, *d_adler, *d_rec, *d_nrec;
+        KE_TRY(ke_reserve(ctx, KE_BUF_SSIM_AUX, (size_t)nrecs * 8, &d_rec));
+        KE_TRY(ke_reserve(ctx, KE_BUF_TILE32, (size_t)m * 4, &d_nrec));
+        KE_TRY(ke_reserve(ctx, KE_BUF_SSIM_IN, (size_t)zbytes + 256, &d_streams));      // the stream windows read up to 64 bytes past an image's data
+        KE_TRY(ke_reserve(ctx, KE_BUF_META, (size_t)m * sizeof(KePngDev), &d_imgs));
+        KE_TRY(ke_reserve(ctx, KE_BUF_JPEG_TABLES, pieces.size() * sizeof(KePngPiece), &d_pieces));
+        KE_TRY(ke_reserve(ctx, KE_BUF_TMP, (size_t)raw_bytes + 64, &d_raw));
+        KE_TRY(ke_reserve(ctx, KE_BUF_OUT1, (size_t)m * kWorkBytes, &d_work));
+        KE_TRY(ke_reserve(ctx, KE_BUF_OUT0, (size_t)m * 4, &d_status));
+        KE_TRY(ke_reserve(ctx, KE_BUF_OUT2, (size_t)m * 4, &d_adler));
+        KE_HIP(ctx, hipMemcpyAsync(d_imgs, devs.data(), (size_t)m * sizeof(KePngDev), hipMemcpyHostToDevice, ctx->stream));
+        KE_HIP(ctx, hipMemcpyAsync(d_pieces, pieces.data(), pieces.size() * sizeof(KePngPiece), hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(ke_png_gather, dim3((unsigned)pieces.size()), dim3(256), 0, ctx->stream, (const KePngPiece *)d_pieces,
+                           (const uint8_t *)d_files, (uint8_t *)d_streams);
+        hipLaunchKernelGGL(ke_png_inflate, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, ctx->stream, (const KePngDev *)d_imgs, m,
+                           (const uint8_t *)d_streams, (uint8_t *)d_raw, (uint8_t *)d_work, (uint2 *)d_rec, (int32_t *)d_status,
+                           (uint32_t *)d_adler, (uint32_t *)d_nrec);
+        hipLaunchKernelGGL(ke_png_matches, dim3((unsigned)m), dim3(64), 0, ctx->stream, (const KePngDev *)d_imgs, (uint8_t *)d_raw,
+                           (const uint2 *)d_rec, (const int32_t *)d_status, (const uint32_t *)d_nrec);
+        const size_t row_lds = (size_t)max_groups * 16;
+        hipLaunchKernelGGL(ke_png_unfilter<1>, dim3((unsigned)m), dim3(64), row_lds, ctx->stream, (const KePngDev *)d_imgs,
+                           (const uint8_t *)d_raw, pixels_out, (int32_t *)d_status, (const uint32_t *)d_adler);
+        hipLaunchKernelGGL(ke_png_unfilter<3>, dim3((unsigned)m), dim3(64), row_lds, ctx->stream, (const KePngDev *)d_imgs,
+                           (const uint8_t *)d_raw, pixels_out, (int32_t *)d_status, (const uint32_t *)d_adler);
+        hipLaunchKernelGGL(ke_png_unfilter<4>, dim3((unsigned)m), dim3(64), row_lds, ctx->stream, (const KePngDev *)d_imgs,
+                           (const uint8_t *)d_raw, pixels_out, (int32_t *)d_status, (const uint32_t *)d_adler);
+        KE_HIP(ctx, hipGetLastError());
+        st.resize((size_t)m);
+        KE_HIP(ctx, hipMemcpyAsync(st.data(), d_status, (size_t)m * 4, hipMemcpyDeviceToHost, ctx->stream));
+        KE_HIP(ctx, hipStreamSynchronize(ctx->stream));                  // devs / pieces / st are host vectors; scratch is reused
+        for (int64_t k = 0; k < m; ++k) status_out[items[first + (size_t)k].which] = st[(size_t)k];
+        first = last;
+    }
     ke_time_end(ctx, KE_T_JPEG);
-    std::vector<int32_t> st((size_t)m);
-    KE_HIP(ctx, hipMemcpyAsync(st.data(), d_status, (size_t)m * 4, hipMemcpyDeviceToHost, ctx->stream));
-    KE_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    for (int64_t k = 0; k < m; ++k) status_out[which[(size_t)k]] = st[(size_t)k];
     return KE_OK;
 }

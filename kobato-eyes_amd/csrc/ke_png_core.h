@@ -4,163 +4,271 @@
 // matter of following the two specifications; what is decoded is what `Image.open(path)` hands the reference's batch hasher
 // (src/core/fastsig.py:31-34) for 8-bit grayscale, RGB and RGBA files without interlacing.  Everything else (palette, 16-bit,
 // 1/2/4-bit, gray+alpha, Adam7) is refused by the parser and stays with Pillow.
+//
+// The inflate is written against three small policies so that one body serves both builds:
+//   Src   word(k): the k-th little-endian dword of the zlib stream (zeros past its end); tick(k): called once per symbol
+//   Sink  put(byte), copy(distance, length), size(), finish()
+//   Tab   the decoding tables of the current block (on the GPU: registers and per-lane slices of LDS)
+// Symbols are decoded by canonical-code comparison (RFC 1951 3.2.2: codes of one length are consecutive and shorter codes
+// sort first when left-aligned, so the length of the code in front of the reader is the number of per-length limits the next
+// 15 bits reach): fifteen 16-bit limits and bases per code and the symbols in code order are all the state there is, which is
+// what lets a GPU lane keep its tables in registers plus a few hundred bytes of LDS.
 #pragma once
 
 #include <stdint.h>
 
 #ifdef __HIPCC__
 #define KE_PNG_HD __host__ __device__ __forceinline__
+#define KE_PNG_MEMBER __host__ __device__ __forceinline__
 #else
 #define KE_PNG_HD static inline
+#define KE_PNG_MEMBER inline
 #endif
 
 enum { KE_PNG_OK = 0, KE_PNG_UNSUPPORTED = 1, KE_PNG_CORRUPT = 2 };
-
-// Canonical Huffman decoding tables of one deflate block (RFC 1951 3.2.2): count[len] codes of each length, symbols sorted by
-// (length, value).  One pair (literal/length, distance) per decoding thread.
-struct KeInflateTables {
-    uint16_t lcount[16];
-    uint16_t lsym[288];
-    uint16_t dcount[16];
-    uint16_t dsym[32];
-};
+enum { KE_PNG_MAX_WIDTH = 16384 };
 
 struct KePngInfo {
     int32_t status;
     int32_t width, height, channels;     // channels 1 (L), 3 (RGB), 4 (RGBA)
-    uint32_t zoff, zlen;                 // the zlib stream (all IDAT payloads, concatenated by the host) inside the staged bytes
+    uint32_t zoff, zlen;                 // the zlib stream (all IDAT payloads, concatenated) inside the staged stream bytes
 };
 
-// LSB-first bit reader over bytes fetched through `Src::byte(pos)` (RFC 1951 3.1.1)
+KE_PNG_HD uint32_t ke_brev32(uint32_t v) {
+#ifdef __HIP_DEVICE_COMPILE__
+    return __brev(v);
+#else
+    v = ((v >> 1) & 0x55555555u) | ((v & 0x55555555u) << 1);
+    v = ((v >> 2) & 0x33333333u) | ((v & 0x33333333u) << 2);
+    v = ((v >> 4) & 0x0F0F0F0Fu) | ((v & 0x0F0F0F0Fu) << 4);
+    v = ((v >> 8) & 0x00FF00FFu) | ((v & 0x00FF00FFu) << 8);
+    return (v >> 16) | (v << 16);
+#endif
+}
+
+// LSB-first bit reader (RFC 1951 3.1.1) over the stream's dwords; after a refill at least 33 bits are in `acc`
 template <typename Src>
 struct KeBitsLsb {
     Src *src;
-    uint32_t pos, end;
+    uint32_t wpos;       // next dword to fetch
     uint64_t acc;
     int32_t n;
-    int32_t overrun;
 };
 
 template <typename Src>
-KE_PNG_HD void ke_lsb_fill(KeBitsLsb<Src> &b) {
-    while (b.n <= 56) {
-        uint32_t byte = 0;
-        if (b.pos < b.end) byte = b.src->byte(b.pos++); else b.overrun += 1;
-        b.acc |= (uint64_t)byte << b.n;
-        b.n += 8;
+KE_PNG_HD void ke_lsb_refill(KeBitsLsb<Src> &b) {
+    if (b.n <= 32) {
+        b.acc |= (uint64_t)b.src->word(b.wpos++) << b.n;
+        b.n += 32;
     }
 }
 
 template <typename Src>
-KE_PNG_HD uint32_t ke_lsb_bits(KeBitsLsb<Src> &b, int k) {      // k <= 16
-    ke_lsb_fill(b);
-    const uint32_t v = (uint32_t)(b.acc & ((1u << k) - 1u));
+KE_PNG_HD uint32_t ke_lsb_take(KeBitsLsb<Src> &b, int k) {      // k <= 16 bits that a refill has made available
+    const uint32_t v = (uint32_t)b.acc & ((1u << k) - 1u);
     b.acc >>= k;
     b.n -= k;
     return v;
 }
 
-// one symbol with the canonical tables (the decode of zlib's puff.c, which follows the RFC directly); -1 = invalid code
 template <typename Src>
-KE_PNG_HD int ke_inflate_symbol(KeBitsLsb<Src> &b, const uint16_t *count, const uint16_t *sym) {
-    ke_lsb_fill(b);
-    int code = 0, first = 0, index = 0;
-    uint32_t bits = (uint32_t)b.acc;
-    for (int len = 1; len <= 15; ++len) {
-        code |= (int)(bits & 1u);
-        bits >>= 1;
-        const int cnt = count[len];
-        if (code - cnt < first) {
-            b.acc >>= len;
-            b.n -= len;
-            return sym[index + (code - first)];
-        }
-        index += cnt;
-        first += cnt;
-        first <<= 1;
-        code <<= 1;
-    }
-    return -1;
+KE_PNG_HD uint32_t ke_lsb_bits(KeBitsLsb<Src> &b, int k) {
+    ke_lsb_refill(b);
+    return ke_lsb_take(b, k);
 }
 
-// count[] / sym[] from code lengths (RFC 1951 3.2.2); returns 0 for a complete code, > 0 incomplete, < 0 over-subscribed
-KE_PNG_HD int ke_inflate_build(const uint8_t *lengths, int n, uint16_t *count, uint16_t *sym) {
-    for (int l = 0; l < 16; ++l) count[l] = 0;
-    for (int s = 0; s < n; ++s) count[lengths[s]] += 1;
-    if (count[0] == n) return 0;                      // no codes: complete, but unusable
+template <typename Src>
+KE_PNG_HD uint64_t ke_lsb_consumed(const KeBitsLsb<Src> &b) { return (uint64_t)b.wpos * 32u - (uint64_t)b.n; }
+
+// ---- reference table storage (the CPU build; the GPU keeps the same fields per lane, see ke_png.hip)
+struct KeInflateTables {
+    uint32_t lim_[2][8];                 // [0] literal/length, [1] distance: limits of lengths 2k, 2k+1 packed in halves
+    uint32_t base_[2][8];                // sorted position - first code of each length, int16 halves
+    uint16_t lsym_[288];
+    uint8_t dsym_[32];
+    uint32_t nib_[40];                   // code lengths of a block header, 8 per dword
+    uint32_t lim2(int which, int k) const { return lim_[which][k]; }
+    void set_lim2(int which, int k, uint32_t v) { lim_[which][k] = v; }
+    uint32_t base2(int which, int k) const { return base_[which][k]; }
+    void set_base2(int which, int k, uint32_t v) { base_[which][k] = v; }
+    uint32_t sym(int which, uint32_t i) const { return which ? dsym_[i & 31] : lsym_[i < 288 ? i : 0]; }
+    void clear_syms(int) {}
+    void set_sym(int which, uint32_t i, uint32_t s) { if (which) dsym_[i & 31] = (uint8_t)s; else lsym_[i < 288 ? i : 0] = (uint16_t)s; }
+    uint32_t nibword(int k) const { return nib_[k]; }
+    void set_nibword(int k, uint32_t v) { nib_[k] = v; }
+};
+
+// 16-bit halves of the packed per-length arrays
+KE_PNG_HD uint32_t ke_half_get(uint32_t word, int l) { return (l & 1) ? word >> 16 : word & 0xFFFFu; }
+KE_PNG_HD uint32_t ke_half_set(uint32_t word, int l, uint32_t v) {
+    return (l & 1) ? (word & 0xFFFFu) | (v << 16) : (word & 0xFFFF0000u) | (v & 0xFFFFu);
+}
+
+// code lengths pushed in order into the table's nibble words
+template <typename Tab>
+struct KeNibWriter {
+    Tab &t;
+    uint32_t cur, idx;
+    KE_PNG_MEMBER void push(uint32_t v) {
+        cur |= v << (4 * (idx & 7));
+        if ((++idx & 7) == 0) { t.set_nibword((int)(idx >> 3) - 1, cur); cur = 0; }
+    }
+    KE_PNG_MEMBER void flush() { if (idx & 7) t.set_nibword((int)(idx >> 3), cur); }
+};
+
+// Builds the decoding tables of one code from the lengths at nibbles [nib0, nib0 + n) (RFC 1951 3.2.2).
+// Returns 0 for a complete code (or one without any symbol, which decodes nothing), > 0 incomplete, < 0 over-subscribed;
+// *unused = number of symbols without a code.
+template <typename Tab>
+KE_PNG_HD int ke_inflate_build(Tab &t, int which, int n, int nib0, int *unused) {
+    // count[length], 9 bits each (n <= 288), in three 64-bit words: no addressable array needed
+    uint64_t c0 = 0, c1 = 0, c2 = 0;
+    uint32_t w = 0;
+    for (int s = 0; s < n; ++s) {
+        const int at = nib0 + s;
+        if (s == 0 || (at & 7) == 0) w = t.nibword(at >> 3);
+        const int l = (int)(w >> (4 * (at & 7))) & 15;
+        c0 += l < 7 ? 1ull << (9 * l) : 0ull;
+        c1 += (l >= 7 && l < 14) ? 1ull << (9 * (l - 7)) : 0ull;
+        c2 += l >= 14 ? 1ull << (9 * (l - 14)) : 0ull;
+    }
+    auto cnt = [&](int l) -> uint32_t {
+        return (uint32_t)((l < 7 ? c0 >> (9 * l) : l < 14 ? c1 >> (9 * (l - 7)) : c2 >> (9 * (l - 14))) & 511u);
+    };
+    *unused = (int)cnt(0);
+    if ((int)cnt(0) == n) {                           // no codes: every limit is reached, nothing decodes
+        t.set_lim2(which, 0, 0x00008000u);
+        for (int k = 1; k < 8; ++k) t.set_lim2(which, k, 0);
+        return 0;
+    }
     int left = 1;
     for (int l = 1; l <= 15; ++l) {
         left <<= 1;
-        left -= count[l];
+        left -= (int)cnt(l);
         if (left < 0) return left;
     }
-    uint16_t offs[16];
-    offs[1] = 0;
-    for (int l = 1; l < 15; ++l) offs[l + 1] = (uint16_t)(offs[l] + count[l]);
-    for (int s = 0; s < n; ++s)
-        if (lengths[s] != 0) sym[offs[lengths[s]]++] = (uint16_t)s;
+    // the symbols in code order: next position of every length counted up in the base slots
+    {
+        uint32_t off = 0, bw = 0;
+        for (int l = 1; l <= 15; ++l) {
+            bw = ke_half_set(bw, l, off);
+            if (l & 1) { t.set_base2(which, l >> 1, bw); bw = 0; }
+            off += cnt(l);
+        }
+    }
+    t.clear_syms(which);
+    for (int s = 0; s < n; ++s) {
+        const int at = nib0 + s;
+        if (s == 0 || (at & 7) == 0) w = t.nibword(at >> 3);
+        const int l = (int)(w >> (4 * (at & 7))) & 15;
+        if (l == 0) continue;
+        const uint32_t bw = t.base2(which, l >> 1);
+        const uint32_t idx = ke_half_get(bw, l);
+        t.set_base2(which, l >> 1, ke_half_set(bw, l, idx + 1));
+        t.set_sym(which, idx, (uint32_t)s);
+    }
+    {
+        uint32_t code = 0, off = 0, lw = 0x8000u, bw = 0;
+        for (int l = 1; l <= 15; ++l) {
+            const uint32_t c = cnt(l);
+            lw = ke_half_set(lw, l, (code + c) << (15 - l));         // one past the last code of this length, left-aligned
+            bw = ke_half_set(bw, l, (off - code) & 0xFFFFu);
+            if (l & 1) { t.set_lim2(which, l >> 1, lw); t.set_base2(which, l >> 1, bw); lw = bw = 0; }
+            code = (code + c) << 1;
+            off += c;
+        }
+    }
     return left;
 }
 
-// Sink: out.put(byte), out.get(distance) (a byte written `distance` positions back), out.size() bytes written so far.
-// Inflates one zlib stream of at most `limit` output bytes; returns KE_PNG_OK or KE_PNG_CORRUPT.  `work`: 320 bytes of
-// scratch for the code lengths of a dynamic block.
-template <typename Src, typename Sink>
-KE_PNG_HD int ke_inflate_zlib(KeBitsLsb<Src> &b, Sink &out, uint32_t limit, KeInflateTables &t, uint8_t *work) {
-    const uint16_t lbase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
-    const uint8_t lext[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
-    const uint16_t dbase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097,
-                                6145, 8193, 12289, 16385, 24577};
-    const uint8_t dext[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
-    const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+// canonical decode of the code in the low bits of `lo` (LSB-first as read): its length (0 = no such code) and symbol
+template <typename Tab>
+KE_PNG_HD int ke_inflate_canon(Tab &t, int which, uint32_t lo, int *len_out) {
+    const uint32_t v = ke_brev32(lo) >> 17;          // the next 15 bits, first bit on top
+    // limits reached, two per step: with bit 15 set in both halves, (v | 0x8000) - limit keeps that bit exactly where
+    // v >= limit (limits are <= 0x8000, so no half borrows from the other)
+    const uint32_t vv = (v | (v << 16)) | 0x80008000u;
+    uint32_t hits = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) hits += ((vv - t.lim2(which, k)) >> 15) & 0x00010001u;
+    const int len = (int)((hits & 0xFFFFu) + (hits >> 16)) + 1;
+    if (len > 15) { *len_out = 0; return -1; }
+    *len_out = len;
+    const int base = (int)(int16_t)ke_half_get(t.base2(which, len >> 1), len);
+    return (int)t.sym(which, (uint32_t)(base + (int)(v >> (15 - len))));
+}
+
+// Inflates one zlib stream of `zlen` bytes into at most `limit` output bytes.  The Adler-32 trailer is handed back in
+// *adler_out for the caller to hold against the output (the GPU does that where the output is read next, in parallel).
+// Returns KE_PNG_OK or KE_PNG_CORRUPT.
+template <typename Src, typename Sink, typename Tab>
+KE_PNG_HD int ke_inflate_zlib(KeBitsLsb<Src> &b, Sink &out, uint32_t zlen, uint32_t limit, Tab &t, uint32_t *adler_out) {
+    const uint64_t zbits = (uint64_t)zlen * 8u;
     // zlib header (RFC 1950): deflate, window <= 32K, no preset dictionary, check bits
     const uint32_t cmf = ke_lsb_bits(b, 8), flg = ke_lsb_bits(b, 8);
     if ((cmf & 15) != 8 || (cmf >> 4) > 7 || (flg & 32) || ((cmf << 8) | flg) % 31 != 0) return KE_PNG_CORRUPT;
-    uint32_t s1 = 1, s2 = 0, pending = 0;             // Adler-32 of the output
     int last;
     do {
+        if (ke_lsb_consumed(b) > zbits) return KE_PNG_CORRUPT;           // ran off the stream (only zeros come from there)
         last = (int)ke_lsb_bits(b, 1);
         const int type = (int)ke_lsb_bits(b, 2);
         if (type == 0) {                              // stored
-            const int drop = b.n & 7;                 // to the byte boundary
-            b.acc >>= drop;
-            b.n -= drop;
+            ke_lsb_take(b, b.n & 7);                  // to the byte boundary
             const uint32_t len = ke_lsb_bits(b, 16), nlen = ke_lsb_bits(b, 16);
             if ((len ^ 0xFFFFu) != nlen || out.size() + len > limit) return KE_PNG_CORRUPT;
-            for (uint32_t k = 0; k < len; ++k) {
-                const uint32_t v = ke_lsb_bits(b, 8);
-                out.put((uint8_t)v);
-                s1 += v; s2 += s1;
-                if (++pending == 5552) { s1 %= 65521u; s2 %= 65521u; pending = 0; }
-            }
+            for (uint32_t k = 0; k < len; ++k) out.put((uint8_t)ke_lsb_bits(b, 8));
             continue;
         }
         if (type == 3) return KE_PNG_CORRUPT;
+        int nlen, ndist;
+        KeNibWriter<Tab> nw{t, 0, 0};
         if (type == 1) {                              // fixed codes (3.2.6)
-            for (int s = 0; s < 144; ++s) work[s] = 8;
-            for (int s = 144; s < 256; ++s) work[s] = 9;
-            for (int s = 256; s < 280; ++s) work[s] = 7;
-            for (int s = 280; s < 288; ++s) work[s] = 8;
-            ke_inflate_build(work, 288, t.lcount, t.lsym);
-            for (int s = 0; s < 30; ++s) work[s] = 5;
-            ke_inflate_build(work, 30, t.dcount, t.dsym);
+            nlen = 288; ndist = 30;
+            for (int s = 0; s < 144; ++s) nw.push(8);
+            for (int s = 144; s < 256; ++s) nw.push(9);
+            for (int s = 256; s < 280; ++s) nw.push(7);
+            for (int s = 280; s < 288; ++s) nw.push(8);
+            for (int s = 0; s < 30; ++s) nw.push(5);
+            nw.flush();
         } else {                                      // dynamic codes (3.2.7)
-            const int nlen = (int)ke_lsb_bits(b, 5) + 257, ndist = (int)ke_lsb_bits(b, 5) + 1, ncode = (int)ke_lsb_bits(b, 4) + 4;
+            nlen = (int)ke_lsb_bits(b, 5) + 257;
+            ndist = (int)ke_lsb_bits(b, 5) + 1;
+            const int ncode = (int)ke_lsb_bits(b, 4) + 4;
             if (nlen > 286 || ndist > 30) return KE_PNG_CORRUPT;
-            for (int k = 0; k < 19; ++k) work[k] = 0;
-            for (int k = 0; k < ncode; ++k) work[order[k]] = (uint8_t)ke_lsb_bits(b, 3);
-            if (ke_inflate_build(work, 19, t.lcount, t.lsym) != 0) return KE_PNG_CORRUPT;   // the code length code must be complete
+            // the code length code: up to 19 lengths of 3 bits, sent in the order 16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4,
+            // 12, 3, 13, 2, 14, 1, 15; gathered as nibbles of a 64-bit + a 32-bit word
+            uint64_t cl_lo = 0;
+            uint32_t cl_hi = 0;
+            for (int k = 0; k < ncode; ++k) {
+                const int pos = k < 3 ? 16 + k : k == 3 ? 0 : (k & 1) ? 8 - ((k - 3) >> 1) : 8 + ((k - 4) >> 1);
+                const uint32_t v = ke_lsb_bits(b, 3);
+                if (pos < 16) cl_lo |= (uint64_t)v << (4 * pos); else cl_hi |= v << (4 * (pos - 16));
+            }
+            t.set_nibword(0, (uint32_t)cl_lo);
+            t.set_nibword(1, (uint32_t)(cl_lo >> 32));
+            t.set_nibword(2, cl_hi);
+            int unused;
+            if (ke_inflate_build(t, 1, 19, 0, &unused) != 0) return KE_PNG_CORRUPT;   // the code length code must be complete
+            // the literal/length and distance code lengths, run-length coded with that code (it sits in the distance slots,
+            // which the block's own distance code replaces below)
+            uint32_t prev = 0;
             int idx = 0;
             while (idx < nlen + ndist) {
-                int sym = ke_inflate_symbol(b, t.lcount, t.lsym);
-                if (sym < 0) return KE_PNG_CORRUPT;
+                ke_lsb_refill(b);
+                int cl;
+                const int sym = ke_inflate_canon(t, 1, (uint32_t)b.acc, &cl);
+                if (cl == 0) return KE_PNG_CORRUPT;
+                ke_lsb_take(b, cl);
                 if (sym < 16) {
-                    work[32 + idx++] = (uint8_t)sym;
+                    nw.push((uint32_t)sym);
+                    prev = (uint32_t)sym;
+                    ++idx;
                 } else {
-                    int len = 0, rep;
+                    uint32_t len = 0;
+                    int rep;
                     if (sym == 16) {
                         if (idx == 0) return KE_PNG_CORRUPT;
-                        len = work[32 + idx - 1];
+                        len = prev;
                         rep = 3 + (int)ke_lsb_bits(b, 2);
                     } else if (sym == 17) {
                         rep = 3 + (int)ke_lsb_bits(b, 3);
@@ -168,74 +276,96 @@ KE_PNG_HD int ke_inflate_zlib(KeBitsLsb<Src> &b, Sink &out, uint32_t limit, KeIn
                         rep = 11 + (int)ke_lsb_bits(b, 7);
                     }
                     if (idx + rep > nlen + ndist) return KE_PNG_CORRUPT;
-                    while (rep--) work[32 + idx++] = (uint8_t)len;
+                    idx += rep;
+                    while (rep--) nw.push(len);
+                    prev = len;
                 }
+                if (ke_lsb_consumed(b) > zbits) return KE_PNG_CORRUPT;
             }
-            if (work[32 + 256] == 0) return KE_PNG_CORRUPT;               // no end-of-block code
-            // literal/length: incomplete codes are only allowed with a single code (zlib's rule); same for distances
-            int err = ke_inflate_build(work + 32, nlen, t.lcount, t.lsym);
-            if (err < 0 || (err > 0 && nlen - t.lcount[0] != 1)) return KE_PNG_CORRUPT;
-            err = ke_inflate_build(work + 32 + nlen, ndist, t.dcount, t.dsym);
-            if (err < 0 || (err > 0 && ndist - t.dcount[0] != 1)) return KE_PNG_CORRUPT;
+            nw.flush();
+            if (((t.nibword(256 >> 3) >> (4 * (256 & 7))) & 15u) == 0) return KE_PNG_CORRUPT;      // no end-of-block code
         }
+        // literal/length: an incomplete code is only allowed when it has a single code (zlib's rule); same for distances
+        // (the fixed distance code, 30 of 32 five-bit codes, is incomplete by definition)
+        int unused;
+        int err = ke_inflate_build(t, 0, nlen, 0, &unused);
+        if (type == 2 && (err < 0 || (err > 0 && nlen - unused != 1))) return KE_PNG_CORRUPT;
+        err = ke_inflate_build(t, 1, ndist, nlen, &unused);
+        if (type == 2 && (err < 0 || (err > 0 && ndist - unused != 1))) return KE_PNG_CORRUPT;
         for (;;) {                                    // the block's symbols
-            int sym = ke_inflate_symbol(b, t.lcount, t.lsym);
-            if (sym < 0) return KE_PNG_CORRUPT;
+            b.src->tick(b.wpos);
+            ke_lsb_refill(b);
+            int cl;
+            int sym = ke_inflate_canon(t, 0, (uint32_t)b.acc, &cl);
+            if (cl == 0) return KE_PNG_CORRUPT;
+            ke_lsb_take(b, cl);
             if (sym < 256) {
                 if (out.size() >= limit) return KE_PNG_CORRUPT;
                 out.put((uint8_t)sym);
-                s1 += (uint32_t)sym; s2 += s1;
-                if (++pending == 5552) { s1 %= 65521u; s2 %= 65521u; pending = 0; }
                 continue;
             }
             if (sym == 256) break;
             sym -= 257;
             if (sym >= 29) return KE_PNG_CORRUPT;
-            const uint32_t len = lbase[sym] + ke_lsb_bits(b, lext[sym]);
-            const int ds = ke_inflate_symbol(b, t.dcount, t.dsym);
-            if (ds < 0 || ds >= 30) return KE_PNG_CORRUPT;
-            const uint32_t dist = dbase[ds] + ke_lsb_bits(b, dext[ds]);
+            // length 3..258 and its extra bits (3.2.5): eight codes of one length each, then groups of four per extra bit
+            const int lx = (sym < 8 || sym == 28) ? 0 : (sym - 4) >> 2;
+            const uint32_t len = (sym < 8 ? 3u + (uint32_t)sym : sym == 28 ? 258u : 3u + ((4u + ((uint32_t)sym & 3u)) << lx)) + ke_lsb_take(b, lx);
+            ke_lsb_refill(b);
+            int dl;
+            const int ds = ke_inflate_canon(t, 1, (uint32_t)b.acc, &dl);
+            if (dl == 0 || ds >= 30) return KE_PNG_CORRUPT;
+            ke_lsb_take(b, dl);
+            // distance 1..32768: four codes of one distance each, then pairs per extra bit
+            const int dx = ds < 4 ? 0 : (ds - 2) >> 1;
+            const uint32_t dist = (ds < 4 ? 1u + (uint32_t)ds : 1u + ((2u + ((uint32_t)ds & 1u)) << dx)) + ke_lsb_take(b, dx);
             if (dist > out.size() || out.size() + len > limit) return KE_PNG_CORRUPT;
-            for (uint32_t k = 0; k < len; ++k) {
-                const uint32_t v = out.get(dist);
-                out.put((uint8_t)v);
-                s1 += v; s2 += s1;
-                if (++pending == 5552) { s1 %= 65521u; s2 %= 65521u; pending = 0; }
-            }
+            out.copy(dist, len);
         }
     } while (!last);
-    // Adler-32 trailer, big-endian, at the next byte boundary
-    const int drop = b.n & 7;
-    b.acc >>= drop;
-    b.n -= drop;
-    s1 %= 65521u; s2 %= 65521u;
+    out.finish();
+    // Adler-32 of the output, big-endian, at the next byte boundary
+    ke_lsb_take(b, b.n & 7);
     uint32_t adler = 0;
     for (int k = 0; k < 4; ++k) adler = (adler << 8) | ke_lsb_bits(b, 8);
-    if (b.overrun > 8) return KE_PNG_CORRUPT;         // the filler's look-ahead past the data is fine, reading real bits there is not
-    if (adler != ((s2 << 16) | s1)) return KE_PNG_CORRUPT;
+    if (ke_lsb_consumed(b) > zbits) return KE_PNG_CORRUPT;
+    *adler_out = adler;
     return KE_PNG_OK;
 }
 
-// ---- scanline filters (PNG specification, "Filter algorithms"): row of `rb` bytes, bpp bytes per pixel;
-// raw: the filtered bytes (after the filter-type byte); prev: the reconstructed previous row or NULL for the first; out: result
+// Adler-32 (RFC 1950) of `n` bytes, sequentially (the CPU build; the GPU sums it by rows, see ke_png.hip)
+KE_PNG_HD uint32_t ke_adler32(const uint8_t *p, uint64_t n) {
+    uint32_t s1 = 1, s2 = 0;
+    while (n > 0) {
+        const uint32_t run = n < 5552 ? (uint32_t)n : 5552u;
+        for (uint32_t k = 0; k < run; ++k) { s1 += p[k]; s2 += s1; }
+        s1 %= 65521u; s2 %= 65521u;
+        p += run;
+        n -= run;
+    }
+    return (s2 << 16) | s1;
+}
+
+// ---- scanline filters (PNG specification, "Filter algorithms"): x the filtered byte, a left, b above, c above-left
 KE_PNG_HD int ke_paeth(int a, int b, int c) {
     const int p = a + b - c;
     const int pa = p > a ? p - a : a - p, pb = p > b ? p - b : b - p, pc = p > c ? p - c : c - p;
     return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
 }
 
+KE_PNG_HD int ke_png_recon(int type, int x, int a, int b, int c) {
+    const int pred = type == 0 ? 0 : type == 1 ? a : type == 2 ? b : type == 3 ? (a + b) >> 1 : ke_paeth(a, b, c);
+    return (x + pred) & 255;
+}
+
+// row of `rb` bytes, bpp bytes per pixel; raw: the filtered bytes (after the filter-type byte); prev: the reconstructed
+// previous row or NULL for the first; out: result
 KE_PNG_HD int ke_png_unfilter_row(int type, const uint8_t *raw, const uint8_t *prev, uint8_t *out, int rb, int bpp) {
     if (type > 4) return KE_PNG_CORRUPT;
     for (int i = 0; i < rb; ++i) {
         const int a = i >= bpp ? out[i - bpp] : 0;
         const int b = prev ? prev[i] : 0;
         const int c = (prev && i >= bpp) ? prev[i - bpp] : 0;
-        int v = raw[i];
-        if (type == 1) v += a;
-        else if (type == 2) v += b;
-        else if (type == 3) v += (a + b) >> 1;
-        else if (type == 4) v += ke_paeth(a, b, c);
-        out[i] = (uint8_t)v;
+        out[i] = (uint8_t)ke_png_recon(type, raw[i], a, b, c);
     }
     return KE_PNG_OK;
 }

@@ -8,13 +8,23 @@
 namespace {
 struct MemSrc {
     const uint8_t *p;
-    uint32_t byte(uint32_t pos) const { return p[pos]; }
+    uint32_t len;
+    uint32_t word(uint32_t k) const {
+        uint32_t w = 0;
+        for (uint32_t j = 0; j < 4; ++j)
+            if ((uint64_t)k * 4 + j < len) w |= (uint32_t)p[(size_t)k * 4 + j] << (8 * j);
+        return w;
+    }
+    void tick(uint32_t) {}
 };
 struct VecSink {
     std::vector<uint8_t> &v;
     void put(uint8_t b) { v.push_back(b); }
-    uint32_t get(uint32_t dist) const { return v[v.size() - dist]; }
+    void copy(uint32_t dist, uint32_t len) {
+        for (uint32_t k = 0; k < len; ++k) v.push_back(v[v.size() - dist]);
+    }
     uint32_t size() const { return (uint32_t)v.size(); }
+    void finish() {}
 };
 }  // namespace
 
@@ -29,19 +39,22 @@ int ko_png_probe(const uint8_t *file, uint64_t size, int32_t *w, int32_t *h, int
 
 int ko_png_decode(const uint8_t *file, uint64_t size, uint8_t *out) {
     KePngInfo info;
-    std::vector<uint8_t> stream;
-    ke_parse_png(file, (size_t)size, &stream, info);
+    std::vector<KePngSeg> segs;
+    ke_parse_png(file, (size_t)size, &segs, info);
     if (info.status != KE_PNG_OK) return info.status;
+    std::vector<uint8_t> stream;
+    for (const KePngSeg &s : segs) stream.insert(stream.end(), file + s.off, file + s.off + s.len);
     const int rb = info.width * info.channels;
+    const size_t want = (size_t)(rb + 1) * info.height;
     std::vector<uint8_t> raw;
-    raw.reserve((size_t)(rb + 1) * info.height);
-    MemSrc src{stream.data() + info.zoff};
-    KeBitsLsb<MemSrc> bits{&src, 0, info.zlen, 0, 0, 0};
+    raw.reserve(want);
+    MemSrc src{stream.data(), info.zlen};
+    KeBitsLsb<MemSrc> bits{&src, 0, 0, 0};
     VecSink sink{raw};
     KeInflateTables t;
-    uint8_t work[352];
-    if (ke_inflate_zlib(bits, sink, (uint32_t)((size_t)(rb + 1) * info.height), t, work) != KE_PNG_OK) return KE_PNG_CORRUPT;
-    if (raw.size() != (size_t)(rb + 1) * info.height) return KE_PNG_CORRUPT;
+    uint32_t adler = 0;
+    if (ke_inflate_zlib(bits, sink, info.zlen, (uint32_t)want, t, &adler) != KE_PNG_OK) return KE_PNG_CORRUPT;
+    if (raw.size() != want || ke_adler32(raw.data(), raw.size()) != adler) return KE_PNG_CORRUPT;
     for (int y = 0; y < info.height; ++y) {
         const uint8_t *row = raw.data() + (size_t)y * (rb + 1);
         if (ke_png_unfilter_row(row[0], row + 1, y ? out + (size_t)(y - 1) * rb : nullptr, out + (size_t)y * rb, rb, info.channels) != KE_PNG_OK)

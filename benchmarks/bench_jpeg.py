@@ -26,6 +26,9 @@ def main():
     ap.add_argument("--quality", type=int, default=85)
     ap.add_argument("--subsampling", type=int, default=2)
     ap.add_argument("--format", choices=["jpeg", "png"], default="jpeg")
+    ap.add_argument("--content", choices=["corpus", "drawing"], default="corpus",
+                    help="corpus: the synthetic corpus images (textured, photograph-like: PNG stays near half its raw size); "
+                         "drawing: flat 16-px cells, a few ramps and thin outlines (illustration-like: PNG shrinks 20-50x)")
     args = ap.parse_args()
     from PIL import Image
 
@@ -34,6 +37,15 @@ def main():
     ctx = _native.Context(0)
     distinct = 256
     px = ctx.synth_rgb(20260604, 0, distinct, args.side, args.side)
+    if args.content == "drawing":
+        rng = np.random.default_rng(11)
+        s = args.side
+        cells = rng.integers(0, 256, (distinct, s // 16 + 1, s // 16 + 1, 3), dtype=np.uint8)
+        px = np.repeat(np.repeat(cells, 16, 1), 16, 2)[:, :s, :s].copy()
+        ramp = (np.arange(s) * 255 // max(s - 1, 1)).astype(np.uint8)
+        px[:, s // 3: s // 2, :, 1] = ramp[None, None, :]                 # a band with a horizontal ramp in one channel
+        px[:, ::48, :, :] = 0                                             # outlines
+        px[:, :, ::64, :] = 0
     files = []
     for k in range(distinct):
         b = io.BytesIO()
@@ -70,7 +82,7 @@ def main():
         list(ex.map(dec, sample, chunksize=8))
     t_cpu = time.perf_counter() - t0
     wall, kern = float(np.median(t_wall)), float(np.median(t_kern))
-    print(json.dumps({"case": args.format + "_decode", "images": args.images, "side": args.side, "quality": args.quality,
+    print(json.dumps({"case": args.format + "_decode", "content": args.content, "images": args.images, "side": args.side, "quality": args.quality,
                       "subsampling": ["4:4:4", "4:2:2", "4:2:0"][args.subsampling], "compressed_mb": comp_bytes / 1e6,
                       "decode_kernels_ms": kern, "decode_images_per_s": args.images / (kern * 1e-3),
                       "decode_plus_hash_wall_ms": wall * 1e3, "decode_plus_hash_images_per_s": args.images / wall,

@@ -74,6 +74,10 @@ int         ke_device_info(ke_ctx *ctx, char *name, size_t name_len, int32_t *co
 /* device memory helpers for hosts that do not bring their own allocator */
 int ke_malloc(ke_ctx *ctx, size_t bytes, void **dev_ptr_out);
 int ke_free(ke_ctx *ctx, void *dev_ptr);
+/* page-locked host memory (hipHostMalloc): compressed files packed here cross PCIe at link speed and asynchronously, from
+ * pageable memory the runtime stages them through its own bounce buffer first.  ke_host_free waits for the context's stream. */
+int ke_host_alloc(ke_ctx *ctx, size_t bytes, void **host_ptr_out);
+int ke_host_free(ke_ctx *ctx, void *host_ptr);
 int ke_memcpy(ke_ctx *ctx, void *dst, const void *src, size_t bytes);   /* any direction, synchronous */
 
 /* ---- hashing: replaces sig.phash.phash / dhash (src/sig/phash.py:21-57) as driven by
@@ -155,11 +159,13 @@ int ke_jpeg_probe(const uint8_t *files, const uint64_t *offsets, const uint64_t 
 int ke_jpeg_decode(ke_ctx *ctx, const uint8_t *files, const uint64_t *offsets, const uint64_t *sizes, int64_t n,
                    uint8_t *pixels_out, const uint64_t *out_offsets, int32_t *status_out);
 
-/* ---- PNG decode on the GPU: the same step for PNG files with 8-bit grayscale ("L"), RGB or RGBA pixels and no interlacing;
- * zlib/deflate and the five scanline filters, one thread per image for each of the two (both are sequential per image).
- * Lossless, hence the pixels of Image.open by construction; chunk CRCs and the Adler-32 of the data are verified as Pillow /
- * zlib do.  Palette, 16-bit, sub-byte, gray+alpha, interlaced and animated files: KE_JPEG_UNSUPPORTED_ (1) per file, damaged
- * ones KE_JPEG_CORRUPT_ (2).  Arguments and conventions as ke_jpeg_probe / ke_jpeg_decode; channels is 1, 3 or 4. */
+/* ---- PNG decode on the GPU: the same step for PNG files with 8-bit grayscale ("L"), RGB or RGBA pixels and no interlacing.
+ * Lossless, hence the pixels of Image.open by construction (zlib/deflate, the five scanline filters).  One thread per image
+ * walks the deflate stream (literals to their place, LZ77 copies recorded), one wave per image then makes the copies and one
+ * wave per image undoes the filters and checks the stream's Adler-32; throughput comes from the batch.  Chunk CRCs are verified
+ * where Pillow verifies them (every chunk but IDAT).  Palette, 16-bit, sub-byte, gray+alpha, interlaced and animated files and
+ * rows wider than 16384 pixels: KE_JPEG_UNSUPPORTED_ (1) per file, damaged ones KE_JPEG_CORRUPT_ (2).  Arguments and
+ * conventions as ke_jpeg_probe / ke_jpeg_decode; channels is 1, 3 or 4. */
 int ke_png_probe(const uint8_t *files, const uint64_t *offsets, const uint64_t *sizes, int64_t n, int32_t *widths,
                  int32_t *heights, int32_t *channels, int32_t *status_out);
 int ke_png_decode(ke_ctx *ctx, const uint8_t *files, const uint64_t *offsets, const uint64_t *sizes, int64_t n,

@@ -28,7 +28,7 @@ EXPORTS = (
     "ke_hash_images", "ke_hash_uniform", "ke_hash_images_ex", "ke_hash_uniform_ex", "ke_luma_tiles_uniform", "ke_hamming_scan",
     "ke_stage_create", "ke_stage_destroy", "ke_stage_acquire", "ke_stage_submit_hash", "ke_stage_wait",
     "ke_comm_unique_id", "ke_comm_create", "ke_comm_destroy", "ke_allgather_u64", "ke_allgather_hashes", "ke_allgather_edges",
-    "ke_interleave_shards", "ke_jpeg_probe", "ke_jpeg_decode", "ke_png_probe", "ke_png_decode", "ke_cluster_labels", "ke_ssim_pairs_uniform", "ke_ssim_pairs", "ke_ssim_set_mode", "ke_resize_luma_uniform", "ke_fit_luma_uniform", "ke_tile_ahash", "ke_sad_pairs", "ke_synth_rgb",
+    "ke_interleave_shards", "ke_host_alloc", "ke_host_free", "ke_jpeg_probe", "ke_jpeg_decode", "ke_png_probe", "ke_png_decode", "ke_cluster_labels", "ke_ssim_pairs_uniform", "ke_ssim_pairs", "ke_ssim_set_mode", "ke_resize_luma_uniform", "ke_fit_luma_uniform", "ke_tile_ahash", "ke_sad_pairs", "ke_synth_rgb",
     "ke_synth_rgb_indexed",
     "ke_synth_hashes", "ke_last_kernel_ms",
 )
@@ -115,6 +115,8 @@ def load_library() -> C.CDLL:
         lib.ke_allgather_hashes.argtypes = [vp, vp, i32, vp, i64, vp]
         lib.ke_allgather_edges.argtypes = [vp, vp, i32, vp, i64, vp, i64, C.POINTER(i64), vp]
         lib.ke_interleave_shards.argtypes = [vp, vp, i32, i64, vp]
+        lib.ke_host_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+        lib.ke_host_free.argtypes = [vp, vp]
         lib.ke_jpeg_probe.argtypes = [vp, vp, vp, i64, vp, vp, vp, vp]
         lib.ke_jpeg_decode.argtypes = [vp, vp, vp, vp, i64, vp, vp, vp]
         lib.ke_png_probe.argtypes = [vp, vp, vp, i64, vp, vp, vp, vp]
@@ -138,7 +140,7 @@ def load_library() -> C.CDLL:
                      "ke_hash_images", "ke_hash_uniform", "ke_hash_images_ex", "ke_hash_uniform_ex", "ke_luma_tiles_uniform", "ke_hamming_scan",
                      "ke_stage_create", "ke_stage_destroy", "ke_stage_acquire", "ke_stage_submit_hash", "ke_stage_wait",
                      "ke_comm_unique_id", "ke_comm_create", "ke_comm_destroy", "ke_allgather_u64", "ke_allgather_hashes", "ke_allgather_edges",
-                     "ke_interleave_shards", "ke_jpeg_probe", "ke_jpeg_decode", "ke_png_probe", "ke_png_decode", "ke_cluster_labels", "ke_ssim_pairs_uniform", "ke_ssim_pairs", "ke_ssim_set_mode", "ke_resize_luma_uniform", "ke_fit_luma_uniform", "ke_tile_ahash",
+                     "ke_interleave_shards", "ke_host_alloc", "ke_host_free", "ke_jpeg_probe", "ke_jpeg_decode", "ke_png_probe", "ke_png_decode", "ke_cluster_labels", "ke_ssim_pairs_uniform", "ke_ssim_pairs", "ke_ssim_set_mode", "ke_resize_luma_uniform", "ke_fit_luma_uniform", "ke_tile_ahash",
                      "ke_sad_pairs", "ke_synth_rgb", "ke_synth_rgb_indexed", "ke_synth_hashes"):
             getattr(lib, name).restype = C.c_int
         _lib = lib
@@ -168,11 +170,19 @@ class Context:
             msg = self._lib.ke_create_error().decode("utf-8", "replace")
             raise NativeUnavailable(f"ke_create({device}) failed: {msg}")
         self.device = int(device)
-        self._lock = threading.Lock()
+        self._lock = threading.RLock()
+        self._pack_ptr, self._pack_cap = 0, 0
+        self._decoded_ptr, self._decoded_cap = 0, 0
 
     # -- lifetime ---------------------------------------------------------------------------
     def close(self) -> None:
         if getattr(self, "_h", None):
+            if getattr(self, "_pack_ptr", 0):
+                self._lib.ke_host_free(self._h, self._pack_ptr)
+                self._pack_ptr, self._pack_cap = 0, 0
+            if getattr(self, "_decoded_ptr", 0):
+                self._lib.ke_free(self._h, self._decoded_ptr)
+                self._decoded_ptr, self._decoded_cap = 0, 0
             self._lib.ke_destroy(self._h)
             self._h = None
 
@@ -352,6 +362,43 @@ class Context:
         flat = np.frombuffer(b"".join(blobs) + bytes(64), np.uint8)     # one C-level copy; the decoder takes any alignment
         return flat, offsets, sizes
 
+    def _pack_blobs_pinned(self, blobs):
+        """The files back to back in the context's page-locked buffer (grown on demand, reused from call to call): the copy
+        to the device then runs at link speed.  Call with the lock held; the buffer is busy until the decode has returned."""
+        sizes = np.fromiter((len(b) for b in blobs), np.uint64, len(blobs))
+        offsets = np.zeros(len(blobs), np.uint64)
+        offsets[1:] = np.cumsum(sizes[:-1])
+        total = int(sizes.sum()) + 64
+        if total > self._pack_cap:
+            if self._pack_ptr:
+                self._check(self._lib.ke_host_free(self._h, self._pack_ptr), "ke_host_free")
+                self._pack_ptr, self._pack_cap = 0, 0
+            cap = max(total + total // 4, 1 << 24)
+            p = C.c_void_p()
+            self._check(self._lib.ke_host_alloc(self._h, cap, C.byref(p)), "ke_host_alloc")
+            self._pack_ptr, self._pack_cap = int(p.value), cap
+        base = self._pack_ptr
+
+        def copy(lo, hi):
+            for i in range(lo, hi):
+                C.memmove(base + int(offsets[i]), blobs[i], len(blobs[i]))     # releases the GIL
+
+        n = len(blobs)
+        workers = min(8, max(1, total >> 26))
+        if workers > 1:
+            cuts = np.searchsorted(offsets, np.linspace(0, total, workers + 1)[1:-1]).tolist()
+            bounds = [0] + cuts + [n]
+            threads = [threading.Thread(target=copy, args=(bounds[k], bounds[k + 1])) for k in range(workers)]
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
+        else:
+            copy(0, n)
+        C.memset(base + total - 64, 0, 64)
+        flat = np.ctypeslib.as_array((C.c_uint8 * total).from_address(base))
+        return flat, offsets, sizes
+
     def jpeg_probe(self, blobs, kind: str = "jpeg"):
         """(widths, heights, channels, status) of JPEG (or, kind="png", PNG) files given as bytes; status 0 = the GPU
         decoder takes the file."""
@@ -374,45 +421,55 @@ class Context:
         return self.jpeg_hash(blobs, want_dhash=want_dhash, kind="png")
 
     def _jpeg_to_device(self, blobs, kind: str = "jpeg"):
-        """Decode what the GPU decoder takes into a device buffer: (device ptr or 0, byte offsets, widths, heights, channels,
-        status).  The caller frees the buffer."""
-        flat, offsets, sizes = self._pack_blobs(blobs)
+        """Decode what the GPU decoder takes into the context's decode buffer (device memory, grown on demand and kept:
+        allocating tens of GB per call costs up to a second): (device ptr or 0, byte offsets, widths, heights, channels,
+        status).  Call with the lock held and keep it until the pixels have been used."""
         n = len(blobs)
         w, h, c, st = (np.zeros(n, np.int32) for _ in range(4))
-        rc = getattr(self._lib, f"ke_{kind}_probe")(_addr(flat), _addr(offsets), _addr(sizes), n, _addr(w), _addr(h), _addr(c), _addr(st))
-        if rc != KE_OK:
-            raise ValueError(f"ke_{kind}_probe: bad arguments")
-        nbytes = np.where(st == 0, w.astype(np.int64) * h * c, 0)
-        padded = (nbytes + 15) & ~np.int64(15)
-        out_off = np.zeros(n, np.uint64)
-        out_off[1:] = np.cumsum(padded[:-1]).astype(np.uint64)
-        total = int(padded.sum())
-        if total == 0:
-            return 0, out_off, w, h, c, st
-        dev = self.malloc(total + 64)
-        try:
-            with self._lock:
-                self._check(getattr(self._lib, f"ke_{kind}_decode")(self._h, _addr(flat), _addr(offsets), _addr(sizes), n, dev,
-                                                                    _addr(out_off), _addr(st)), f"ke_{kind}_decode")
-        except Exception:
-            self.free(dev)
-            raise
+        with self._lock:
+            flat, offsets, sizes = self._pack_blobs_pinned(blobs)
+            rc = getattr(self._lib, f"ke_{kind}_probe")(_addr(flat), _addr(offsets), _addr(sizes), n, _addr(w), _addr(h), _addr(c), _addr(st))
+            if rc != KE_OK:
+                raise ValueError(f"ke_{kind}_probe: bad arguments")
+            nbytes = np.where(st == 0, w.astype(np.int64) * h * c, 0)
+            padded = (nbytes + 15) & ~np.int64(15)
+            out_off = np.zeros(n, np.uint64)
+            out_off[1:] = np.cumsum(padded[:-1]).astype(np.uint64)
+            total = int(padded.sum())
+            if total == 0:
+                return 0, out_off, w, h, c, st
+            if total + 64 > self._decoded_cap:
+                if self._decoded_ptr:
+                    self.free(self._decoded_ptr)
+                    self._decoded_ptr, self._decoded_cap = 0, 0
+                cap = total + total // 8 + 64
+                self._decoded_ptr, self._decoded_cap = self.malloc(cap), cap
+            dev = self._decoded_ptr
+            self._check(getattr(self._lib, f"ke_{kind}_decode")(self._h, _addr(flat), _addr(offsets), _addr(sizes), n, dev,
+                                                                _addr(out_off), _addr(st)), f"ke_{kind}_decode")
         return dev, out_off, w, h, c, st
+
+    def release_decode_buffers(self) -> None:
+        """Give back the page-locked packing buffer and the device decode buffer (they are kept between calls otherwise)."""
+        with self._lock:
+            if self._pack_ptr:
+                self._check(self._lib.ke_host_free(self._h, self._pack_ptr), "ke_host_free")
+                self._pack_ptr, self._pack_cap = 0, 0
+            if self._decoded_ptr:
+                self.free(self._decoded_ptr)
+                self._decoded_ptr, self._decoded_cap = 0, 0
 
     def jpeg_decode(self, blobs, kind: str = "jpeg"):
         """Pixels of JPEG files decoded on the GPU: list of ndarrays (HxW or HxWx3, what np.asarray(Image.open(f)) gives) with
         None where the decoder refused the file (status != 0); also returns the statuses."""
-        dev, out_off, w, h, c, st = self._jpeg_to_device(blobs, kind)
         out = [None] * len(blobs)
-        try:
+        with self._lock:
+            dev, out_off, w, h, c, st = self._jpeg_to_device(blobs, kind)
             for i in range(len(blobs)):
                 if st[i] == 0:
                     arr = np.empty((h[i], w[i], c[i]) if c[i] > 1 else (h[i], w[i]), np.uint8)
                     self.memcpy(arr, dev + int(out_off[i]), arr.nbytes)
                     out[i] = arr
-        finally:
-            if dev:
-                self.free(dev)
         return out, st
 
     def jpeg_hash(self, blobs, *, want_dhash=True, kind: str = "jpeg"):
@@ -423,8 +480,8 @@ class Context:
         dh = np.zeros(n, np.uint64) if want_dhash else None
         if n == 0:
             return ph, dh, np.zeros(0, np.int32)
-        dev, out_off, w, h, c, st = self._jpeg_to_device(blobs, kind)
-        try:
+        with self._lock:
+            dev, out_off, w, h, c, st = self._jpeg_to_device(blobs, kind)
             for ch in (1, 3, 4):
                 idx = np.nonzero((st == 0) & (c == ch))[0]
                 if len(idx) == 0:
@@ -441,9 +498,6 @@ class Context:
                 if want_dhash:
                     dh[idx] = d
                 st[idx[status != 0]] = 2
-        finally:
-            if dev:
-                self.free(dev)
         return ph, dh, st
 
     # -- scan -------------------------------------------------------------------------------

@@ -278,6 +278,20 @@ KE_API int ke_free(ke_ctx *ctx, void *p) {
     return KE_OK;
 }
 
+KE_API int ke_host_alloc(ke_ctx *ctx, size_t bytes, void **out) {
+    if (!ctx || !out) return KE_EINVAL;
+    KE_HIP(ctx, hipSetDevice(ctx->device));
+    KE_HIP(ctx, hipHostMalloc(out, bytes ? bytes : 16, hipHostMallocDefault));
+    return KE_OK;
+}
+
+KE_API int ke_host_free(ke_ctx *ctx, void *p) {
+    if (!ctx) return KE_EINVAL;
+    KE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    KE_HIP(ctx, hipHostFree(p));
+    return KE_OK;
+}
+
 KE_API int ke_memcpy(ke_ctx *ctx, void *dst, const void *src, size_t bytes) {
     if (!ctx || (!dst && bytes) || (!src && bytes)) return KE_EINVAL;
     if (!bytes) return KE_OK;

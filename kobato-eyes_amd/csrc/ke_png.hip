@@ -105,29 +105,23 @@ struct LdsStream {
     }
 };
 
-// Literals go to their final place in HBM (as whole dwords where the position allows); an LZ77 copy is only written down --
-// (destination, distance, length) -- and its bytes are left open: reading the source back here would stall the wave once per
-// match, so ke_png_matches fills the copies in afterwards with a whole wave per image.
+// Literals go to their final place in HBM, four at a time; an LZ77 copy is only written down -- (destination, distance,
+// length) -- and its bytes are left open: reading the source back here would stall the wave once per match, so ke_png_matches
+// fills the copies in afterwards with a whole wave per image.  A dword that straddles the edge of a copy is written with
+// zeros on the copy's side; the copy overwrites them later.
 struct RecSink {
     uint8_t *p;
-    uint32_t n, w, gathering;      // gathering: the bytes of the dword being filled are in w (else they went out singly)
+    uint32_t n, w;
     uint2 *rec;
     uint32_t nrec;
     __device__ __forceinline__ uint32_t size() const { return n; }
     __device__ __forceinline__ void put(uint8_t b) {
-        if (gathering) {
-            w |= (uint32_t)b << (8 * (n & 3));
-            ++n;
-            if ((n & 3) == 0) { *reinterpret_cast<uint32_t *>(p + n - 4) = w; w = 0; }
-        } else {
-            p[n] = b;
-            ++n;
-            gathering = (n & 3) == 0;
-        }
+        w |= (uint32_t)b << (8 * (n & 3));
+        ++n;
+        if ((n & 3) == 0) { *reinterpret_cast<uint32_t *>(p + n - 4) = w; w = 0; }
     }
-    // what has been gathered goes out with zeros behind it: those fall into the copy that follows (or the slack at the end)
     __device__ __forceinline__ void settle() {
-        if (gathering && (n & 3)) *reinterpret_cast<uint32_t *>(p + (n & ~3u)) = w;
+        if (n & 3) *reinterpret_cast<uint32_t *>(p + (n & ~3u)) = w;
         w = 0;
     }
     __device__ __forceinline__ void finish() { settle(); }
@@ -135,7 +129,6 @@ struct RecSink {
         settle();
         rec[nrec++] = make_uint2(n, (dist << 9) | (len - 3));
         n += len;
-        gathering = (n & 3) == 0;
     }
 };
 
@@ -201,7 +194,7 @@ __global__ __launch_bounds__(64) void ke_png_inflate(const KePngDev *__restrict_
     src.nchunk = (d.info.zlen + 15u) >> 4;
     src.avail = src.req = src.t = 0;
     KeBitsLsb<LdsStream> bits{&src, 0, 0, 0};
-    RecSink sink{raw + d.raw_off, 0, 0, 1, records + d.rec_off, 0};
+    RecSink sink{raw + d.raw_off, 0, 0, records + d.rec_off, 0};
     LaneTab tab;
     tab.lsym_ = s_lsym + threadIdx.x;
     tab.lhigh_ = s_lhigh + threadIdx.x;

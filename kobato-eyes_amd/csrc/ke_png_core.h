@@ -181,21 +181,54 @@ KE_PNG_HD int ke_inflate_build(Tab &t, int which, int n, int nib0, int *unused) 
     return left;
 }
 
+// The limits and bases of both codes as plain values: what the symbol loop decodes from.  They are taken out of the table
+// once per block and handed on one by one -- as values, never as a struct behind a reference: selecting among fields
+// of an object in memory is rewritten by the compiler into one load at a computed address, which on the GPU pins the object
+// in scratch memory and puts a memory round trip into every symbol.
+#define KE_OCT_PARAMS(p) uint32_t p##0, uint32_t p##1, uint32_t p##2, uint32_t p##3, uint32_t p##4, uint32_t p##5, uint32_t p##6, uint32_t p##7
+#define KE_OCT_ARGS(p) p##0, p##1, p##2, p##3, p##4, p##5, p##6, p##7
+#define KE_OCT_LOAD(p, expr)                                                                                                   \
+    const uint32_t p##0 = expr(0), p##1 = expr(1), p##2 = expr(2), p##3 = expr(3), p##4 = expr(4), p##5 = expr(5), p##6 = expr(6), \
+                   p##7 = expr(7)
+
+#define KE_LIM0(k) t.lim2(0, k)
+#define KE_BASE0(k) t.base2(0, k)
+#define KE_LIM1(k) t.lim2(1, k)
+#define KE_BASE1(k) t.base2(1, k)
+
+KE_PNG_HD uint32_t ke_oct_get(int k, KE_OCT_PARAMS(a)) {
+    uint32_t r = a0;
+    r = k == 1 ? a1 : r; r = k == 2 ? a2 : r; r = k == 3 ? a3 : r; r = k == 4 ? a4 : r;
+    r = k == 5 ? a5 : r; r = k == 6 ? a6 : r; r = k == 7 ? a7 : r;
+    return r;
+}
+
 // canonical decode of the code in the low bits of `lo` (LSB-first as read): its length (0 = no such code) and symbol
+// (-1 then); `dist` selects between the literal/length code (l, b) and the distance code (m, c) -- per lane on the GPU
 template <typename Tab>
-KE_PNG_HD int ke_inflate_canon(Tab &t, int which, uint32_t lo, int *len_out) {
+KE_PNG_HD int ke_inflate_canon(Tab &t, int dist, uint32_t lo, int *len_out, KE_OCT_PARAMS(l), KE_OCT_PARAMS(b), KE_OCT_PARAMS(m),
+                               KE_OCT_PARAMS(c)) {
     const uint32_t v = ke_brev32(lo) >> 17;          // the next 15 bits, first bit on top
     // limits reached, two per step: with bit 15 set in both halves, (v | 0x8000) - limit keeps that bit exactly where
     // v >= limit (limits are <= 0x8000, so no half borrows from the other)
     const uint32_t vv = (v | (v << 16)) | 0x80008000u;
     uint32_t hits = 0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) hits += ((vv - t.lim2(which, k)) >> 15) & 0x00010001u;
-    const int len = (int)((hits & 0xFFFFu) + (hits >> 16)) + 1;
-    if (len > 15) { *len_out = 0; return -1; }
-    *len_out = len;
-    const int base = (int)(int16_t)ke_half_get(t.base2(which, len >> 1), len);
-    return (int)t.sym(which, (uint32_t)(base + (int)(v >> (15 - len))));
+    hits += ((vv - (dist ? m0 : l0)) >> 15) & 0x00010001u;
+    hits += ((vv - (dist ? m1 : l1)) >> 15) & 0x00010001u;
+    hits += ((vv - (dist ? m2 : l2)) >> 15) & 0x00010001u;
+    hits += ((vv - (dist ? m3 : l3)) >> 15) & 0x00010001u;
+    hits += ((vv - (dist ? m4 : l4)) >> 15) & 0x00010001u;
+    hits += ((vv - (dist ? m5 : l5)) >> 15) & 0x00010001u;
+    hits += ((vv - (dist ? m6 : l6)) >> 15) & 0x00010001u;
+    hits += ((vv - (dist ? m7 : l7)) >> 15) & 0x00010001u;
+    const int reached = (int)((hits & 0xFFFFu) + (hits >> 16));
+    const bool none = reached >= 15;                 // every limit reached: no code starts with these bits
+    const int len = none ? 15 : reached + 1;
+    const uint32_t bw = dist ? ke_oct_get(len >> 1, KE_OCT_ARGS(c)) : ke_oct_get(len >> 1, KE_OCT_ARGS(b));
+    const int base = (int)(int16_t)ke_half_get(bw, len);
+    const int sym = (int)t.sym(dist, (uint32_t)(base + (int)(v >> (15 - len))));
+    *len_out = none ? 0 : len;
+    return none ? -1 : sym;
 }
 
 // Inflates one zlib stream of `zlen` bytes into at most `limit` output bytes.  The Adler-32 trailer is handed back in
@@ -251,12 +284,14 @@ KE_PNG_HD int ke_inflate_zlib(KeBitsLsb<Src> &b, Sink &out, uint32_t zlen, uint3
             if (ke_inflate_build(t, 1, 19, 0, &unused) != 0) return KE_PNG_CORRUPT;   // the code length code must be complete
             // the literal/length and distance code lengths, run-length coded with that code (it sits in the distance slots,
             // which the block's own distance code replaces below)
+            KE_OCT_LOAD(q, KE_LIM1);
+            KE_OCT_LOAD(r, KE_BASE1);
             uint32_t prev = 0;
             int idx = 0;
             while (idx < nlen + ndist) {
                 ke_lsb_refill(b);
                 int cl;
-                const int sym = ke_inflate_canon(t, 1, (uint32_t)b.acc, &cl);
+                const int sym = ke_inflate_canon(t, 1, (uint32_t)b.acc, &cl, KE_OCT_ARGS(q), KE_OCT_ARGS(r), KE_OCT_ARGS(q), KE_OCT_ARGS(r));
                 if (cl == 0) return KE_PNG_CORRUPT;
                 ke_lsb_take(b, cl);
                 if (sym < 16) {
@@ -292,35 +327,39 @@ KE_PNG_HD int ke_inflate_zlib(KeBitsLsb<Src> &b, Sink &out, uint32_t zlen, uint3
         if (type == 2 && (err < 0 || (err > 0 && nlen - unused != 1))) return KE_PNG_CORRUPT;
         err = ke_inflate_build(t, 1, ndist, nlen, &unused);
         if (type == 2 && (err < 0 || (err > 0 && ndist - unused != 1))) return KE_PNG_CORRUPT;
-        for (;;) {                                    // the block's symbols
+        // the block's symbols.  Written for lock-step execution (on the GPU all 64 lanes of a wave pay for every path any of
+        // them takes, every symbol): one way out of the loop, damage remembered instead of returned mid-way.
+        KE_OCT_LOAD(l, KE_LIM0);
+        KE_OCT_LOAD(g, KE_BASE0);
+        KE_OCT_LOAD(m, KE_LIM1);
+        KE_OCT_LOAD(h, KE_BASE1);
+        uint32_t bad = 0;
+        for (;;) {
             b.src->tick(b.wpos);
-            ke_lsb_refill(b);
+            ke_lsb_refill(b);                         // >= 33 bits: a code (<= 15) and its extra bits (<= 13)
             int cl;
-            int sym = ke_inflate_canon(t, 0, (uint32_t)b.acc, &cl);
-            if (cl == 0) return KE_PNG_CORRUPT;
+            int sym = ke_inflate_canon(t, 0, (uint32_t)b.acc, &cl, KE_OCT_ARGS(l), KE_OCT_ARGS(g), KE_OCT_ARGS(m), KE_OCT_ARGS(h));
             ke_lsb_take(b, cl);
-            if (sym < 256) {
-                if (out.size() >= limit) return KE_PNG_CORRUPT;
-                out.put((uint8_t)sym);
-                continue;
+            bad |= (uint32_t)(cl == 0);               // no such code (sym is -1 then)
+            if ((uint32_t)sym < 256u) {
+                if (out.size() < limit) out.put((uint8_t)sym); else bad = 1;
+            } else if (sym > 256) {
+                // length 3..258 (3.2.5): eight codes of one length each, then groups of four per extra bit, then 258 itself
+                const int ls = sym - 257;
+                const int lx = (ls < 8 || ls >= 28) ? 0 : (ls - 4) >> 2;
+                const uint32_t len = (ls < 8 ? 3u + (uint32_t)ls : ls >= 28 ? 258u : 3u + ((4u + ((uint32_t)ls & 3u)) << lx)) + ke_lsb_take(b, lx);
+                ke_lsb_refill(b);
+                int dl;
+                const int ds = ke_inflate_canon(t, 1, (uint32_t)b.acc, &dl, KE_OCT_ARGS(l), KE_OCT_ARGS(g), KE_OCT_ARGS(m), KE_OCT_ARGS(h));
+                ke_lsb_take(b, dl);
+                // distance 1..32768: four codes of one distance each, then pairs per extra bit
+                const int dx = ds < 4 ? 0 : ((ds - 2) >> 1) & 15;
+                const uint32_t dist = (ds < 4 ? 1u + (uint32_t)(ds & 3) : 1u + ((2u + ((uint32_t)ds & 1u)) << dx)) + ke_lsb_take(b, dx);
+                if (ls >= 29 || dl == 0 || ds >= 30 || dist > out.size() || out.size() + len > limit) bad = 1; else out.copy(dist, len);
             }
-            if (sym == 256) break;
-            sym -= 257;
-            if (sym >= 29) return KE_PNG_CORRUPT;
-            // length 3..258 and its extra bits (3.2.5): eight codes of one length each, then groups of four per extra bit
-            const int lx = (sym < 8 || sym == 28) ? 0 : (sym - 4) >> 2;
-            const uint32_t len = (sym < 8 ? 3u + (uint32_t)sym : sym == 28 ? 258u : 3u + ((4u + ((uint32_t)sym & 3u)) << lx)) + ke_lsb_take(b, lx);
-            ke_lsb_refill(b);
-            int dl;
-            const int ds = ke_inflate_canon(t, 1, (uint32_t)b.acc, &dl);
-            if (dl == 0 || ds >= 30) return KE_PNG_CORRUPT;
-            ke_lsb_take(b, dl);
-            // distance 1..32768: four codes of one distance each, then pairs per extra bit
-            const int dx = ds < 4 ? 0 : (ds - 2) >> 1;
-            const uint32_t dist = (ds < 4 ? 1u + (uint32_t)ds : 1u + ((2u + ((uint32_t)ds & 1u)) << dx)) + ke_lsb_take(b, dx);
-            if (dist > out.size() || out.size() + len > limit) return KE_PNG_CORRUPT;
-            out.copy(dist, len);
+            if (sym == 256 || bad) break;
         }
+        if (bad) return KE_PNG_CORRUPT;
     } while (!last);
     out.finish();
     // Adler-32 of the output, big-endian, at the next byte boundary

@@ -4,6 +4,8 @@ compression level incl. stored blocks and optimised encoding, sizes from 1x1) an
 from __future__ import annotations
 
 import io
+import struct
+import zlib
 
 import numpy as np
 from PIL import Image
@@ -37,6 +39,50 @@ def supported(full: bool = False):
                     yield f"{w}x{h}_k{kind}_{mode}_{kw}", data, np.asarray(Image.open(io.BytesIO(data)))
 
 
+def _container(raw: bytes, w: int, h: int, ctype: int, level: int, strategy: int, chunk: int) -> bytes:
+    """A PNG around filtered scanlines given as they are, with control over what Pillow's writer never varies: the zlib
+    strategy and the size of the IDAT chunks."""
+    co = zlib.compressobj(level, zlib.DEFLATED, 15, 9, strategy)
+    z = co.compress(raw) + co.flush()
+
+    def ch(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d))
+
+    out = b"\x89PNG\r\n\x1a\n" + ch(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, ctype, 0, 0, 0))
+    for o in range(0, len(z), chunk):
+        out += ch(b"IDAT", z[o:o + chunk])
+    return out + ch(b"IEND", b"")
+
+
+def handmade(full: bool = False):
+    """Yields (name, file bytes, pixels as Pillow decodes them): streams Pillow's own writer does not produce -- code lengths
+    up to 15 bits (a geometric byte histogram), Huffman-only / RLE / fixed-code / stored blocks, IDAT data cut into chunks
+    of a few bytes, every filter type on random rows."""
+    rng = np.random.default_rng(5)
+    sizes = [(257, 129), (640, 480)] if full else [(257, 129)]
+    for (w, h) in sizes:
+        for ctype, ch_ in ((0, 1), (2, 3), (6, 4)):
+            vals = np.minimum(rng.geometric(0.35, size=(h, w * ch_)) - 1, 255).astype(np.uint8)
+            rows = np.concatenate([rng.integers(0, 5, (h, 1), dtype=np.uint8), vals], 1)
+            for level, strategy, chunk in ((6, 0, 1 << 30), (9, zlib.Z_FILTERED, 4096), (1, zlib.Z_HUFFMAN_ONLY, 100), (6, zlib.Z_RLE, 7),
+                                           (6, zlib.Z_FIXED, 1 << 30), (0, 0, 5000)):
+                data = _container(rows.tobytes(), w, h, ctype, level, strategy, chunk)
+                yield f"handmade_{w}x{h}_c{ctype}_l{level}_s{strategy}_k{chunk}", data, np.asarray(Image.open(io.BytesIO(data)))
+    # copies of every short distance, overlapping their own output, in long dependent chains: row y repeats a random pattern
+    # of (y % 24) + 1 bytes; then rows that repeat earlier rows at distances of a few hundred to a few thousand bytes
+    for (w, h, ctype, ch_) in ((1200, 96, 0, 1), (401, 96, 2, 3), (16384, 3, 6, 4), (3, 4000, 2, 3)):
+        rb = w * ch_
+        body = np.empty((h, rb), np.uint8)
+        for y in range(h):
+            pat = rng.integers(0, 256, (y % 24) + 1, dtype=np.uint8)
+            body[y] = np.resize(pat, rb)
+        body[h // 2:] = body[: h - h // 2]
+        rows = np.concatenate([np.zeros((h, 1), np.uint8), body], 1)
+        for level in (6, 9):
+            data = _container(rows.tobytes(), w, h, ctype, level, 0, 1 << 30)
+            yield f"periodic_{w}x{h}_c{ctype}_l{level}", data, np.asarray(Image.open(io.BytesIO(data)))
+
+
 def refused():
     """Yields (name, file bytes, expected status): 1 = left to Pillow, 2 = damaged."""
     rng = np.random.default_rng(4)
@@ -49,6 +95,7 @@ def refused():
     Image.fromarray(rng.integers(0, 65535, (20, 30)).astype(np.uint16)).save(b, "PNG")
     yield "16bit", b.getvalue(), 1
     good = _save(rng.integers(0, 256, (40, 50, 3), dtype=np.uint8))
+    yield "bad_adler", good[:-17] + bytes([good[-17] ^ 0x40]) + good[-16:], 2     # last byte of the zlib trailer (IDAT's CRC and the 12 bytes of IEND follow)
     yield "truncated", good[: len(good) // 2], 2
     yield "bit_flip_in_idat", good[:100] + bytes([good[100] ^ 1]) + good[101:], 2
     yield "not_a_png", b"GIF89a" + bytes(64), 2

@@ -78,6 +78,9 @@ int ke_free(ke_ctx *ctx, void *dev_ptr);
  * pageable memory the runtime stages them through its own bounce buffer first.  ke_host_free waits for the context's stream. */
 int ke_host_alloc(ke_ctx *ctx, size_t bytes, void **host_ptr_out);
 int ke_host_free(ke_ctx *ctx, void *host_ptr);
+/* n separate host buffers (srcs[i], sizes[i] bytes) copied to dst + offsets[i] on the host's threads: how a list of files read
+ * one by one becomes the single `files` range the decoders take, without an interpreter-level loop over the files. */
+int ke_host_pack(uint8_t *dst, const uint8_t *const *srcs, const uint64_t *offsets, const uint64_t *sizes, int64_t n);
 int ke_memcpy(ke_ctx *ctx, void *dst, const void *src, size_t bytes);   /* any direction, synchronous */
 
 /* ---- hashing: replaces sig.phash.phash / dhash (src/sig/phash.py:21-57) as driven by

@@ -28,7 +28,7 @@ EXPORTS = (
     "ke_hash_images", "ke_hash_uniform", "ke_hash_images_ex", "ke_hash_uniform_ex", "ke_luma_tiles_uniform", "ke_hamming_scan",
     "ke_stage_create", "ke_stage_destroy", "ke_stage_acquire", "ke_stage_submit_hash", "ke_stage_wait",
     "ke_comm_unique_id", "ke_comm_create", "ke_comm_destroy", "ke_allgather_u64", "ke_allgather_hashes", "ke_allgather_edges",
-    "ke_interleave_shards", "ke_host_alloc", "ke_host_free", "ke_jpeg_probe", "ke_jpeg_decode", "ke_png_probe", "ke_png_decode", "ke_cluster_labels", "ke_ssim_pairs_uniform", "ke_ssim_pairs", "ke_ssim_set_mode", "ke_resize_luma_uniform", "ke_fit_luma_uniform", "ke_tile_ahash", "ke_sad_pairs", "ke_synth_rgb",
+    "ke_interleave_shards", "ke_host_alloc", "ke_host_free", "ke_host_pack", "ke_jpeg_probe", "ke_jpeg_decode", "ke_png_probe", "ke_png_decode", "ke_cluster_labels", "ke_ssim_pairs_uniform", "ke_ssim_pairs", "ke_ssim_set_mode", "ke_resize_luma_uniform", "ke_fit_luma_uniform", "ke_tile_ahash", "ke_sad_pairs", "ke_synth_rgb",
     "ke_synth_rgb_indexed",
     "ke_synth_hashes", "ke_last_kernel_ms",
 )
@@ -117,6 +117,7 @@ def load_library() -> C.CDLL:
         lib.ke_interleave_shards.argtypes = [vp, vp, i32, i64, vp]
         lib.ke_host_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
         lib.ke_host_free.argtypes = [vp, vp]
+        lib.ke_host_pack.argtypes = [vp, vp, vp, vp, i64]
         lib.ke_jpeg_probe.argtypes = [vp, vp, vp, i64, vp, vp, vp, vp]
         lib.ke_jpeg_decode.argtypes = [vp, vp, vp, vp, i64, vp, vp, vp]
         lib.ke_png_probe.argtypes = [vp, vp, vp, i64, vp, vp, vp, vp]
@@ -140,7 +141,7 @@ def load_library() -> C.CDLL:
                      "ke_hash_images", "ke_hash_uniform", "ke_hash_images_ex", "ke_hash_uniform_ex", "ke_luma_tiles_uniform", "ke_hamming_scan",
                      "ke_stage_create", "ke_stage_destroy", "ke_stage_acquire", "ke_stage_submit_hash", "ke_stage_wait",
                      "ke_comm_unique_id", "ke_comm_create", "ke_comm_destroy", "ke_allgather_u64", "ke_allgather_hashes", "ke_allgather_edges",
-                     "ke_interleave_shards", "ke_host_alloc", "ke_host_free", "ke_jpeg_probe", "ke_jpeg_decode", "ke_png_probe", "ke_png_decode", "ke_cluster_labels", "ke_ssim_pairs_uniform", "ke_ssim_pairs", "ke_ssim_set_mode", "ke_resize_luma_uniform", "ke_fit_luma_uniform", "ke_tile_ahash",
+                     "ke_interleave_shards", "ke_host_alloc", "ke_host_free", "ke_host_pack", "ke_jpeg_probe", "ke_jpeg_decode", "ke_png_probe", "ke_png_decode", "ke_cluster_labels", "ke_ssim_pairs_uniform", "ke_ssim_pairs", "ke_ssim_set_mode", "ke_resize_luma_uniform", "ke_fit_luma_uniform", "ke_tile_ahash",
                      "ke_sad_pairs", "ke_synth_rgb", "ke_synth_rgb_indexed", "ke_synth_hashes"):
             getattr(lib, name).restype = C.c_int
         _lib = lib
@@ -378,25 +379,12 @@ class Context:
             self._check(self._lib.ke_host_alloc(self._h, cap, C.byref(p)), "ke_host_alloc")
             self._pack_ptr, self._pack_cap = int(p.value), cap
         base = self._pack_ptr
-
-        def copy(lo, hi):
-            for i in range(lo, hi):
-                C.memmove(base + int(offsets[i]), blobs[i], len(blobs[i]))     # releases the GIL
-
-        n = len(blobs)
-        workers = min(8, max(1, total >> 26))
-        if workers > 1:
-            cuts = np.searchsorted(offsets, np.linspace(0, total, workers + 1)[1:-1]).tolist()
-            bounds = [0] + cuts + [n]
-            threads = [threading.Thread(target=copy, args=(bounds[k], bounds[k + 1])) for k in range(workers)]
-            for t in threads:
-                t.start()
-            for t in threads:
-                t.join()
-        else:
-            copy(0, n)
-        C.memset(base + total - 64, 0, 64)
         flat = np.ctypeslib.as_array((C.c_uint8 * total).from_address(base))
+        n = len(blobs)
+        srcs = (C.c_char_p * n)(*blobs)                    # the buffers of the bytes objects themselves, no copies
+        if self._lib.ke_host_pack(base, srcs, _addr(offsets), _addr(sizes), n) != KE_OK:
+            raise ValueError("ke_host_pack: bad arguments")
+        C.memset(base + total - 64, 0, 64)
         return flat, offsets, sizes
 
     def jpeg_probe(self, blobs, kind: str = "jpeg"):

@@ -285,6 +285,14 @@ KE_API int ke_host_alloc(ke_ctx *ctx, size_t bytes, void **out) {
     return KE_OK;
 }
 
+KE_API int ke_host_pack(uint8_t *dst, const uint8_t *const *srcs, const uint64_t *offsets, const uint64_t *sizes, int64_t n) {
+    if (n < 0 || (n > 0 && (!dst || !srcs || !offsets || !sizes))) return KE_EINVAL;
+    ke_parallel_ranges(n, [=](int64_t lo, int64_t hi, int) {
+        for (int64_t i = lo; i < hi; ++i) std::memcpy(dst + offsets[i], srcs[i], (size_t)sizes[i]);
+    });
+    return KE_OK;
+}
+
 KE_API int ke_host_free(ke_ctx *ctx, void *p) {
     if (!ctx) return KE_EINVAL;
     KE_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -7,6 +7,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <thread>
 #include <tuple>
 #include <utility>
 #include <vector>
@@ -204,3 +205,17 @@ int ke_launch_ssim(ke_ctx *ctx, const uint8_t *d_images, int w, int h, int chann
 int ke_launch_synth_rgb(ke_ctx *ctx, uint64_t seed, int64_t first, const int64_t *d_indices, int64_t n, int w, int h,
                         uint8_t *d_out);
 int ke_launch_synth_hashes(ke_ctx *ctx, uint64_t seed, int64_t n, uint64_t *d_out);
+
+// Host-side loops over the files of a batch (header parsing): [0, n) cut into contiguous ranges, one per thread; fn(lo, hi, t).
+// KE_HOST_THREADS overrides the thread count (default: the hardware's, at most 16, at least 256 items per thread).
+template <typename Fn>
+static inline int ke_parallel_ranges(int64_t n, Fn fn) {
+    int want = (int)std::thread::hardware_concurrency();
+    if (const char *e = std::getenv("KE_HOST_THREADS")) want = std::atoi(e);
+    int nt = (int)std::min<int64_t>(std::max(want, 1), std::min<int64_t>(16, n / 256));
+    if (nt <= 1) { fn((int64_t)0, n, 0); return 1; }
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; ++t) th.emplace_back([=]() { fn(n * t / nt, n * (t + 1) / nt, t); });
+    for (auto &x : th) x.join();
+    return nt;
+}

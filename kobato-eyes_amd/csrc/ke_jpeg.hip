@@ -326,14 +326,16 @@ __global__ __launch_bounds__(256) void ke_jpeg_colour(const KeJpegDev *__restric
 KE_API int ke_jpeg_probe(const uint8_t *files, const uint64_t *offsets, const uint64_t *sizes, int64_t n, int32_t *widths,
                          int32_t *heights, int32_t *channels, int32_t *status_out) {
     if (n < 0 || (n > 0 && (!files || !offsets || !sizes || !widths || !heights || !channels || !status_out))) return KE_EINVAL;
-    KeJpegTables tables;
-    for (int64_t i = 0; i < n; ++i) {
-        KeJpegInfo info;
-        ke_parse_jpeg(files + offsets[i], (size_t)sizes[i], tables, info, false);     // headers only
-        widths[i] = info.width; heights[i] = info.height; channels[i] = info.ncomp;
-        status_out[i] = info.status;
-        if (tables.pool.size() > 64) { tables.pool.clear(); tables.keys.clear(); }
-    }
+    ke_parallel_ranges(n, [=](int64_t lo, int64_t hi, int) {
+        KeJpegTables tables;
+        for (int64_t i = lo; i < hi; ++i) {
+            KeJpegInfo info;
+            ke_parse_jpeg(files + offsets[i], (size_t)sizes[i], tables, info, false);     // headers only
+            widths[i] = info.width; heights[i] = info.height; channels[i] = info.ncomp;
+            status_out[i] = info.status;
+            if (tables.pool.size() > 64) { tables.pool.clear(); tables.keys.clear(); }
+        }
+    });
     return KE_OK;
 }
 
@@ -349,22 +351,50 @@ KE_API int ke_jpeg_decode(ke_ctx *ctx, const uint8_t *files, const uint64_t *off
         if (ke_is_device_ptr(p)) return ke_fail(ctx, KE_EINVAL, "offsets/sizes/status are host arrays");
     KE_HIP(ctx, hipSetDevice(ctx->device));
     // ---- host: headers, Huffman tables, geometry
-    KeJpegTables tables;
+    // (on the host's threads: a header costs a few microseconds -- marker walk, Huffman tables, the search for the end of the
+    // scan -- which at 65 536 files is more than the kernels take)
+    struct Part {
+        KeJpegTables tables;
+        std::vector<KeJpegDev> devs;
+        std::vector<int64_t> which;
+        uint64_t lo = ~0ull, hi = 0;
+    };
+    std::vector<Part> parts(16);
+    const int nparts = ke_parallel_ranges(n, [&](int64_t first, int64_t last, int t) {
+        Part &p = parts[(size_t)t];
+        for (int64_t i = first; i < last; ++i) {
+            KeJpegDev d;
+            ke_parse_jpeg(files + offsets[i], (size_t)sizes[i], p.tables, d.info);
+            status_out[i] = d.info.status;
+            if (d.info.status != KE_JPEG_OK) continue;
+            d.file_off = offsets[i];
+            d.out_off = out_offsets[i];
+            p.lo = std::min(p.lo, offsets[i]);
+            p.hi = std::max(p.hi, offsets[i] + sizes[i]);
+            p.devs.push_back(d);
+            p.which.push_back(i);
+        }
+    });
+    KeJpegTables tables;                              // one pool for the batch: every part's tables interned again
     std::vector<KeJpegDev> devs;
     std::vector<int64_t> which;                       // batch position of every decodable image
-    devs.reserve((size_t)n);
     uint64_t lo = ~0ull, hi = 0;
-    for (int64_t i = 0; i < n; ++i) {
-        KeJpegDev d;
-        ke_parse_jpeg(files + offsets[i], (size_t)sizes[i], tables, d.info);
-        status_out[i] = d.info.status;
-        if (d.info.status != KE_JPEG_OK) continue;
-        d.file_off = offsets[i];
-        d.out_off = out_offsets[i];
-        lo = std::min(lo, offsets[i]);
-        hi = std::max(hi, offsets[i] + sizes[i]);
-        devs.push_back(d);
-        which.push_back(i);
+    for (int t = 0; t < nparts; ++t) {
+        Part &p = parts[(size_t)t];
+        std::vector<int> remap(p.tables.keys.size());
+        for (size_t k = 0; k < remap.size(); ++k) {
+            const std::vector<uint8_t> &key = p.tables.keys[k];
+            remap[k] = tables.intern(key.data(), key.data() + 16, (int)key.size() - 16);
+        }
+        for (KeJpegDev &d : p.devs)
+            for (int c = 0; c < d.info.ncomp; ++c) {
+                d.info.huff_dc[c] = remap[(size_t)d.info.huff_dc[c]];
+                d.info.huff_ac[c] = remap[(size_t)d.info.huff_ac[c]];
+            }
+        devs.insert(devs.end(), p.devs.begin(), p.devs.end());
+        which.insert(which.end(), p.which.begin(), p.which.end());
+        lo = std::min(lo, p.lo);
+        hi = std::max(hi, p.hi);
     }
     if (devs.empty()) return KE_OK;
     // compressed bytes of the decodable files (one contiguous range of the caller's buffer) -> device

@@ -436,12 +436,14 @@ __global__ __launch_bounds__(64) void ke_png_unfilter(const KePngDev *__restrict
 KE_API int ke_png_probe(const uint8_t *files, const uint64_t *offsets, const uint64_t *sizes, int64_t n, int32_t *widths,
                         int32_t *heights, int32_t *channels, int32_t *status_out) {
     if (n < 0 || (n > 0 && (!files || !offsets || !sizes || !widths || !heights || !channels || !status_out))) return KE_EINVAL;
-    for (int64_t i = 0; i < n; ++i) {
-        KePngInfo info;
-        ke_parse_png(files + offsets[i], (size_t)sizes[i], nullptr, info);
-        widths[i] = info.width; heights[i] = info.height; channels[i] = info.channels;
-        status_out[i] = info.status;
-    }
+    ke_parallel_ranges(n, [=](int64_t lo, int64_t hi, int) {
+        for (int64_t i = lo; i < hi; ++i) {
+            KePngInfo info;
+            ke_parse_png(files + offsets[i], (size_t)sizes[i], nullptr, info);
+            widths[i] = info.width; heights[i] = info.height; channels[i] = info.channels;
+            status_out[i] = info.status;
+        }
+    });
     return KE_OK;
 }
 
@@ -457,23 +459,41 @@ KE_API int ke_png_decode(ke_ctx *ctx, const uint8_t *files, const uint64_t *offs
         if (ke_is_device_ptr(p)) return ke_fail(ctx, KE_EINVAL, "offsets/sizes/status are host arrays");
     KE_HIP(ctx, hipSetDevice(ctx->device));
     // ---- host: containers (chunk walk, CRCs of the header chunks), where each image's IDAT payloads lie
+    // (on the host's threads, as for JPEG)
     struct Item { KePngDev d; size_t seg0, seg1; int64_t which; };
+    struct Part {
+        std::vector<Item> items;
+        std::vector<KePngSeg> segs;
+        uint64_t lo = ~0ull, hi = 0;
+    };
+    std::vector<Part> parts(16);
+    const int nparts = ke_parallel_ranges(n, [&](int64_t first, int64_t last, int t) {
+        Part &p = parts[(size_t)t];
+        for (int64_t i = first; i < last; ++i) {
+            Item it;
+            it.seg0 = p.segs.size();
+            ke_parse_png(files + offsets[i], (size_t)sizes[i], &p.segs, it.d.info);
+            status_out[i] = it.d.info.status;
+            if (it.d.info.status != KE_PNG_OK) continue;
+            it.seg1 = p.segs.size();
+            for (size_t s = it.seg0; s < it.seg1; ++s) p.segs[s].off += offsets[i];      // now relative to `files`
+            it.d.out_off = out_offsets[i];
+            it.which = i;
+            p.lo = std::min(p.lo, offsets[i]);
+            p.hi = std::max(p.hi, offsets[i] + sizes[i]);
+            p.items.push_back(it);
+        }
+    });
     std::vector<Item> items;
     std::vector<KePngSeg> segs;
     uint64_t lo = ~0ull, hi = 0;
-    for (int64_t i = 0; i < n; ++i) {
-        Item it;
-        it.seg0 = segs.size();
-        ke_parse_png(files + offsets[i], (size_t)sizes[i], &segs, it.d.info);
-        status_out[i] = it.d.info.status;
-        if (it.d.info.status != KE_PNG_OK) continue;
-        it.seg1 = segs.size();
-        for (size_t s = it.seg0; s < it.seg1; ++s) segs[s].off += offsets[i];      // now relative to `files`
-        it.d.out_off = out_offsets[i];
-        it.which = i;
-        lo = std::min(lo, offsets[i]);
-        hi = std::max(hi, offsets[i] + sizes[i]);
-        items.push_back(it);
+    for (int t = 0; t < nparts; ++t) {
+        Part &p = parts[(size_t)t];
+        for (Item &it : p.items) { it.seg0 += segs.size(); it.seg1 += segs.size(); }
+        items.insert(items.end(), p.items.begin(), p.items.end());
+        segs.insert(segs.end(), p.segs.begin(), p.segs.end());
+        lo = std::min(lo, p.lo);
+        hi = std::max(hi, p.hi);
     }
     if (items.empty()) return KE_OK;
     // lanes of one wave finish together at best: neighbours in the batch should have streams of like length

@@ -11,10 +11,9 @@
 
 #include "ke_png_core.h"
 
-static inline const uint32_t *ke_crc_tables() {
-    static uint32_t t[4][256];
-    static bool ready = false;
-    if (!ready) {
+struct KeCrcTables {
+    uint32_t t[4][256];
+    KeCrcTables() {
         for (uint32_t i = 0; i < 256; ++i) {
             uint32_t c = i;
             for (int k = 0; k < 8; ++k) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
@@ -22,9 +21,12 @@ static inline const uint32_t *ke_crc_tables() {
         }
         for (uint32_t i = 0; i < 256; ++i)
             for (int k = 1; k < 4; ++k) t[k][i] = (t[k - 1][i] >> 8) ^ t[0][t[k - 1][i] & 0xFF];
-        ready = true;
     }
-    return &t[0][0];
+};
+
+static inline const uint32_t *ke_crc_tables() {
+    static const KeCrcTables tables;                 // initialised once, also when several parsing threads get here together
+    return &tables.t[0][0];
 }
 
 static inline uint32_t ke_crc32(uint32_t crc, const uint8_t *p, size_t n) {

@@ -152,7 +152,37 @@ def main():
     ctx.set_stream(stream.cuda_stream)
     # the exchange steps: ke_allgather_hashes / ke_allgather_edges on the library's own RCCL communicator (the process
     # group only carried the unique id)
-    exchange = RcclExchange(ctx) if distributed and not args.torch_collectives else None
+    exchange = None
+    if distributed and not args.torch_collectives:
+        # made and rehearsed before anything is timed: a small table through ke_allgather_hashes against torch's own
+        # all-gather.  Should the library's communicator fail on any rank (or disagree), every rank takes the
+        # torch.distributed route instead -- both are RCCL, the JSON line says which one ran.
+        ok = 1
+        try:
+            exchange = RcclExchange(ctx)
+            n_try = 4099 * world
+            per_try = (n_try + world - 1) // world
+            mine_try = torch.arange(rank, n_try, world, dtype=torch.int64, device=dev) * 0x1E3779B97F4A7C15   # wraps; any values do
+            local_try = torch.zeros(per_try, dtype=torch.int64, device=dev)
+            local_try[: mine_try.numel()] = mine_try
+            table_try = torch.empty(n_try, dtype=torch.int64, device=dev)
+            exchange.hashes(local_try.data_ptr(), n_try, table_try.data_ptr())
+            torch.cuda.synchronize()
+            if not torch.equal(table_try, allgather_hashes(local_try, n_try)):
+                raise RuntimeError("ke_allgather_hashes disagrees with torch.distributed.all_gather_into_tensor")
+        except Exception as exc:   # noqa: BLE001 - any failure here only selects the other exchange
+            print(f"[bench] rank {rank}: library RCCL exchange unavailable ({exc}); using torch.distributed", file=sys.stderr)
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0 and exchange is not None:
+            try:
+                exchange.close()
+            except Exception:   # noqa: BLE001
+                pass
+            exchange = None
+        elif int(flag.item()) == 0:
+            exchange = None
 
     n_total, side = args.images, args.side
     img_bytes = side * side * 3

@@ -27,4 +27,13 @@ done
 # 4. the scan alone at several table sizes (N = 1 000 000 is BASELINE configs[3]'s table), the streaming-read ceiling
 run python3 "$root/benchmarks/scan_sizes.py" > "$out/${tag}_scan_sizes.jsonl" 2> "$out/${tag}_scan_sizes.err"
 if [ -x "$root/benchmarks/micro/hbm_read.bin" ]; then run "$root/benchmarks/micro/hbm_read.bin" > "$out/${tag}_hbm_read.txt" 2>&1; fi
+# 5. the decode step in front of the path: JPEG and PNG rates per batch size, kernel statistics of one batch of each
+D="$root/benchmarks/bench_jpeg.py"
+: > "$out/${tag}_decode.jsonl"
+for spec in "jpeg corpus 4096" "jpeg corpus 16384" "jpeg corpus 65536" "png corpus 4096" "png corpus 16384" "png drawing 4096" "png drawing 16384" "png drawing 65536"; do
+    set -- $spec
+    run python3 "$D" --format "$1" --content "$2" --images "$3" >> "$out/${tag}_decode.jsonl" 2>> "$out/${tag}_decode.err"
+done
+run rocprofv3 --kernel-trace --stats --output-format csv -d "$out/${tag}_stats_png" -- python3 "$D" --format png --images 4096 > "$out/${tag}_stats_png.log" 2>&1
+run rocprofv3 --kernel-trace --stats --output-format csv -d "$out/${tag}_stats_jpeg" -- python3 "$D" --format jpeg --images 16384 > "$out/${tag}_stats_jpeg.log" 2>&1
 ls "$out" | grep "^${tag}_" | head -40

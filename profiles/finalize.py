@@ -21,6 +21,10 @@ for name in (f"{tag}_bench.json", f"{tag}_bench_ssim095.json"):
     open(os.path.join(here, name), "w").write(line)
 for name, keep in ((f"{tag}_scan_sizes.jsonl", lambda l: l.startswith("{")), (f"{tag}_hbm_read.txt", lambda l: not l.startswith(("==", "rc=")))):
     open(os.path.join(here, name), "w").writelines(l for l in open(os.path.join(g, name)) if keep(l))
+if os.path.exists(os.path.join(g, f"{tag}_decode.jsonl")):
+    open(os.path.join(here, f"{tag}_decode.jsonl"), "w").writelines(l for l in open(os.path.join(g, f"{tag}_decode.jsonl")) if l.startswith("{"))
+    for fmt in ("png", "jpeg"):
+        shutil.copy(newest(os.path.join(g, f"{tag}_stats_{fmt}", "**", "*_kernel_stats.csv")), os.path.join(here, f"{tag}_{fmt}_decode_kernel_stats.csv"))
 h = json.load(open(os.path.join(here, f"{tag}_pmc.json")))["hash"]
 json.dump({"kernel": "ke_phash_fused_mx<8,5,false,false,3,false>", "images_per_launch": 100000, "side": 512,
            "source": f"profiles/{tag}_pmc.json: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, bench.py --steps 2 --warmup 1 "

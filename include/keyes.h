@@ -81,6 +81,13 @@ int ke_host_free(ke_ctx *ctx, void *host_ptr);
 /* n separate host buffers (srcs[i], sizes[i] bytes) copied to dst + offsets[i] on the host's threads: how a list of files read
  * one by one becomes the single `files` range the decoders take, without an interpreter-level loop over the files. */
 int ke_host_pack(uint8_t *dst, const uint8_t *const *srcs, const uint64_t *offsets, const uint64_t *sizes, int64_t n);
+/* The files at paths[0..n) read back to back into dst (capacity bytes, normally page-locked) on the host's threads: what
+ * `Image.open(path)` of the reference's worker (src/core/fastsig.py:31) does for the bytes, for a whole batch at once.
+ * offsets[i] / sizes[i] locate file i; a file that cannot be read has size 0 (the decoders report it as damaged, the caller
+ * drops it as the reference drops a file that raises).  *needed_out = bytes the batch needs; when that exceeds capacity nothing
+ * is read and KE_ENOMEM comes back, so that the caller can grow the buffer and call again. */
+int ke_host_read_files(const char *const *paths, int64_t n, uint8_t *dst, uint64_t capacity, uint64_t *offsets, uint64_t *sizes,
+                       uint64_t *needed_out);
 int ke_memcpy(ke_ctx *ctx, void *dst, const void *src, size_t bytes);   /* any direction, synchronous */
 
 /* ---- hashing: replaces sig.phash.phash / dhash (src/sig/phash.py:21-57) as driven by

@@ -28,7 +28,7 @@ EXPORTS = (
     "ke_hash_images", "ke_hash_uniform", "ke_hash_images_ex", "ke_hash_uniform_ex", "ke_luma_tiles_uniform", "ke_hamming_scan",
     "ke_stage_create", "ke_stage_destroy", "ke_stage_acquire", "ke_stage_submit_hash", "ke_stage_wait",
     "ke_comm_unique_id", "ke_comm_create", "ke_comm_destroy", "ke_allgather_u64", "ke_allgather_hashes", "ke_allgather_edges",
-    "ke_interleave_shards", "ke_host_alloc", "ke_host_free", "ke_host_pack", "ke_jpeg_probe", "ke_jpeg_decode", "ke_png_probe", "ke_png_decode", "ke_cluster_labels", "ke_ssim_pairs_uniform", "ke_ssim_pairs", "ke_ssim_set_mode", "ke_resize_luma_uniform", "ke_fit_luma_uniform", "ke_tile_ahash", "ke_sad_pairs", "ke_synth_rgb",
+    "ke_interleave_shards", "ke_host_alloc", "ke_host_free", "ke_host_pack", "ke_host_read_files", "ke_jpeg_probe", "ke_jpeg_decode", "ke_png_probe", "ke_png_decode", "ke_cluster_labels", "ke_ssim_pairs_uniform", "ke_ssim_pairs", "ke_ssim_set_mode", "ke_resize_luma_uniform", "ke_fit_luma_uniform", "ke_tile_ahash", "ke_sad_pairs", "ke_synth_rgb",
     "ke_synth_rgb_indexed",
     "ke_synth_hashes", "ke_last_kernel_ms",
 )
@@ -118,6 +118,7 @@ def load_library() -> C.CDLL:
         lib.ke_host_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
         lib.ke_host_free.argtypes = [vp, vp]
         lib.ke_host_pack.argtypes = [vp, vp, vp, vp, i64]
+        lib.ke_host_read_files.argtypes = [vp, i64, vp, C.c_uint64, vp, vp, C.POINTER(C.c_uint64)]
         lib.ke_jpeg_probe.argtypes = [vp, vp, vp, i64, vp, vp, vp, vp]
         lib.ke_jpeg_decode.argtypes = [vp, vp, vp, vp, i64, vp, vp, vp]
         lib.ke_png_probe.argtypes = [vp, vp, vp, i64, vp, vp, vp, vp]
@@ -141,7 +142,7 @@ def load_library() -> C.CDLL:
                      "ke_hash_images", "ke_hash_uniform", "ke_hash_images_ex", "ke_hash_uniform_ex", "ke_luma_tiles_uniform", "ke_hamming_scan",
                      "ke_stage_create", "ke_stage_destroy", "ke_stage_acquire", "ke_stage_submit_hash", "ke_stage_wait",
                      "ke_comm_unique_id", "ke_comm_create", "ke_comm_destroy", "ke_allgather_u64", "ke_allgather_hashes", "ke_allgather_edges",
-                     "ke_interleave_shards", "ke_host_alloc", "ke_host_free", "ke_host_pack", "ke_jpeg_probe", "ke_jpeg_decode", "ke_png_probe", "ke_png_decode", "ke_cluster_labels", "ke_ssim_pairs_uniform", "ke_ssim_pairs", "ke_ssim_set_mode", "ke_resize_luma_uniform", "ke_fit_luma_uniform", "ke_tile_ahash",
+                     "ke_interleave_shards", "ke_host_alloc", "ke_host_free", "ke_host_pack", "ke_host_read_files", "ke_jpeg_probe", "ke_jpeg_decode", "ke_png_probe", "ke_png_decode", "ke_cluster_labels", "ke_ssim_pairs_uniform", "ke_ssim_pairs", "ke_ssim_set_mode", "ke_resize_luma_uniform", "ke_fit_luma_uniform", "ke_tile_ahash",
                      "ke_sad_pairs", "ke_synth_rgb", "ke_synth_rgb_indexed", "ke_synth_hashes"):
             getattr(lib, name).restype = C.c_int
         _lib = lib
@@ -363,13 +364,7 @@ class Context:
         flat = np.frombuffer(b"".join(blobs) + bytes(64), np.uint8)     # one C-level copy; the decoder takes any alignment
         return flat, offsets, sizes
 
-    def _pack_blobs_pinned(self, blobs):
-        """The files back to back in the context's page-locked buffer (grown on demand, reused from call to call): the copy
-        to the device then runs at link speed.  Call with the lock held; the buffer is busy until the decode has returned."""
-        sizes = np.fromiter((len(b) for b in blobs), np.uint64, len(blobs))
-        offsets = np.zeros(len(blobs), np.uint64)
-        offsets[1:] = np.cumsum(sizes[:-1])
-        total = int(sizes.sum()) + 64
+    def _grow_pack(self, total: int) -> None:
         if total > self._pack_cap:
             if self._pack_ptr:
                 self._check(self._lib.ke_host_free(self._h, self._pack_ptr), "ke_host_free")
@@ -378,6 +373,32 @@ class Context:
             p = C.c_void_p()
             self._check(self._lib.ke_host_alloc(self._h, cap, C.byref(p)), "ke_host_alloc")
             self._pack_ptr, self._pack_cap = int(p.value), cap
+
+    def _read_files_pinned(self, paths):
+        """The files themselves, read by the library's host threads straight into the page-locked buffer (no bytes objects, no
+        interpreter loop over the files); unreadable files get size 0.  Call with the lock held."""
+        n = len(paths)
+        names = (C.c_char_p * n)(*[os.fsencode(p) for p in paths])
+        offsets, sizes = np.zeros(n, np.uint64), np.zeros(n, np.uint64)
+        needed = C.c_uint64(0)
+        rc = self._lib.ke_host_read_files(names, n, self._pack_ptr, self._pack_cap, _addr(offsets), _addr(sizes), C.byref(needed))
+        if rc == -4:                                       # KE_ENOMEM: the buffer is too small for this batch
+            self._grow_pack(int(needed.value))
+            rc = self._lib.ke_host_read_files(names, n, self._pack_ptr, self._pack_cap, _addr(offsets), _addr(sizes), C.byref(needed))
+        if rc != KE_OK:
+            raise ValueError("ke_host_read_files: bad arguments")
+        total = int(needed.value)
+        flat = np.ctypeslib.as_array((C.c_uint8 * total).from_address(self._pack_ptr))
+        return flat, offsets, sizes
+
+    def _pack_blobs_pinned(self, blobs):
+        """The files back to back in the context's page-locked buffer (grown on demand, reused from call to call): the copy
+        to the device then runs at link speed.  Call with the lock held; the buffer is busy until the decode has returned."""
+        sizes = np.fromiter((len(b) for b in blobs), np.uint64, len(blobs))
+        offsets = np.zeros(len(blobs), np.uint64)
+        offsets[1:] = np.cumsum(sizes[:-1])
+        total = int(sizes.sum()) + 64
+        self._grow_pack(total)
         base = self._pack_ptr
         flat = np.ctypeslib.as_array((C.c_uint8 * total).from_address(base))
         n = len(blobs)
@@ -408,14 +429,14 @@ class Context:
     def png_hash(self, blobs, *, want_dhash=True):
         return self.jpeg_hash(blobs, want_dhash=want_dhash, kind="png")
 
-    def _jpeg_to_device(self, blobs, kind: str = "jpeg"):
+    def _jpeg_to_device(self, blobs, kind: str = "jpeg", *, paths=None):
         """Decode what the GPU decoder takes into the context's decode buffer (device memory, grown on demand and kept:
         allocating tens of GB per call costs up to a second): (device ptr or 0, byte offsets, widths, heights, channels,
         status).  Call with the lock held and keep it until the pixels have been used."""
-        n = len(blobs)
+        n = len(blobs) if paths is None else len(paths)
         w, h, c, st = (np.zeros(n, np.int32) for _ in range(4))
         with self._lock:
-            flat, offsets, sizes = self._pack_blobs_pinned(blobs)
+            flat, offsets, sizes = self._pack_blobs_pinned(blobs) if paths is None else self._read_files_pinned(paths)
             rc = getattr(self._lib, f"ke_{kind}_probe")(_addr(flat), _addr(offsets), _addr(sizes), n, _addr(w), _addr(h), _addr(c), _addr(st))
             if rc != KE_OK:
                 raise ValueError(f"ke_{kind}_probe: bad arguments")
@@ -460,16 +481,20 @@ class Context:
                     out[i] = arr
         return out, st
 
-    def jpeg_hash(self, blobs, *, want_dhash=True, kind: str = "jpeg"):
+    def hash_files(self, paths, *, want_dhash=True, kind: str = "jpeg"):
+        """jpeg_hash for files on disk: read (host threads, page-locked buffer), decoded and hashed on the GPU."""
+        return self.jpeg_hash(None, want_dhash=want_dhash, kind=kind, paths=list(paths))
+
+    def jpeg_hash(self, blobs, *, want_dhash=True, kind: str = "jpeg", paths=None):
         """pHash / dHash of JPEG files, decoded and hashed without the pixels leaving the GPU.  Returns (phash u64[n],
         dhash u64[n] | None, status int32[n]); status != 0 = not handled here (decode the file with Pillow)."""
-        n = len(blobs)
+        n = len(blobs) if paths is None else len(paths)
         ph = np.zeros(n, np.uint64)
         dh = np.zeros(n, np.uint64) if want_dhash else None
         if n == 0:
             return ph, dh, np.zeros(0, np.int32)
         with self._lock:
-            dev, out_off, w, h, c, st = self._jpeg_to_device(blobs, kind)
+            dev, out_off, w, h, c, st = self._jpeg_to_device(blobs, kind, paths=paths)
             for ch in (1, 3, 4):
                 idx = np.nonzero((st == 0) & (c == ch))[0]
                 if len(idx) == 0:

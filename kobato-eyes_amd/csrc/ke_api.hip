@@ -8,6 +8,10 @@
 #include <numeric>
 #include <unordered_map>
 
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include "ke_internal.h"
 
 static thread_local std::string g_create_err;
@@ -290,6 +294,47 @@ KE_API int ke_host_pack(uint8_t *dst, const uint8_t *const *srcs, const uint64_t
     ke_parallel_ranges(n, [=](int64_t lo, int64_t hi, int) {
         for (int64_t i = lo; i < hi; ++i) std::memcpy(dst + offsets[i], srcs[i], (size_t)sizes[i]);
     });
+    return KE_OK;
+}
+
+KE_API int ke_host_read_files(const char *const *paths, int64_t n, uint8_t *dst, uint64_t capacity, uint64_t *offsets, uint64_t *sizes,
+                              uint64_t *needed_out) {
+    if (n < 0 || (n > 0 && (!paths || !offsets || !sizes)) || !needed_out) return KE_EINVAL;
+    // sizes first (a file that cannot be opened or is not a regular file counts 0 bytes), then the layout, then the bytes
+    std::vector<int> fds((size_t)n, -1);
+    ke_parallel_ranges(n, [&](int64_t lo, int64_t hi, int) {
+        for (int64_t i = lo; i < hi; ++i) {
+            sizes[i] = 0;
+            const int fd = paths[i] ? ::open(paths[i], O_RDONLY | O_CLOEXEC) : -1;
+            if (fd < 0) continue;
+            struct stat st;
+            if (::fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size <= 0) { ::close(fd); continue; }
+            sizes[i] = (uint64_t)st.st_size;
+            fds[(size_t)i] = fd;
+        }
+    });
+    uint64_t at = 0;
+    for (int64_t i = 0; i < n; ++i) { offsets[i] = at; at += sizes[i]; }
+    *needed_out = at + 64;
+    const bool fits = dst && at + 64 <= capacity;
+    ke_parallel_ranges(n, [&](int64_t lo, int64_t hi, int) {
+        for (int64_t i = lo; i < hi; ++i) {
+            const int fd = fds[(size_t)i];
+            if (fd < 0) continue;
+            if (fits) {
+                uint64_t got = 0;
+                while (got < sizes[i]) {
+                    const ssize_t r = ::read(fd, dst + offsets[i] + got, (size_t)(sizes[i] - got));
+                    if (r <= 0) break;
+                    got += (uint64_t)r;
+                }
+                if (got != sizes[i]) std::memset(dst + offsets[i], 0, (size_t)sizes[i]);      // a short read: not a decodable file
+            }
+            ::close(fd);
+        }
+    });
+    if (!fits) return KE_ENOMEM;
+    std::memset(dst + at, 0, 64);
     return KE_OK;
 }
 

@@ -34,6 +34,23 @@ Task = Tuple[int, str]
 Row = Tuple[int, int, int]
 
 
+def _usable_cpus() -> int:
+    """CPUs this process may actually use: the affinity mask and the cgroup's quota, not the machine's core count (the
+    reference's `os.cpu_count() - 1` default starts 255 decode threads on a 16-CPU share of a large host)."""
+    n = os.cpu_count() or 4
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def _to_signed64(x: int) -> int:
     v = int(x) & U64MASK
     return v - (1 << 64) if v >> 63 else v
@@ -92,6 +109,10 @@ class _GpuStage:
         ``ke_hash_images``); status != 0: the decoder leaves the file to Pillow."""
         return self.ctx.jpeg_hash(blobs, want_dhash=True, kind=kind)
 
+    def hash_files(self, paths, kind: str = "jpeg"):
+        """jpeg_hash for files on disk: the library reads them (host threads, page-locked memory), no bytes objects."""
+        return self.ctx.hash_files(paths, want_dhash=True, kind=kind)
+
     def hash_one(self, arr):
         """(phash, dhash) or None for an image that did not fit a staging buffer."""
         ph, dh, ok = _phash.hash_batch([arr], want_dhash=True, device=self.device)
@@ -102,23 +123,27 @@ _make_stage = _GpuStage
 
 
 class _Pipeline:
-    """decode (threads) -> pinned staging buffer -> H2D + hash (GPU), without a host-side copy in between.
+    """decode (threads) -> pinned staging buffer -> H2D + hash (GPU), without a host-side copy in between; JPEG and PNG files
+    decoded on the GPU instead.
 
-    Files are taken ``chunk`` at a time.  The decode threads of chunk k write their pixels straight into one of the
-    context's two page-locked staging buffers (``ke_stage_acquire``; a bump allocator hands out 16-byte aligned
-    regions); ``ke_stage_submit_hash`` then enqueues the copy and the kernels and returns, so chunk k+1 is decoded into
-    the other buffer while chunk k crosses PCIe and is hashed.  An image that does not fit what is left of a buffer is
-    hashed on its own through ``ke_hash_images``.
+    Files are taken ``KE_GPU_BATCH`` (default 8192) at a time.  Within such a batch:
 
-    JPEG and PNG files (by suffix) skip Pillow altogether: the threads only read the bytes, ``ke_jpeg_decode`` /
-    ``ke_png_decode`` decode the chunk's files on the GPU -- pixel-identical to ``Image.open`` for baseline JPEGs and for 8-bit
-    L / RGB / RGBA PNGs -- and the hash kernels run on the decoded pixels where they lie.  Files the decoders refuse
-    (progressive, CMYK, palette, 16-bit, damaged ...) take the Pillow route after all.  ``KE_GPU_JPEG=0`` / ``KE_GPU_PNG=0``
-    turn the routes off.
+    * JPEG and PNG files (by suffix) skip Pillow altogether: the threads only read the bytes -- the next batch's files while
+      this one is on the GPU -- and ONE ``ke_jpeg_decode`` / ``ke_png_decode`` call per kind decodes them all, pixel-identical to
+      ``Image.open`` for baseline JPEGs and for 8-bit L / RGB / RGBA PNGs; the hash kernels run on the decoded pixels where
+      they lie.  The batch is large because those decoders are one thread per image: a wave of 64 files takes as long as
+      thousands of waves side by side.  ``KE_GPU_JPEG=0`` / ``KE_GPU_PNG=0`` turn the routes off.
+    * every other file, and what the GPU decoders refuse (progressive, CMYK, palette, 16-bit, damaged ...), is decoded by
+      Pillow on the thread pool ``chunk`` files at a time: the threads of chunk k write their pixels straight into one of the
+      context's two page-locked staging buffers (``ke_stage_acquire``; a bump allocator hands out 16-byte aligned regions);
+      ``ke_stage_submit_hash`` then enqueues the copy and the kernels and returns, so chunk k+1 is decoded into the other
+      buffer while chunk k crosses PCIe and is hashed.  An image that does not fit what is left of a buffer is hashed on its
+      own through ``ke_hash_images``.
     """
 
     def __init__(self, tasks: Sequence[Task], workers: int, chunk: int, device: int) -> None:
         self.tasks, self.chunk, self.device = tasks, max(1, int(chunk)), device
+        self.batch = max(self.chunk, int(os.environ.get("KE_GPU_BATCH", "8192")))
         self.pool = ThreadPoolExecutor(max_workers=max(1, workers))
         self.stage = _make_stage(device, int(os.environ.get("KE_STAGE_BYTES", str(256 << 20))), self.chunk)
 
@@ -138,83 +163,96 @@ class _Pipeline:
         h, w = arr.shape[:2]
         return (off, w, h, 1 if arr.ndim == 2 else arr.shape[2])
 
-    def _start(self, start: int):
-        slot, view = self.stage.acquire()
-        alloc = {"lock": threading.Lock(), "cursor": 0}
+    # ---- the GPU decoders' share of a batch
+    def _start_reads(self, start: int) -> dict:
+        """position -> (kind, future of the file's bytes) for the JPEG / PNG files of the batch that begins at ``start``."""
         gpu_jpeg = os.environ.get("KE_GPU_JPEG", "1") != "0"
         gpu_png = os.environ.get("KE_GPU_PNG", "1") != "0"
-        futures = []
-        for _, p in self.tasks[start:start + self.chunk]:
-            low = str(p).lower()
+        by_path = hasattr(self.stage, "hash_files")          # the library reads the files itself: nothing to start here
+        reads = {}
+        for k in range(start, min(start + self.batch, len(self.tasks))):
+            low = str(self.tasks[k][1]).lower()
             if gpu_jpeg and low.endswith(JPEG_SUFFIXES):
-                futures.append(("jpeg", p, self.pool.submit(_read_bytes, p)))
+                reads[k] = ("jpeg", None if by_path else self.pool.submit(_read_bytes, self.tasks[k][1]))
             elif gpu_png and low.endswith(PNG_SUFFIXES):
-                futures.append(("png", p, self.pool.submit(_read_bytes, p)))
-            else:
-                futures.append(("pixels", p, self.pool.submit(self._decode_into, p, view, alloc)))
-        return slot, (futures, view, alloc)
+                reads[k] = ("png", None if by_path else self.pool.submit(_read_bytes, self.tasks[k][1]))
+        return reads
 
-    def _submit(self, slot: int, started):
-        futures, view, alloc = started
-        decoded: list = [None] * len(futures)
+    def _decode_on_gpu(self, reads: dict, out: dict) -> list:
+        """Fills ``out[position]`` for the files the GPU decoders take; returns the positions they left to Pillow."""
         coded: dict = {"jpeg": ([], []), "png": ([], [])}
-        for k, (kind, _, fut) in enumerate(futures):
-            res = fut.result()
-            if kind == "pixels":
-                decoded[k] = res
-            elif res is not None:
+        for k, (kind, fut) in reads.items():
+            res = str(self.tasks[k][1]) if fut is None else fut.result()
+            if res is not None:
                 coded[kind][0].append(k)
                 coded[kind][1].append(res)
-        jpeg_done = {}
+        by_path = hasattr(self.stage, "hash_files")
+        refused = []
         for kind, (positions, blobs) in coded.items():
             if not blobs:
                 continue
-            ph, dh, st = self.stage.jpeg_hash(blobs, kind)
+            ph, dh, st = self.stage.hash_files(blobs, kind) if by_path else self.stage.jpeg_hash(blobs, kind)
             for k, p, d, code in zip(positions, ph.tolist(), dh.tolist(), st.tolist()):
                 if code == 0:
-                    jpeg_done[k] = (p, d)
+                    out[k] = (_to_signed64(p), _to_signed64(d))
                 else:                                  # outside the GPU decoder: Pillow decodes it, as the reference does
-                    decoded[k] = self._decode_into(futures[k][1], view, alloc)
+                    refused.append(k)
+        return refused
+
+    # ---- the Pillow share: chunks through the two staging buffers
+    def _start(self, positions: Sequence[int]):
+        slot, view = self.stage.acquire()
+        alloc = {"lock": threading.Lock(), "cursor": 0}
+        futures = [self.pool.submit(self._decode_into, self.tasks[k][1], view, alloc) for k in positions]
+        return slot, futures
+
+    def _submit(self, slot: int, futures):
+        decoded = [fut.result() for fut in futures]
         staged = [(k, d) for k, d in enumerate(decoded) if d is not None and d[0] != "spill"]
         spills = [(k, d[1]) for k, d in enumerate(decoded) if d is not None and d[0] == "spill"]
         handle = None
         if staged:
             handle = self.stage.submit(slot, [d[0] for _, d in staged], [d[1] for _, d in staged],
                                        [d[2] for _, d in staged], [d[3] for _, d in staged])
-        return len(decoded), [k for k, _ in staged], handle, spills, jpeg_done
+        return [k for k, _ in staged], handle, spills
 
-    def _collect(self, slot: int, submitted) -> list:
-        """Per file of the chunk: (phash_s64, dhash_s64) or None."""
-        count, staged_pos, handle, spills, jpeg_done = submitted
-        out: list = [None] * count
-        for k, (p, d) in jpeg_done.items():
-            out[k] = (_to_signed64(p), _to_signed64(d))
+    def _collect(self, slot: int, positions: Sequence[int], submitted, out: dict) -> None:
+        staged_pos, handle, spills = submitted
         if handle is not None:
             self.stage.wait(slot)
             for k, p, d, st in zip(staged_pos, handle["phash"].tolist(), handle["dhash"].tolist(), handle["status"].tolist()):
                 if st == 0:
-                    out[k] = (_to_signed64(p), _to_signed64(d))
+                    out[positions[k]] = (_to_signed64(p), _to_signed64(d))
         for k, arr in spills:                                    # larger than a staging buffer's free space
             sig = self.stage.hash_one(arr)
             if sig is not None:
-                out[k] = (_to_signed64(sig[0]), _to_signed64(sig[1]))
-        return out
+                out[positions[k]] = (_to_signed64(sig[0]), _to_signed64(sig[1]))
+
+    def _decode_with_pillow(self, todo: Sequence[int], out: dict) -> None:
+        previous = None                                           # (positions, slot, submitted) of the chunk on the GPU
+        for c0 in range(0, len(todo), self.chunk):
+            positions = todo[c0:c0 + self.chunk]
+            slot, futures = self._start(positions)                # decode of this chunk runs on the pool from here on
+            if previous is not None:                              # ... while the previous one is copied and hashed
+                self._collect(previous[1], previous[0], previous[2], out)
+            previous = (positions, slot, self._submit(slot, futures))
+        if previous is not None:
+            self._collect(previous[1], previous[0], previous[2], out)
 
     def run(self) -> Iterator[Tuple[int, Optional[Tuple[int, int]]]]:
         """Yields (file_id, hashes | None) in task order."""
         try:
-            previous = None                                       # (start, slot, submitted) of the chunk on the GPU
-            for start in range(0, len(self.tasks), self.chunk):
-                slot, futures = self._start(start)                # decode of this chunk runs on the pool from here on
-                if previous is not None:                          # ... while the previous one is copied, hashed, handed out
-                    p_start, p_slot, p_sub = previous
-                    for (fid, _), sig in zip(self.tasks[p_start:p_start + self.chunk], self._collect(p_slot, p_sub)):
-                        yield int(fid), sig
-                previous = (start, slot, self._submit(slot, futures))
-            if previous is not None:
-                p_start, p_slot, p_sub = previous
-                for (fid, _), sig in zip(self.tasks[p_start:p_start + self.chunk], self._collect(p_slot, p_sub)):
-                    yield int(fid), sig
+            reads_next = self._start_reads(0)
+            for start in range(0, len(self.tasks), self.batch):
+                stop = min(start + self.batch, len(self.tasks))
+                reads = reads_next
+                reads_next = self._start_reads(stop) if stop < len(self.tasks) else {}
+                out: dict = {}
+                refused = self._decode_on_gpu(reads, out)
+                todo = sorted([k for k in range(start, stop) if k not in reads] + refused)
+                self._decode_with_pillow(todo, out)
+                for k in range(start, stop):
+                    yield int(self.tasks[k][0]), out.get(k)
         finally:
             self.pool.shutdown(wait=True, cancel_futures=True)    # no thread may still be writing into a staging buffer
             try:
@@ -231,7 +269,7 @@ def compute_signatures_mp(tasks: List[Task], *, max_workers: Optional[int] = Non
     rows: List[Row] = []
     if total == 0:
         return rows
-    workers = max_workers or max(1, (os.cpu_count() or 4) - 1)
+    workers = max_workers or max(1, _usable_cpus() - 1)
     for seen, (fid, sig) in enumerate(_Pipeline(tasks, workers, chunksize, device).run(), 1):
         if cancel_fn is not None and cancel_fn():
             break                                   # the generator's finally clause cancels what is queued

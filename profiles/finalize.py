@@ -23,6 +23,8 @@ for name, keep in ((f"{tag}_scan_sizes.jsonl", lambda l: l.startswith("{")), (f"
     open(os.path.join(here, name), "w").writelines(l for l in open(os.path.join(g, name)) if keep(l))
 if os.path.exists(os.path.join(g, f"{tag}_decode.jsonl")):
     open(os.path.join(here, f"{tag}_decode.jsonl"), "w").writelines(l for l in open(os.path.join(g, f"{tag}_decode.jsonl")) if l.startswith("{"))
+    if os.path.exists(os.path.join(g, f"{tag}_fastsig.jsonl")):
+        open(os.path.join(here, f"{tag}_fastsig.jsonl"), "w").writelines(l for l in open(os.path.join(g, f"{tag}_fastsig.jsonl")) if l.startswith("{"))
     for fmt in ("png", "jpeg"):
         shutil.copy(newest(os.path.join(g, f"{tag}_stats_{fmt}", "**", "*_kernel_stats.csv")), os.path.join(here, f"{tag}_{fmt}_decode_kernel_stats.csv"))
 h = json.load(open(os.path.join(here, f"{tag}_pmc.json")))["hash"]

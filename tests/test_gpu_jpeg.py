@@ -105,8 +105,15 @@ def test_fast_fill_takes_the_gpu_route_for_jpeg_files(tmp_path, monkeypatch):
                 expect[k + 1] = O.hash_image(np.asarray(im.convert("RGB") if im.mode not in ("L", "RGB") else im))
         except OSError:
             pass
+    items.insert(7, (900, str(tmp_path / "gone.jpg")))             # no such file: dropped by either route
+    (tmp_path / "empty.png").write_bytes(b"")
+    items.insert(19, (901, str(tmp_path / "empty.png")))
     rows = K.compute_signatures_mp(items, max_workers=4, chunksize=16)
+    monkeypatch.setenv("KE_GPU_BATCH", "5")                        # GPU batches of 16 (never below the chunk size), then of 7
+    assert K.compute_signatures_mp(items, max_workers=4, chunksize=16) == rows
+    assert K.compute_signatures_mp(items, max_workers=4, chunksize=7) == rows
     monkeypatch.setenv("KE_GPU_JPEG", "0")
+    monkeypatch.setenv("KE_GPU_PNG", "0")
     rows_pillow = K.compute_signatures_mp(items, max_workers=4, chunksize=16)
     assert rows == rows_pillow
     assert [r[0] for r in rows] == sorted(expect)

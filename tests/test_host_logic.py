@@ -37,6 +37,45 @@ def test_library_exports_every_declared_symbol(K):
     assert lib.ke_abi_version() == 1
 
 
+def test_host_side_file_batching_needs_no_gpu(K, tmp_path):
+    """ke_host_read_files / ke_host_pack are plain host code (threads, read(2), memcpy): a batch of paths lands back to back
+    in the caller's buffer, unreadable or empty files with size 0, and a buffer that is too small is reported, not overrun."""
+    import ctypes as C
+
+    lib = K._native.load_library()
+    rng = np.random.default_rng(7)
+    blobs = [rng.integers(0, 256, int(k), dtype=np.uint8).tobytes() for k in rng.integers(1, 5000, 700)]
+    paths = []
+    for k, b in enumerate(blobs):
+        p = tmp_path / f"b{k}.bin"
+        p.write_bytes(b)
+        paths.append(str(p))
+    (tmp_path / "empty.bin").write_bytes(b"")
+    paths[100:100] = [str(tmp_path / "missing.bin"), str(tmp_path / "empty.bin"), str(tmp_path)]      # a directory, too
+    blobs[100:100] = [b"", b"", b""]
+    n = len(paths)
+    names = (C.c_char_p * n)(*[os.fsencode(p) for p in paths])
+    off, size, needed = np.zeros(n, np.uint64), np.zeros(n, np.uint64), C.c_uint64(0)
+    rc = lib.ke_host_read_files(names, n, None, 0, off.ctypes.data, size.ctypes.data, C.byref(needed))
+    total = sum(len(b) for b in blobs)
+    assert rc == -4 and needed.value == total + 64 and size.tolist() == [len(b) for b in blobs]
+    small = np.full(total, 0xAB, np.uint8)
+    assert lib.ke_host_read_files(names, n, small.ctypes.data, total, off.ctypes.data, size.ctypes.data, C.byref(needed)) == -4
+    assert (small == 0xAB).all()
+    buf = np.full(total + 64, 0xAB, np.uint8)
+    assert lib.ke_host_read_files(names, n, buf.ctypes.data, total + 64, off.ctypes.data, size.ctypes.data, C.byref(needed)) == 0
+    assert bytes(buf[:total]) == b"".join(blobs) and not buf[total:].any()
+    assert off.tolist() == np.concatenate([[0], np.cumsum([len(b) for b in blobs])[:-1]]).tolist()
+    # the same bytes from buffers already in memory
+    keep = [b for b in blobs if b]
+    sizes = np.array([len(b) for b in keep], np.uint64)
+    offs = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.uint64)
+    dst = np.zeros(total, np.uint8)
+    srcs = (C.c_char_p * len(keep))(*keep)
+    assert lib.ke_host_pack(dst.ctypes.data, srcs, offs.ctypes.data, sizes.ctypes.data, len(keep)) == 0
+    assert bytes(dst) == b"".join(keep)
+
+
 def test_no_cpu_fallback_without_gpu(K):
     import torch
 

@@ -138,3 +138,49 @@ def test_png_decode_matches_pillow_in_one_mixed_batch(ctx):
     refs = [c[2] for c in cases if min(c[2].shape[:2]) >= 16][:60]
     for k, ref in enumerate(refs):
         assert st[k] == 0 and (int(ph[k]), int(dh[k])) == O.hash_image(ref), k
+
+
+def test_png_damage_is_reported_not_decoded(ctx):
+    """Hundreds of damaged variants of valid files in one call (bytes flipped inside the image data, truncated streams,
+    lengths and filter bytes overwritten): the kernels must come back with a status for each -- and a file they do decode
+    must be one Pillow decodes to the same pixels."""
+    import io
+
+    from PIL import Image
+
+    rng = np.random.default_rng(21)
+    good = [c for c in P.supported() if c[2].shape[0] >= 64][:9] + list(P.handmade())[:6]
+    blobs, refs = [], []
+    for name, data, ref in good:
+        idat = data.index(b"IDAT") + 4
+        for v in range(40):
+            d = bytearray(data)
+            kind = v % 4
+            if kind == 0:                                  # one flipped bit somewhere in the image data
+                pos = int(rng.integers(idat, len(d) - 16))
+                d[pos] ^= 1 << int(rng.integers(0, 8))
+            elif kind == 1:                                # a run of random bytes
+                pos = int(rng.integers(idat, len(d) - 40))
+                d[pos:pos + 24] = rng.integers(0, 256, 24, dtype=np.uint8).tobytes()
+            elif kind == 2:                                # the head of the zlib stream / first block header
+                pos = idat + int(rng.integers(0, 12))
+                d[pos] = int(rng.integers(0, 256))
+            else:                                          # data zeroed from some point on (chunk structure intact)
+                pos = int(rng.integers(idat, len(d) - 16))
+                d[pos:len(d) - 16] = bytes(len(d) - 16 - pos)
+            blobs.append(bytes(d))
+            refs.append(name)
+    out, status = ctx.png_decode(blobs)
+    decoded = 0
+    for k, blob in enumerate(blobs):
+        assert status[k] in (0, 2), (refs[k], k)
+        if status[k] == 0:
+            decoded += 1
+            with Image.open(io.BytesIO(blob)) as im:
+                assert np.array_equal(np.asarray(im), out[k]), (refs[k], k)
+        else:
+            assert out[k] is None
+    assert decoded < len(blobs) // 4                       # a flip in unused padding bits or a stored block's data can survive
+    # the context is still good for a clean batch afterwards
+    clean, st = ctx.png_decode([g[1] for g in good])
+    assert (st == 0).all() and all(np.array_equal(a, g[2]) for a, g in zip(clean, good))

@@ -37,6 +37,10 @@ _lib: Optional[C.CDLL] = None
 _lib_lock = threading.Lock()
 
 
+class _BatchTooLarge(Exception):
+    """A decode batch whose compressed or decoded bytes exceed the context's limits: the caller halves it."""
+
+
 class NativeUnavailable(RuntimeError):
     """libkeyes_hip.so (or a gfx950 device) is not available."""
 
@@ -175,6 +179,9 @@ class Context:
         self._lock = threading.RLock()
         self._pack_ptr, self._pack_cap = 0, 0
         self._decoded_ptr, self._decoded_cap = 0, 0
+        # a decode call beyond these is split in halves: compressed bytes in page-locked memory, decoded pixels on the device
+        self.pack_limit = int(os.environ.get("KE_PACK_LIMIT_BYTES", str(8 << 30)))
+        self.decode_limit = int(os.environ.get("KE_DECODE_LIMIT_BYTES", str(48 << 30)))
 
     # -- lifetime ---------------------------------------------------------------------------
     def close(self) -> None:
@@ -383,6 +390,8 @@ class Context:
         needed = C.c_uint64(0)
         rc = self._lib.ke_host_read_files(names, n, self._pack_ptr, self._pack_cap, _addr(offsets), _addr(sizes), C.byref(needed))
         if rc == -4:                                       # KE_ENOMEM: the buffer is too small for this batch
+            if int(needed.value) > self.pack_limit and n > 1:
+                raise _BatchTooLarge
             self._grow_pack(int(needed.value))
             rc = self._lib.ke_host_read_files(names, n, self._pack_ptr, self._pack_cap, _addr(offsets), _addr(sizes), C.byref(needed))
         if rc != KE_OK:
@@ -398,6 +407,8 @@ class Context:
         offsets = np.zeros(len(blobs), np.uint64)
         offsets[1:] = np.cumsum(sizes[:-1])
         total = int(sizes.sum()) + 64
+        if total > self.pack_limit and len(blobs) > 1:
+            raise _BatchTooLarge
         self._grow_pack(total)
         base = self._pack_ptr
         flat = np.ctypeslib.as_array((C.c_uint8 * total).from_address(base))
@@ -447,6 +458,8 @@ class Context:
             total = int(padded.sum())
             if total == 0:
                 return 0, out_off, w, h, c, st
+            if total > self.decode_limit and n > 1:
+                raise _BatchTooLarge
             if total + 64 > self._decoded_cap:
                 if self._decoded_ptr:
                     self.free(self._decoded_ptr)
@@ -473,7 +486,13 @@ class Context:
         None where the decoder refused the file (status != 0); also returns the statuses."""
         out = [None] * len(blobs)
         with self._lock:
-            dev, out_off, w, h, c, st = self._jpeg_to_device(blobs, kind)
+            try:
+                dev, out_off, w, h, c, st = self._jpeg_to_device(blobs, kind)
+            except _BatchTooLarge:
+                half = len(blobs) // 2
+                a, sa = self.jpeg_decode(blobs[:half], kind)
+                b, sb = self.jpeg_decode(blobs[half:], kind)
+                return a + b, np.concatenate([sa, sb])
             for i in range(len(blobs)):
                 if st[i] == 0:
                     arr = np.empty((h[i], w[i], c[i]) if c[i] > 1 else (h[i], w[i]), np.uint8)
@@ -494,7 +513,14 @@ class Context:
         if n == 0:
             return ph, dh, np.zeros(0, np.int32)
         with self._lock:
-            dev, out_off, w, h, c, st = self._jpeg_to_device(blobs, kind, paths=paths)
+            try:
+                dev, out_off, w, h, c, st = self._jpeg_to_device(blobs, kind, paths=paths)
+            except _BatchTooLarge:
+                half = n // 2
+                parts = [self.jpeg_hash(None if blobs is None else blobs[lo:hi], want_dhash=want_dhash, kind=kind,
+                                        paths=None if paths is None else paths[lo:hi]) for lo, hi in ((0, half), (half, n))]
+                return (np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts]) if want_dhash else None,
+                        np.concatenate([p[2] for p in parts]))
             for ch in (1, 3, 4):
                 idx = np.nonzero((st == 0) & (c == ch))[0]
                 if len(idx) == 0:

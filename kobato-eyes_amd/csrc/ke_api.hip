@@ -300,39 +300,35 @@ KE_API int ke_host_pack(uint8_t *dst, const uint8_t *const *srcs, const uint64_t
 KE_API int ke_host_read_files(const char *const *paths, int64_t n, uint8_t *dst, uint64_t capacity, uint64_t *offsets, uint64_t *sizes,
                               uint64_t *needed_out) {
     if (n < 0 || (n > 0 && (!paths || !offsets || !sizes)) || !needed_out) return KE_EINVAL;
-    // sizes first (a file that cannot be opened or is not a regular file counts 0 bytes), then the layout, then the bytes
-    std::vector<int> fds((size_t)n, -1);
+    // sizes first (a file that is not there or is not a regular file counts 0 bytes), then the layout, then the bytes; no
+    // descriptor stays open between the two passes (a batch is tens of thousands of files, the descriptor limit is not)
     ke_parallel_ranges(n, [&](int64_t lo, int64_t hi, int) {
         for (int64_t i = lo; i < hi; ++i) {
-            sizes[i] = 0;
-            const int fd = paths[i] ? ::open(paths[i], O_RDONLY | O_CLOEXEC) : -1;
-            if (fd < 0) continue;
             struct stat st;
-            if (::fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size <= 0) { ::close(fd); continue; }
-            sizes[i] = (uint64_t)st.st_size;
-            fds[(size_t)i] = fd;
+            sizes[i] = (paths[i] && ::stat(paths[i], &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) ? (uint64_t)st.st_size : 0;
         }
     });
     uint64_t at = 0;
     for (int64_t i = 0; i < n; ++i) { offsets[i] = at; at += sizes[i]; }
     *needed_out = at + 64;
     const bool fits = dst && at + 64 <= capacity;
-    ke_parallel_ranges(n, [&](int64_t lo, int64_t hi, int) {
-        for (int64_t i = lo; i < hi; ++i) {
-            const int fd = fds[(size_t)i];
-            if (fd < 0) continue;
-            if (fits) {
+    if (fits)
+        ke_parallel_ranges(n, [&](int64_t lo, int64_t hi, int) {
+            for (int64_t i = lo; i < hi; ++i) {
+                if (sizes[i] == 0) continue;
                 uint64_t got = 0;
-                while (got < sizes[i]) {
-                    const ssize_t r = ::read(fd, dst + offsets[i] + got, (size_t)(sizes[i] - got));
-                    if (r <= 0) break;
-                    got += (uint64_t)r;
+                const int fd = ::open(paths[i], O_RDONLY | O_CLOEXEC);
+                if (fd >= 0) {
+                    while (got < sizes[i]) {
+                        const ssize_t r = ::read(fd, dst + offsets[i] + got, (size_t)(sizes[i] - got));
+                        if (r <= 0) break;
+                        got += (uint64_t)r;
+                    }
+                    ::close(fd);
                 }
-                if (got != sizes[i]) std::memset(dst + offsets[i], 0, (size_t)sizes[i]);      // a short read: not a decodable file
+                if (got != sizes[i]) std::memset(dst + offsets[i], 0, (size_t)sizes[i]);      // unreadable or shrunk meanwhile: not a decodable file
             }
-            ::close(fd);
-        }
-    });
+        });
     if (!fits) return KE_ENOMEM;
     std::memset(dst + at, 0, 64);
     return KE_OK;

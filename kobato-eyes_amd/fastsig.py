@@ -126,7 +126,8 @@ class _Pipeline:
     """decode (threads) -> pinned staging buffer -> H2D + hash (GPU), without a host-side copy in between; JPEG and PNG files
     decoded on the GPU instead.
 
-    Files are taken ``KE_GPU_BATCH`` (default 8192) at a time.  Within such a batch:
+    Files are taken ``KE_GPU_BATCH`` (default 32768) at a time (a batch whose compressed bytes exceed ``KE_PACK_LIMIT_BYTES`` or
+    whose pixels exceed ``KE_DECODE_LIMIT_BYTES`` is halved by the context until it fits).  Within such a batch:
 
     * JPEG and PNG files (by suffix) skip Pillow altogether: the threads only read the bytes -- the next batch's files while
       this one is on the GPU -- and ONE ``ke_jpeg_decode`` / ``ke_png_decode`` call per kind decodes them all, pixel-identical to
@@ -143,7 +144,7 @@ class _Pipeline:
 
     def __init__(self, tasks: Sequence[Task], workers: int, chunk: int, device: int) -> None:
         self.tasks, self.chunk, self.device = tasks, max(1, int(chunk)), device
-        self.batch = max(self.chunk, int(os.environ.get("KE_GPU_BATCH", "8192")))
+        self.batch = max(self.chunk, int(os.environ.get("KE_GPU_BATCH", "32768")))
         self.pool = ThreadPoolExecutor(max_workers=max(1, workers))
         self.stage = _make_stage(device, int(os.environ.get("KE_STAGE_BYTES", str(256 << 20))), self.chunk)
 

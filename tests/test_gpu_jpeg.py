@@ -184,3 +184,31 @@ def test_png_damage_is_reported_not_decoded(ctx):
     # the context is still good for a clean batch afterwards
     clean, st = ctx.png_decode([g[1] for g in good])
     assert (st == 0).all() and all(np.array_equal(a, g[2]) for a, g in zip(clean, good))
+
+
+def test_decode_batches_beyond_the_byte_limits_are_halved(ctx, tmp_path):
+    """A call whose compressed bytes or decoded pixels exceed the context's limits is split in halves until each part fits;
+    the hashes are those of the unsplit call -- from buffers and from files on disk."""
+    cases = [c for c in J.supported()][:40]
+    blobs = [c[1] for c in cases]
+    ph, dh, st = ctx.jpeg_hash(blobs)
+    paths = []
+    for k, b in enumerate(blobs):
+        p = tmp_path / f"{k}.jpg"
+        p.write_bytes(b)
+        paths.append(str(p))
+    saved = ctx.pack_limit, ctx.decode_limit
+    try:
+        ctx.release_decode_buffers()
+        ctx.pack_limit = max(len(b) for b in blobs) * 3
+        for got in (ctx.jpeg_hash(blobs), ctx.hash_files(paths)):
+            assert np.array_equal(got[0], ph) and np.array_equal(got[1], dh) and np.array_equal(got[2], st)
+        ctx.pack_limit = saved[0]
+        ctx.decode_limit = 200_000
+        for got in (ctx.jpeg_hash(blobs), ctx.hash_files(paths)):
+            assert np.array_equal(got[0], ph) and np.array_equal(got[1], dh) and np.array_equal(got[2], st)
+        pixels, st2 = ctx.jpeg_decode(blobs)
+        assert np.array_equal(st2, st) and all((a is None) == (s != 0) for a, s in zip(pixels, st))
+    finally:
+        ctx.pack_limit, ctx.decode_limit = saved
+        ctx.release_decode_buffers()

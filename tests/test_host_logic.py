@@ -63,7 +63,14 @@ def test_host_side_file_batching_needs_no_gpu(K, tmp_path):
     assert lib.ke_host_read_files(names, n, small.ctypes.data, total, off.ctypes.data, size.ctypes.data, C.byref(needed)) == -4
     assert (small == 0xAB).all()
     buf = np.full(total + 64, 0xAB, np.uint8)
-    assert lib.ke_host_read_files(names, n, buf.ctypes.data, total + 64, off.ctypes.data, size.ctypes.data, C.byref(needed)) == 0
+    import resource
+
+    soft, hard = resource.getrlimit(resource.RLIMIT_NOFILE)
+    resource.setrlimit(resource.RLIMIT_NOFILE, (min(soft, 128), hard))      # far fewer descriptors than files in the batch
+    try:
+        assert lib.ke_host_read_files(names, n, buf.ctypes.data, total + 64, off.ctypes.data, size.ctypes.data, C.byref(needed)) == 0
+    finally:
+        resource.setrlimit(resource.RLIMIT_NOFILE, (soft, hard))
     assert bytes(buf[:total]) == b"".join(blobs) and not buf[total:].any()
     assert off.tolist() == np.concatenate([[0], np.cumsum([len(b) for b in blobs])[:-1]]).tolist()
     # the same bytes from buffers already in memory

@@ -20,6 +20,8 @@ from concurrent.futures import Future, ThreadPoolExecutor
 from pathlib import Path
 from typing import Callable, Iterable, Iterator, List, Optional, Sequence, Tuple
 
+import numpy as np
+
 from . import _native
 
 _phash = importlib.import_module(".phash", __package__)   # the package also exports a function named phash
@@ -193,9 +195,10 @@ class _Pipeline:
             if not blobs:
                 continue
             ph, dh, st = self.stage.hash_files(blobs, kind) if by_path else self.stage.jpeg_hash(blobs, kind)
-            for k, p, d, code in zip(positions, ph.tolist(), dh.tolist(), st.tolist()):
+            signed = zip(np.asarray(ph, np.uint64).view(np.int64).tolist(), np.asarray(dh, np.uint64).view(np.int64).tolist())
+            for k, sig, code in zip(positions, signed, np.asarray(st).tolist()):
                 if code == 0:
-                    out[k] = (_to_signed64(p), _to_signed64(d))
+                    out[k] = sig
                 else:                                  # outside the GPU decoder: Pillow decodes it, as the reference does
                     refused.append(k)
         return refused
@@ -242,6 +245,11 @@ class _Pipeline:
 
     def run(self) -> Iterator[Tuple[int, Optional[Tuple[int, int]]]]:
         """Yields (file_id, hashes | None) in task order."""
+        for fids, sigs in self.run_batches():
+            yield from zip(fids, sigs)
+
+    def run_batches(self) -> Iterator[Tuple[List[int], List[Optional[Tuple[int, int]]]]]:
+        """Yields ([file_id], [hashes | None]) batch by batch, in task order."""
         try:
             reads_next = self._start_reads(0)
             for start in range(0, len(self.tasks), self.batch):
@@ -252,8 +260,7 @@ class _Pipeline:
                 refused = self._decode_on_gpu(reads, out)
                 todo = sorted([k for k in range(start, stop) if k not in reads] + refused)
                 self._decode_with_pillow(todo, out)
-                for k in range(start, stop):
-                    yield int(self.tasks[k][0]), out.get(k)
+                yield [int(t[0]) for t in self.tasks[start:stop]], [out.get(k) for k in range(start, stop)]
         finally:
             self.pool.shutdown(wait=True, cancel_futures=True)    # no thread may still be writing into a staging buffer
             try:
@@ -271,16 +278,33 @@ def compute_signatures_mp(tasks: List[Task], *, max_workers: Optional[int] = Non
     if total == 0:
         return rows
     workers = max_workers or max(1, _usable_cpus() - 1)
-    for seen, (fid, sig) in enumerate(_Pipeline(tasks, workers, chunksize, device).run(), 1):
-        if cancel_fn is not None and cancel_fn():
+    def report(seen: int) -> None:
+        try:
+            progress(seen, total)
+        except Exception:
+            pass
+
+    pipeline = _Pipeline(tasks, workers, chunksize, device)
+    if cancel_fn is None:                           # nobody to ask between files: whole batches at a time
+        seen = 0
+        for fids, sigs in pipeline.run_batches():
+            rows.extend((fid, sig[0], sig[1]) for fid, sig in zip(fids, sigs) if sig is not None)
+            if progress is not None:
+                before, seen = seen, seen + len(fids)
+                for mark in range((before // PROGRESS_STRIDE + 1) * PROGRESS_STRIDE, seen + 1, PROGRESS_STRIDE):
+                    report(mark)
+                if seen == total and seen % PROGRESS_STRIDE:
+                    report(seen)
+            else:
+                seen += len(fids)
+        return rows
+    for seen, (fid, sig) in enumerate(pipeline.run(), 1):
+        if cancel_fn():
             break                                   # the generator's finally clause cancels what is queued
         if sig is not None:
             rows.append((fid, sig[0], sig[1]))
         if progress is not None and (seen % PROGRESS_STRIDE == 0 or seen == total):
-            try:
-                progress(seen, total)
-            except Exception:
-                pass
+            report(seen)
     return rows
 
 

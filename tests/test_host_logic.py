@@ -250,6 +250,28 @@ def test_fastsig_drops_missing_files_and_reports_progress(K, monkeypatch, tmp_pa
     assert len(out) == 2                                   # partial result after cancel
 
 
+def test_fastsig_progress_cadence_over_whole_batches(K, monkeypatch):
+    """Without a cancel callback results are taken a GPU batch at a time; progress still fires at every 200th file and at
+    the end (src/core/fastsig.py:95-98), failures are still omitted."""
+    import kobato_eyes_amd.fastsig as fs
+
+    class FakePipeline:
+        def __init__(self, tasks, workers, chunk, device):
+            self.tasks = tasks
+
+        def run_batches(self):
+            for lo in range(0, len(self.tasks), 128):
+                part = self.tasks[lo:lo + 128]
+                yield [t[0] for t in part], [None if t[0] % 50 == 0 else (-t[0], t[0]) for t in part]
+
+    monkeypatch.setattr(fs, "_Pipeline", FakePipeline)
+    for total, marks in ((450, [200, 400, 450]), (400, [200, 400]), (199, [199]), (128, [128])):
+        seen = []
+        rows = fs.compute_signatures_mp([(k, f"f{k}") for k in range(1, total + 1)], progress=lambda d, t: seen.append((d, t)))
+        assert seen == [(m, total) for m in marks]
+        assert rows == [(k, -k, k) for k in range(1, total + 1) if k % 50]
+
+
 _GLOO_WORKER = r"""
 import os, sys
 sys.path.insert(0, sys.argv[1])

@@ -141,6 +141,11 @@ int ke_hash_images_ex(ke_ctx *ctx, const uint8_t *pixels, const uint64_t *offset
  *   ke_stage_wait         -> blocks until the slot's results are in the caller's arrays (slot -1: every slot, oldest first).
  * Hashes are those of ke_hash_images on the same pixels. */
 int ke_stage_create(ke_ctx *ctx, size_t bytes_per_buffer, int64_t max_images, int32_t n_buffers);
+/* The same staging on buffers the caller owns: n_buffers page-aligned regions of bytes_per_buffer bytes (a multiple of 256)
+ * -- e.g. POSIX shared memory that decoder processes attach to, which is how a Python host gets past its interpreter lock the
+ * way the reference does (a process pool, src/core/fastsig.py:83-85).  The library page-locks them (hipHostRegister) until
+ * ke_stage_destroy / the next create; the memory must stay mapped that long. */
+int ke_stage_create_shared(ke_ctx *ctx, void *const *buffers, size_t bytes_per_buffer, int64_t max_images, int32_t n_buffers);
 int ke_stage_destroy(ke_ctx *ctx);
 int ke_stage_acquire(ke_ctx *ctx, int32_t *slot_out, uint8_t **host_ptr_out, size_t *bytes_out);
 int ke_stage_submit_hash(ke_ctx *ctx, int32_t slot, const uint64_t *offsets, const int32_t *widths, const int32_t *heights,

@@ -26,7 +26,7 @@ EXPORTS = (
     "ke_abi_version", "ke_create", "ke_create_error", "ke_destroy", "ke_last_error", "ke_set_stream",
     "ke_get_stream", "ke_synchronize", "ke_device_info", "ke_malloc", "ke_free", "ke_memcpy",
     "ke_hash_images", "ke_hash_uniform", "ke_hash_images_ex", "ke_hash_uniform_ex", "ke_luma_tiles_uniform", "ke_hamming_scan",
-    "ke_stage_create", "ke_stage_destroy", "ke_stage_acquire", "ke_stage_submit_hash", "ke_stage_wait",
+    "ke_stage_create", "ke_stage_create_shared", "ke_stage_destroy", "ke_stage_acquire", "ke_stage_submit_hash", "ke_stage_wait",
     "ke_comm_unique_id", "ke_comm_create", "ke_comm_destroy", "ke_allgather_u64", "ke_allgather_hashes", "ke_allgather_edges",
     "ke_interleave_shards", "ke_host_alloc", "ke_host_free", "ke_host_pack", "ke_host_read_files", "ke_jpeg_probe", "ke_jpeg_decode", "ke_png_probe", "ke_png_decode", "ke_cluster_labels", "ke_ssim_pairs_uniform", "ke_ssim_pairs", "ke_ssim_set_mode", "ke_resize_luma_uniform", "ke_fit_luma_uniform", "ke_tile_ahash", "ke_sad_pairs", "ke_synth_rgb",
     "ke_synth_rgb_indexed",
@@ -108,6 +108,7 @@ def load_library() -> C.CDLL:
         lib.ke_hash_uniform_ex.argtypes = [vp, vp, i64, i32, i32, i32, vp, vp, vp]
         lib.ke_luma_tiles_uniform.argtypes = [vp, vp, i64, i32, i32, i32, vp, vp]
         lib.ke_stage_create.argtypes = [vp, C.c_size_t, i64, i32]
+        lib.ke_stage_create_shared.argtypes = [vp, vp, C.c_size_t, i64, i32]
         lib.ke_stage_destroy.argtypes = [vp]
         lib.ke_stage_acquire.argtypes = [vp, C.POINTER(i32), C.POINTER(vp), C.POINTER(C.c_size_t)]
         lib.ke_stage_submit_hash.argtypes = [vp, i32, vp, vp, vp, vp, i64, vp, vp, vp, vp]
@@ -144,7 +145,7 @@ def load_library() -> C.CDLL:
         lib.ke_last_kernel_ms.restype = dbl
         for name in ("ke_set_stream", "ke_synchronize", "ke_device_info", "ke_malloc", "ke_free", "ke_memcpy",
                      "ke_hash_images", "ke_hash_uniform", "ke_hash_images_ex", "ke_hash_uniform_ex", "ke_luma_tiles_uniform", "ke_hamming_scan",
-                     "ke_stage_create", "ke_stage_destroy", "ke_stage_acquire", "ke_stage_submit_hash", "ke_stage_wait",
+                     "ke_stage_create", "ke_stage_create_shared", "ke_stage_destroy", "ke_stage_acquire", "ke_stage_submit_hash", "ke_stage_wait",
                      "ke_comm_unique_id", "ke_comm_create", "ke_comm_destroy", "ke_allgather_u64", "ke_allgather_hashes", "ke_allgather_edges",
                      "ke_interleave_shards", "ke_host_alloc", "ke_host_free", "ke_host_pack", "ke_host_read_files", "ke_jpeg_probe", "ke_jpeg_decode", "ke_png_probe", "ke_png_decode", "ke_cluster_labels", "ke_ssim_pairs_uniform", "ke_ssim_pairs", "ke_ssim_set_mode", "ke_resize_luma_uniform", "ke_fit_luma_uniform", "ke_tile_ahash",
                      "ke_sad_pairs", "ke_synth_rgb", "ke_synth_rgb_indexed", "ke_synth_hashes"):
@@ -297,6 +298,12 @@ class Context:
     # -- pinned staging ---------------------------------------------------------------------
     def stage_create(self, bytes_per_buffer: int, max_images: int, n_buffers: int = 2) -> None:
         self._check(self._lib.ke_stage_create(self._h, int(bytes_per_buffer), int(max_images), int(n_buffers)), "ke_stage_create")
+
+    def stage_create_shared(self, addresses, bytes_per_buffer: int, max_images: int) -> None:
+        """Staging on the caller's page-aligned buffers (shared memory that decoder processes write into)."""
+        ptrs = (C.c_void_p * len(addresses))(*[int(a) for a in addresses])
+        self._check(self._lib.ke_stage_create_shared(self._h, ptrs, int(bytes_per_buffer), int(max_images), len(addresses)),
+                    "ke_stage_create_shared")
 
     def stage_destroy(self) -> None:
         self._check(self._lib.ke_stage_destroy(self._h), "ke_stage_destroy")

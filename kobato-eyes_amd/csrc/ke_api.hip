@@ -648,6 +648,7 @@ static void stage_free(ke_ctx *ctx) {
     if (st->copy_stream) (void)hipStreamSynchronize(st->copy_stream);
     for (int k = 0; k < st->n_slots; ++k) {
         KeStageSlot &s = st->slot[k];
+        if (s.h_px && s.px_external) { (void)hipHostUnregister(s.h_px); s.h_px = nullptr; }
         for (void *p : {(void *)s.h_px, (void *)s.h_meta, (void *)s.h_ph, (void *)s.h_dh, (void *)s.h_mg})
             if (p) (void)hipHostFree(p);
         for (void *p : {(void *)s.d_px, (void *)s.d_meta, (void *)s.d_ph, (void *)s.d_dh, (void *)s.d_mg})
@@ -666,7 +667,22 @@ KE_API int ke_stage_destroy(ke_ctx *ctx) {
     return KE_OK;
 }
 
+static int stage_create(ke_ctx *ctx, void *const *external, size_t bytes_per_buffer, int64_t max_images, int32_t n_buffers);
+
 KE_API int ke_stage_create(ke_ctx *ctx, size_t bytes_per_buffer, int64_t max_images, int32_t n_buffers) {
+    return stage_create(ctx, nullptr, bytes_per_buffer, max_images, n_buffers);
+}
+
+KE_API int ke_stage_create_shared(ke_ctx *ctx, void *const *buffers, size_t bytes_per_buffer, int64_t max_images, int32_t n_buffers) {
+    if (!ctx) return KE_EINVAL;
+    if (!buffers) return ke_fail(ctx, KE_EINVAL, "NULL argument");
+    for (int k = 0; k < n_buffers && k < KE_MAX_STAGE_SLOTS; ++k)
+        if (!buffers[k] || ((uintptr_t)buffers[k] & 4095) || (bytes_per_buffer & 255))
+            return ke_fail(ctx, KE_EINVAL, "shared staging buffers must be page-aligned and a multiple of 256 bytes long");
+    return stage_create(ctx, buffers, bytes_per_buffer, max_images, n_buffers);
+}
+
+static int stage_create(ke_ctx *ctx, void *const *external, size_t bytes_per_buffer, int64_t max_images, int32_t n_buffers) {
     if (!ctx) return KE_EINVAL;
     if (bytes_per_buffer < 4096 || max_images <= 0 || n_buffers < 1 || n_buffers > KE_MAX_STAGE_SLOTS)
         return ke_fail(ctx, KE_EINVAL, "bad staging geometry (%zu bytes, %lld images, %d buffers)", bytes_per_buffer,
@@ -683,7 +699,14 @@ KE_API int ke_stage_create(ke_ctx *ctx, size_t bytes_per_buffer, int64_t max_ima
     for (int k = 0; k < n_buffers; ++k) {
         KeStageSlot &s = st->slot[k];
         const size_t m8 = (size_t)max_images * 8;
-        if (hipHostMalloc((void **)&s.h_px, st->bytes, hipHostMallocDefault) != hipSuccess) return fail("hipHostMalloc(pixels)");
+        if (external) {
+            // the caller's pages (shared memory that decoder PROCESSES write into), page-locked and mapped for the copy engine
+            if (hipHostRegister(external[k], st->bytes, hipHostRegisterDefault) != hipSuccess) return fail("hipHostRegister(pixels)");
+            s.h_px = (uint8_t *)external[k];
+            s.px_external = true;
+        } else if (hipHostMalloc((void **)&s.h_px, st->bytes, hipHostMallocDefault) != hipSuccess) {
+            return fail("hipHostMalloc(pixels)");
+        }
         if (hipHostMalloc((void **)&s.h_meta, 2 * m8, hipHostMallocDefault) != hipSuccess) return fail("hipHostMalloc(meta)");
         if (hipHostMalloc((void **)&s.h_ph, m8, hipHostMallocDefault) != hipSuccess) return fail("hipHostMalloc");
         if (hipHostMalloc((void **)&s.h_dh, m8, hipHostMallocDefault) != hipSuccess) return fail("hipHostMalloc");

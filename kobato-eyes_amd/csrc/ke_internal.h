@@ -112,6 +112,7 @@ struct KeStageSlot {
     float *h_mg = nullptr, *d_mg = nullptr;
     hipEvent_t copied = nullptr, done = nullptr;
     bool in_flight = false;
+    bool px_external = false;                         // h_px is the caller's memory, registered with the runtime
     uint64_t *user_ph = nullptr, *user_dh = nullptr;  // where the results go when the slot is waited for
     float *user_mg = nullptr;
     int64_t n = 0;

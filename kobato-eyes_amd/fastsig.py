@@ -12,11 +12,15 @@ staging buffer while chunk k is copied to the GPU and hashed (``ke_stage_*``, in
 """
 from __future__ import annotations
 
+import atexit
 import importlib
+import mmap
+import multiprocessing
 import os
 import sqlite3
 import threading
-from concurrent.futures import Future, ThreadPoolExecutor
+from concurrent.futures import Future, ProcessPoolExecutor, ThreadPoolExecutor
+from concurrent.futures.process import BrokenProcessPool
 from pathlib import Path
 from typing import Callable, Iterable, Iterator, List, Optional, Sequence, Tuple
 
@@ -85,6 +89,90 @@ def _read_bytes(path_text: str):
         return None
 
 
+# ---- decoder processes.  Pillow's per-file work in Python (opening, plugin dispatch, conversions) holds the interpreter lock,
+# so decode THREADS stop scaling at two or three cores; the reference runs a spawn-context process pool for that reason
+# (src/core/fastsig.py:83-85).  Here the processes only decode: they write the pixels straight into the staging buffers, which
+# for this purpose are files in /dev/shm mapped by both sides and page-locked by the library (ke_stage_create_shared), and hand
+# back where each image went.  The parent never touches the pixels.
+_worker_maps: dict = {}
+
+
+def _decode_into_shared(job):
+    """Worker: (path of the mapped buffer, region start, region length, [file paths]) -> per file (offset, w, h, channels),
+    "spill" when the region is full, None when the file cannot be read."""
+    shm_path, start, length, paths = job
+    view = _worker_maps.get(shm_path)
+    if view is None:
+        fd = os.open(shm_path, os.O_RDWR)
+        try:
+            view = np.frombuffer(mmap.mmap(fd, 0), np.uint8)
+        finally:
+            os.close(fd)
+        _worker_maps[shm_path] = view
+    out, cursor, end = [], start, start + length
+    for p in paths:
+        arr = _read_pixels(p)
+        if arr is None or arr.size == 0:
+            out.append(None)
+            continue
+        off = (cursor + 15) & ~15
+        if off + arr.size > end:
+            out.append("spill")
+            continue
+        view[off:off + arr.size] = arr.reshape(-1)
+        cursor = off + int(arr.size)
+        h, w = arr.shape[:2]
+        out.append((off, w, h, 1 if arr.ndim == 2 else arr.shape[2]))
+    return out
+
+
+_pools: dict = {}
+
+
+def _process_pool(workers: int) -> ProcessPoolExecutor:
+    """One spawn-context pool per worker count, kept for the life of the process (starting 15 interpreters costs about a
+    second; a library scan calls the batch hasher many times)."""
+    pool = _pools.get(workers)
+    if pool is None:
+        pool = _pools[workers] = ProcessPoolExecutor(max_workers=workers, mp_context=multiprocessing.get_context("spawn"))
+    return pool
+
+
+@atexit.register
+def _stop_pools() -> None:
+    for pool in _pools.values():
+        pool.shutdown(wait=False, cancel_futures=True)
+    _pools.clear()
+
+
+class _SharedBuffers:
+    """Two page-aligned buffers that other processes can map: files in /dev/shm, unlinked when the object goes."""
+
+    def __init__(self, nbytes: int, count: int = 2) -> None:
+        self.paths, self.maps = [], []
+        for k in range(count):
+            path = f"/dev/shm/ke_stage_{os.getpid()}_{id(self):x}_{k}"
+            fd = os.open(path, os.O_CREAT | os.O_EXCL | os.O_RDWR, 0o600)
+            try:
+                os.ftruncate(fd, nbytes)
+                self.maps.append(mmap.mmap(fd, nbytes))
+            finally:
+                os.close(fd)
+            self.paths.append(path)
+        self.addresses = [np.frombuffer(m, np.uint8).ctypes.data for m in self.maps]
+
+    def close(self) -> None:
+        for path in self.paths:
+            try:
+                os.unlink(path)
+            except OSError:
+                pass
+        self.paths = []
+
+    def __del__(self) -> None:  # pragma: no cover
+        self.close()
+
+
 class _GpuStage:
     """The context's pinned staging buffers (``ke_stage_*``) behind the four calls the pipeline needs; tests of the host
     logic put a stand-in here (``_make_stage``)."""
@@ -92,10 +180,29 @@ class _GpuStage:
     def __init__(self, device: int, stage_bytes: int, max_images: int) -> None:
         self.device = device
         self.ctx = _native.get_context(device)
-        geom = (stage_bytes, max_images)
+        stage_bytes = (int(stage_bytes) + 4095) & ~4095
+        shared = os.environ.get("KE_DECODE_PROCESSES", "1") != "0" and os.path.isdir("/dev/shm")
+        geom = (stage_bytes, max_images, shared)
         if getattr(self.ctx, "_stage_geom", None) != geom:
-            self.ctx.stage_create(stage_bytes, max_images, 2)
-            self.ctx._stage_geom = geom
+            old = getattr(self.ctx, "_stage_shared", None)     # stays mapped until the library has let go of it
+            buffers = None
+            if shared:
+                try:
+                    buffers = _SharedBuffers(stage_bytes)
+                    self.ctx.stage_create_shared(buffers.addresses, stage_bytes, max_images)
+                except (OSError, RuntimeError, ValueError):
+                    if buffers is not None:
+                        buffers.close()
+                    buffers, shared = None, False
+            if not shared:
+                self.ctx.stage_create(stage_bytes, max_images, 2)
+            self.ctx._stage_shared = buffers
+            self.ctx._stage_geom = (stage_bytes, max_images, shared)
+            if old is not None:
+                old.close()
+        buffers = getattr(self.ctx, "_stage_shared", None)
+        self.shared_paths = buffers.paths if buffers is not None else None     # slot k <-> shared_paths[k]
+        self.stage_bytes = stage_bytes
 
     def acquire(self):
         return self.ctx.stage_acquire()
@@ -147,8 +254,11 @@ class _Pipeline:
     def __init__(self, tasks: Sequence[Task], workers: int, chunk: int, device: int) -> None:
         self.tasks, self.chunk, self.device = tasks, max(1, int(chunk)), device
         self.batch = max(self.chunk, int(os.environ.get("KE_GPU_BATCH", "32768")))
-        self.pool = ThreadPoolExecutor(max_workers=max(1, workers))
-        self.stage = _make_stage(device, int(os.environ.get("KE_STAGE_BYTES", str(256 << 20))), self.chunk)
+        self.workers = max(1, workers)
+        self.pool = ThreadPoolExecutor(max_workers=self.workers)
+        self.stage = _make_stage(device, int(os.environ.get("KE_STAGE_BYTES", str(256 << 20))), max(self.chunk, 4096))
+        self.process_min = int(os.environ.get("KE_DECODE_PROCESS_MIN", "256"))
+        self.bytes_per_image = 1 << 20                     # running estimate of a decoded image, for sizing the workers' jobs
 
     def _decode_into(self, path_text: str, view, alloc: dict):
         """One file -> (offset, width, height, channels) inside the staging buffer, ("spill", array) when it does not
@@ -232,7 +342,65 @@ class _Pipeline:
             if sig is not None:
                 out[positions[k]] = (_to_signed64(sig[0]), _to_signed64(sig[1]))
 
+    def _decode_with_processes(self, todo: Sequence[int], out: dict) -> None:
+        """The Pillow share on decoder PROCESSES: every round hands each worker a job of a few files and a region of the
+        shared staging buffer to write them into; the buffer of round k is copied and hashed while round k+1 decodes."""
+        pool = _process_pool(self.workers)
+        shared_paths = self.stage.shared_paths
+        region = (self.stage.stage_bytes // self.workers) & ~4095
+        previous, pending, at = None, [], 0
+        try:
+            while at < len(todo):
+                slot, _ = self.stage.acquire()
+                per_job = int(min(64, max(1, region // (2 * max(self.bytes_per_image, 1)))))
+                pending = []
+                for r in range(self.workers):
+                    part = todo[at:at + per_job]
+                    if not part:
+                        break
+                    at += len(part)
+                    job = (shared_paths[slot], r * region, region, [str(self.tasks[k][1]) for k in part])
+                    pending.append((part, pool.submit(_decode_into_shared, job)))
+                if previous is not None:
+                    self._collect(previous[1], previous[0], previous[2], out)
+                    previous = None
+                positions, placed, spills, nbytes = [], [], [], 0
+                for part, fut in pending:
+                    for k, res in zip(part, fut.result()):
+                        if res == "spill":                        # did not fit its worker's region: decoded here, hashed on its own
+                            arr = _read_pixels(str(self.tasks[k][1]))
+                            if arr is not None and arr.size:
+                                spills.append((len(positions), arr))
+                                positions.append(k)
+                        elif res is not None:
+                            placed.append((len(positions), res))
+                            positions.append(k)
+                            nbytes += res[1] * res[2] * res[3]
+                pending = []
+                if placed:
+                    self.bytes_per_image = max(1, nbytes // len(placed))
+                handle = None
+                if placed:
+                    handle = self.stage.submit(slot, [d[0] for _, d in placed], [d[1] for _, d in placed],
+                                               [d[2] for _, d in placed], [d[3] for _, d in placed])
+                previous = (positions, slot, ([i for i, _ in placed], handle, spills))
+            if previous is not None:
+                self._collect(previous[1], previous[0], previous[2], out)
+        finally:
+            for _, fut in pending:                                # nobody may still be writing into a staging buffer
+                try:
+                    fut.result()
+                except Exception:
+                    pass
+
     def _decode_with_pillow(self, todo: Sequence[int], out: dict) -> None:
+        if self.workers > 1 and len(todo) >= self.process_min and getattr(self.stage, "shared_paths", None):
+            try:
+                return self._decode_with_processes(todo, out)
+            except BrokenProcessPool:                             # e.g. a __main__ the children cannot import: threads after all
+                _pools.pop(self.workers, None)
+                self.process_min = 1 << 62
+                todo = [k for k in todo if k not in out]
         previous = None                                           # (positions, slot, submitted) of the chunk on the GPU
         for c0 in range(0, len(todo), self.chunk):
             positions = todo[c0:c0 + self.chunk]

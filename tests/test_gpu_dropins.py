@@ -78,6 +78,34 @@ def test_fast_fill_spills_past_a_small_staging_buffer(K, tmp_path, monkeypatch):
         assert (ph, dh) == (O.to_signed64(ep), O.to_signed64(ed))
 
 
+def test_fast_fill_on_decoder_processes(K, tmp_path, monkeypatch):
+    """The Pillow route on a spawn-context process pool writing into shared, page-locked staging buffers
+    (ke_stage_create_shared): same rows as the thread route and as the oracle -- also when a worker's region of the buffer
+    is too small for its files (decoded by the parent instead) and when files are missing or broken."""
+    items, arrays = _corpus(tmp_path)
+    items.insert(3, (77, str(tmp_path / "does_not_exist.png")))
+    (tmp_path / "broken.bmp").write_bytes(b"not an image")
+    items.insert(5, (78, str(tmp_path / "broken.bmp")))
+    monkeypatch.setenv("KE_GPU_PNG", "0")                        # every file takes the Pillow route
+    monkeypatch.setenv("KE_GPU_JPEG", "0")
+    monkeypatch.setenv("KE_DECODE_PROCESSES", "0")
+    by_threads = K.compute_signatures_mp(items, max_workers=3, chunksize=6)
+    monkeypatch.setenv("KE_DECODE_PROCESSES", "1")
+    monkeypatch.setenv("KE_DECODE_PROCESS_MIN", "1")
+    import kobato_eyes_amd.fastsig as fs
+
+    fs._stop_pools()
+    by_processes = K.compute_signatures_mp(items, max_workers=3, chunksize=6)
+    assert 3 in fs._pools                                        # the pool was made, i.e. the process route ran
+    monkeypatch.setenv("KE_STAGE_BYTES", str(300 * 1024))       # 100 KB per worker: most files do not fit their region
+    squeezed = K.compute_signatures_mp(items, max_workers=3, chunksize=6)
+    assert by_processes == by_threads and squeezed == by_threads
+    assert [fid for fid, _, _ in by_threads] == [fid for fid, _ in items if fid < 70]
+    for fid, ph, dh in by_processes:
+        ep, ed = O.hash_image(arrays[fid])
+        assert (ph, dh) == (O.to_signed64(ep), O.to_signed64(ed))
+
+
 def test_ensure_signatures(K):
     conn = _make_conn()
     for file_id in range(1, 21):

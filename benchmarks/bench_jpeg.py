@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--quality", type=int, default=85)
     ap.add_argument("--subsampling", type=int, default=2)
     ap.add_argument("--format", choices=["jpeg", "png"], default="jpeg")
+    ap.add_argument("--progressive", action="store_true", help="JPEG: progressive files (libjpeg's default scan script)")
     ap.add_argument("--content", choices=["corpus", "drawing"], default="corpus",
                     help="corpus: the synthetic corpus images (textured, photograph-like: PNG stays near half its raw size); "
                          "drawing: flat 16-px cells, a few ramps and thin outlines (illustration-like: PNG shrinks 20-50x)")
@@ -52,7 +53,7 @@ def main():
         if args.format == "png":
             Image.fromarray(px[k]).save(b, "PNG")
         else:
-            Image.fromarray(px[k]).save(b, "JPEG", quality=args.quality, subsampling=args.subsampling)
+            Image.fromarray(px[k]).save(b, "JPEG", quality=args.quality, subsampling=args.subsampling, progressive=args.progressive)
         files.append(b.getvalue())
     blobs = [files[k % distinct] for k in range(args.images)]
     comp_bytes = sum(len(b) for b in blobs)
@@ -82,7 +83,7 @@ def main():
         list(ex.map(dec, sample, chunksize=8))
     t_cpu = time.perf_counter() - t0
     wall, kern = float(np.median(t_wall)), float(np.median(t_kern))
-    print(json.dumps({"case": args.format + "_decode", "content": args.content, "images": args.images, "side": args.side, "quality": args.quality,
+    print(json.dumps({"case": args.format + ("_progressive" if args.progressive else "") + "_decode", "content": args.content, "images": args.images, "side": args.side, "quality": args.quality,
                       "subsampling": ["4:4:4", "4:2:2", "4:2:0"][args.subsampling], "compressed_mb": comp_bytes / 1e6,
                       "decode_kernels_ms": kern, "decode_images_per_s": args.images / (kern * 1e-3),
                       "decode_plus_hash_wall_ms": wall * 1e3, "decode_plus_hash_images_per_s": args.images / wall,

@@ -150,9 +150,9 @@ __global__ __launch_bounds__(64) void ke_jpeg_entropy(const KeJpegDev *__restric
     __shared__ __attribute__((aligned(16))) uint8_t s_blk[64 * kBlkPitch];
     const int lane = threadIdx.x;
     const int64_t i = (int64_t)blockIdx.x * 64 + lane;
-    const bool live = i < n;
-    const KeJpegDev &d = imgs[live ? i : n - 1];
+    const KeJpegDev &d = imgs[i < n ? i : n - 1];
     const KeJpegInfo &in = d.info;
+    const bool live = i < n && !in.progressive;          // progressive files are ke_jpeg_entropy_prog's
     // the workgroup's distinct tables (files of one encoder share them): up to four go to LDS
     if (lane == 0) { s_count = 0; s_all = 1; }
     s_zz[lane] = c_zigzag[lane];
@@ -246,6 +246,180 @@ __global__ __launch_bounds__(64) void ke_jpeg_entropy(const KeJpegDev *__restric
         }
     }
     if (rc == KE_JPEG_OK && bits.overrun > 8) rc = KE_JPEG_CORRUPT;     // ran past the data: truncated file (Pillow raises)
+    status[i] = rc;
+}
+
+// ---- progressive files.  One thread per image again, scan after scan into the image's coefficient array (zeroed before).
+// Every scan of such a file comes with its own optimised Huffman tables, so nothing can be shared between lanes or kept from
+// scan to scan: a lane builds the canonical form of its scan's tables -- 16 limits, 16 bases, the symbols in code order --
+// into its slices of LDS from the DHT bytes of the file (as the PNG kernel does for deflate) and decodes by comparison.
+// What a scan writes needs no read-back except in AC refinement scans: first DC / AC scans store coefficients straight to
+// HBM, a DC refinement is one atomic OR per block; AC refinement pulls the block into LDS, works there and puts it back.
+
+struct ProgTables {            // per lane: three slots (the components of a DC scan; slot 0 for AC scans)
+    uint32_t *lim;             // slot s, dword k (limits of lengths 2k+1 | 2k+2 in halves) at lim[64 * (8 * s + k)]
+    uint32_t *base;            // same layout, int16 halves
+    uint8_t *sym;              // slot s symbol j at sym[64 * (16 * s + j)] (DC: <= 16 symbols a slot; AC: slot 0, 256)
+};
+
+// DHT payload (16 counts, then the symbols) -> canonical form; false when the counts are not a prefix code
+__device__ __forceinline__ bool prog_build(const ProgTables &t, int slot, const uint8_t *dht, int max_syms) {
+    uint32_t code = 0, off = 0, lw = 0, bw = 0;
+    bool ok = true;
+    for (int l = 1; l <= 16; ++l) {
+        const uint32_t cnt = dht[l - 1];
+        const uint32_t b = (off - code) & 0xFFFFu;                 // symbol index = code + base
+        code += cnt;
+        ok = ok && code <= (1u << l);
+        const uint32_t limit = min(code << (16 - l), 0xFFFFu);     // one past the last code of this length, left-aligned
+        if (l & 1) { lw = limit; bw = b; } else { t.lim[64 * (8 * slot + (l >> 1) - 1)] = lw | (limit << 16); t.base[64 * (8 * slot + (l >> 1) - 1)] = bw | (b << 16); }
+        off += cnt;
+        code <<= 1;
+    }
+    ok = ok && off <= (uint32_t)max_syms;
+    const uint32_t n = min(off, (uint32_t)max_syms);
+    for (uint32_t j = 0; j < n; ++j) t.sym[64 * (16 * slot + j)] = dht[16 + j];
+    return ok;
+}
+
+struct ProgReader {            // the reader of ke_prog_*
+    KeBits &b;
+    Stream &st;
+    const ProgTables &t;
+    int sym_mask;              // symbols a slot can hold - 1
+    __device__ __forceinline__ int sym(int slot) {
+        bits_fill(b, st);
+        const uint32_t v = ke_bits_peek(b, 16);
+        int reached = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t w = t.lim[64 * (8 * slot + k)];
+            reached += (int)(v >= (w & 0xFFFFu)) + (int)(v >= (w >> 16));
+        }
+        if (reached >= 16) return -1;                              // beyond the last code
+        const int len = reached + 1;
+        const uint32_t bw = t.base[64 * (8 * slot + (reached >> 1))];
+        const int base = (int)(int16_t)((reached & 1) ? bw >> 16 : bw & 0xFFFFu);
+        ke_bits_skip(b, len);
+        return t.sym[64 * (16 * slot + (((int)(v >> (16 - len)) + base) & sym_mask))];
+    }
+    __device__ __forceinline__ uint32_t bits(int k) {
+        bits_fill(b, st);
+        const uint32_t v = ke_bits_peek(b, k);
+        ke_bits_skip(b, k);
+        return v;
+    }
+    __device__ __forceinline__ int bit() { return (int)bits(1); }
+};
+
+struct StoreBlock {            // a block that is only written: coefficients go straight to HBM
+    int16_t *g;
+    struct Ref {
+        int16_t *p;
+        __device__ __forceinline__ void operator=(int16_t v) { *p = v; }
+    };
+    __device__ __forceinline__ Ref operator[](int pos) const { return Ref{g + pos}; }
+};
+
+__global__ __launch_bounds__(64) void ke_jpeg_entropy_prog(const KeJpegDev *__restrict__ imgs, const int32_t *__restrict__ list, int64_t n,
+                                                           const uint8_t *__restrict__ files, const KeJpegScan *__restrict__ scans,
+                                                           int16_t *__restrict__ coefs, int32_t *__restrict__ status) {
+    __shared__ uint32_t s_lim[24 * 64], s_base[24 * 64];
+    __shared__ uint8_t s_sym[256 * 64];
+    __shared__ uint8_t s_zz[64];
+    __shared__ __attribute__((aligned(16))) uint8_t s_win[64 * kWinPitch];
+    __shared__ __attribute__((aligned(16))) uint8_t s_blk[64 * kBlkPitch];
+    const int lane = threadIdx.x;
+    s_zz[lane] = c_zigzag[lane];
+    __syncthreads();
+    const int64_t slot_i = (int64_t)blockIdx.x * 64 + lane;
+    if (slot_i >= n) return;
+    const int32_t i = list[slot_i];
+    const KeJpegDev &d = imgs[i];
+    const KeJpegInfo &in = d.info;
+    const uint8_t *file = files + d.file_off;
+    ProgTables tab{s_lim + lane, s_base + lane, s_sym + lane};
+    Stream st;
+    st.file = file;
+    st.win = s_win + lane * kWinPitch;
+    int16_t *lblk = reinterpret_cast<int16_t *>(s_blk + lane * kBlkPitch);
+    int16_t *base = coefs + d.coef_off;
+    int rc = KE_JPEG_OK;
+    for (int si = 0; si < in.nscans && rc == KE_JPEG_OK; ++si) {
+        const KeJpegScan &sc = scans[in.first_scan + si];
+        const int ss = sc.ss, se = sc.se, ah = sc.ah, al = sc.al, ns = sc.ncomp, ri = sc.restart_interval;
+        const bool dc = ss == 0;
+        if (!(dc && ah != 0)) {                                      // a DC refinement is raw bits, no table
+            for (int k = 0; k < (dc ? ns : 1); ++k)
+                if (!prog_build(tab, k, file + (dc ? sc.dc_dht[k] : sc.ac_dht[0]), dc ? 16 : 256)) rc = KE_JPEG_CORRUPT;
+            if (rc != KE_JPEG_OK) break;
+        }
+        KeBits bits;
+        ke_bits_init(bits, file, sc.offset, sc.end);
+        st.end = sc.end;
+        stream_load(st, sc.offset);
+        ProgReader rd{bits, st, tab, dc ? 15 : 255};
+        int pred[3] = {0, 0, 0};
+        uint32_t eobrun = 0;
+        int restart_left = ri;
+        if (dc) {
+            // MCUs of hs x vs blocks per component when several components share the scan, single blocks otherwise
+            const bool inter = ns > 1;
+            const int c0 = sc.comp[0];
+            const int units_x = inter ? in.mcus_x : (in.comp_w[c0] + 7) >> 3, units_y = inter ? in.mcus_y : (in.comp_h[c0] + 7) >> 3;
+            for (int uy = 0; uy < units_y && rc == KE_JPEG_OK; ++uy)
+                for (int ux = 0; ux < units_x && rc == KE_JPEG_OK; ++ux) {
+                    if (ri && restart_left == 0) {
+                        if (ke_bits_restart(bits) != KE_JPEG_OK) { rc = KE_JPEG_CORRUPT; break; }
+                        pred[0] = pred[1] = pred[2] = 0;
+                        restart_left = ri;
+                    }
+                    for (int k = 0; k < ns && rc == KE_JPEG_OK; ++k) {
+                        const int c = sc.comp[k];
+                        const int hs = inter ? in.hs[c] : 1, vs = inter ? in.vs[c] : 1, bpr = in.plane_w[c] >> 3;
+                        for (int by = 0; by < vs && rc == KE_JPEG_OK; ++by)
+                            for (int bx = 0; bx < hs; ++bx) {
+                                int16_t *g = base + ((size_t)d.block_base[c] + (size_t)(uy * vs + by) * bpr + (ux * hs + bx)) * 64;
+                                if (ah == 0) {
+                                    int v;
+                                    if (ke_prog_dc_first(rd, k, pred[k], al, &v) != KE_JPEG_OK) { rc = KE_JPEG_CORRUPT; break; }
+                                    g[0] = (int16_t)v;
+                                } else if (rd.bit()) {
+                                    // coefficient 0 is the low half of the block's first dword: one more bit, no read-back
+                                    atomicOr(reinterpret_cast<unsigned int *>(g), 1u << al);
+                                }
+                            }
+                    }
+                    --restart_left;
+                }
+        } else {
+            const int c = sc.comp[0], bpr = in.plane_w[c] >> 3;
+            const int bw = (in.comp_w[c] + 7) >> 3, bh = (in.comp_h[c] + 7) >> 3;
+            for (int brow = 0; brow < bh && rc == KE_JPEG_OK; ++brow)
+                for (int bcol = 0; bcol < bw; ++bcol) {
+                    if (ri && restart_left == 0) {
+                        if (ke_bits_restart(bits) != KE_JPEG_OK) { rc = KE_JPEG_CORRUPT; break; }
+                        eobrun = 0;
+                        restart_left = ri;
+                    }
+                    int16_t *g = base + ((size_t)d.block_base[c] + (size_t)brow * bpr + bcol) * 64;
+                    if (ah == 0) {
+                        StoreBlock blk{g};
+                        if (ke_prog_ac_first(rd, 0, blk, s_zz, ss, se, al, eobrun) != KE_JPEG_OK) { rc = KE_JPEG_CORRUPT; break; }
+                    } else {
+                        const uint4 *src = reinterpret_cast<const uint4 *>(g);
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) reinterpret_cast<uint4 *>(lblk)[k] = src[k];
+                        if (ke_prog_ac_refine(rd, 0, lblk, s_zz, ss, se, al, eobrun) != KE_JPEG_OK) { rc = KE_JPEG_CORRUPT; break; }
+                        uint4 *dst = reinterpret_cast<uint4 *>(g);
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) dst[k] = reinterpret_cast<const uint4 *>(lblk)[k];
+                    }
+                    --restart_left;
+                }
+        }
+        if (rc == KE_JPEG_OK && bits.overrun > 8) rc = KE_JPEG_CORRUPT;   // ran past the scan's data: truncated file (Pillow raises)
+    }
     status[i] = rc;
 }
 
@@ -357,14 +531,16 @@ KE_API int ke_jpeg_decode(ke_ctx *ctx, const uint8_t *files, const uint64_t *off
         KeJpegTables tables;
         std::vector<KeJpegDev> devs;
         std::vector<int64_t> which;
+        std::vector<KeJpegScan> scans;
         uint64_t lo = ~0ull, hi = 0;
     };
     std::vector<Part> parts(16);
     const int nparts = ke_parallel_ranges(n, [&](int64_t first, int64_t last, int t) {
         Part &p = parts[(size_t)t];
+        p.tables.sequential_only = true;
         for (int64_t i = first; i < last; ++i) {
             KeJpegDev d;
-            ke_parse_jpeg(files + offsets[i], (size_t)sizes[i], p.tables, d.info);
+            ke_parse_jpeg(files + offsets[i], (size_t)sizes[i], p.tables, d.info, true, &p.scans);
             status_out[i] = d.info.status;
             if (d.info.status != KE_JPEG_OK) continue;
             d.file_off = offsets[i];
@@ -378,16 +554,20 @@ KE_API int ke_jpeg_decode(ke_ctx *ctx, const uint8_t *files, const uint64_t *off
     KeJpegTables tables;                              // one pool for the batch: every part's tables interned again
     std::vector<KeJpegDev> devs;
     std::vector<int64_t> which;                       // batch position of every decodable image
+    std::vector<KeJpegScan> scans;                    // of the progressive files, image after image
     uint64_t lo = ~0ull, hi = 0;
     for (int t = 0; t < nparts; ++t) {
         Part &p = parts[(size_t)t];
+        for (KeJpegDev &d : p.devs)
+            if (d.info.progressive) d.info.first_scan += (uint32_t)scans.size();
+        scans.insert(scans.end(), p.scans.begin(), p.scans.end());
         std::vector<int> remap(p.tables.keys.size());
         for (size_t k = 0; k < remap.size(); ++k) {
             const std::vector<uint8_t> &key = p.tables.keys[k];
             remap[k] = tables.intern(key.data(), key.data() + 16, (int)key.size() - 16);
         }
         for (KeJpegDev &d : p.devs)
-            for (int c = 0; c < d.info.ncomp; ++c) {
+            for (int c = 0; c < d.info.ncomp && !d.info.progressive; ++c) {
                 d.info.huff_dc[c] = remap[(size_t)d.info.huff_dc[c]];
                 d.info.huff_ac[c] = remap[(size_t)d.info.huff_ac[c]];
             }
@@ -404,6 +584,12 @@ KE_API int ke_jpeg_decode(ke_ctx *ctx, const uint8_t *files, const uint64_t *off
     void *d_tables;
     KE_TRY(ke_reserve(ctx, KE_BUF_JPEG_TABLES, tables.pool.size() * sizeof(KeHuffTable), &d_tables));
     KE_HIP(ctx, hipMemcpyAsync(d_tables, tables.pool.data(), tables.pool.size() * sizeof(KeHuffTable), hipMemcpyHostToDevice, ctx->stream));
+    void *d_scans = nullptr;
+    if (!scans.empty()) {
+        KE_TRY(ke_reserve(ctx, KE_BUF_SSIM_AUX, scans.size() * sizeof(KeJpegScan), &d_scans));
+        KE_HIP(ctx, hipMemcpyAsync(d_scans, scans.data(), scans.size() * sizeof(KeJpegScan), hipMemcpyHostToDevice, ctx->stream));
+    }
+    std::vector<int32_t> prog_list;
     // sub-batches bounded by scratch: coefficients (2 B per sample) + planes (1 B per sample)
     // one thread per image: the larger the sub-batch the better the chip is filled -- up to a third of the free HBM
     size_t free_b = 0, total_b = 0;
@@ -448,10 +634,33 @@ KE_API int ke_jpeg_decode(ke_ctx *ctx, const uint8_t *files, const uint64_t *off
         KE_TRY(ke_reserve(ctx, KE_BUF_SSIM_IN, (size_t)plane_bytes + 64, &d_planes));
         KE_TRY(ke_reserve(ctx, KE_BUF_OUT0, (size_t)m * 4, &d_status));
         KE_HIP(ctx, hipMemcpyAsync(d_imgs, devs.data() + first, (size_t)m * sizeof(KeJpegDev), hipMemcpyHostToDevice, ctx->stream));
-        // no clearing of the coefficient array: every block of an image that decodes is written whole; a damaged image's
-        // remaining blocks hold whatever was there, and its pixels are discarded with its status
-        hipLaunchKernelGGL(ke_jpeg_entropy, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, ctx->stream, (const KeJpegDev *)d_imgs, m,
-                           (const uint8_t *)d_files, (const KeHuffTable *)d_tables, (int16_t *)d_coef, (int32_t *)d_status);
+        // sequential files: no clearing of the coefficient array, every block of an image that decodes is written whole (a
+        // damaged image's remaining blocks hold whatever was there, and its pixels are discarded with its status);
+        // progressive files build their coefficients up scan by scan, from zero
+        prog_list.clear();
+        for (int64_t k = 0; k < m; ++k)
+            if (devs[first + (size_t)k].info.progressive) prog_list.push_back((int32_t)k);
+        if ((int64_t)prog_list.size() < m)
+            hipLaunchKernelGGL(ke_jpeg_entropy, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, ctx->stream, (const KeJpegDev *)d_imgs, m,
+                               (const uint8_t *)d_files, (const KeHuffTable *)d_tables, (int16_t *)d_coef, (int32_t *)d_status);
+        if (!prog_list.empty()) {
+            void *d_list;
+            KE_TRY(ke_reserve(ctx, KE_BUF_OUT1, prog_list.size() * 4, &d_list));
+            KE_HIP(ctx, hipMemcpyAsync(d_list, prog_list.data(), prog_list.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+            size_t run0 = 0;                           // their coefficients to zero, one memset per run of neighbours in the batch
+            while (run0 < prog_list.size()) {
+                size_t run1 = run0;
+                while (run1 + 1 < prog_list.size() && prog_list[run1 + 1] == prog_list[run1] + 1) ++run1;
+                const KeJpegDev &a = devs[first + (size_t)prog_list[run0]], &b = devs[first + (size_t)prog_list[run1]];
+                const uint64_t from = a.coef_off, to = b.coef_off + (uint64_t)b.blocks_total * 64;
+                KE_HIP(ctx, hipMemsetAsync((int16_t *)d_coef + from, 0, (size_t)(to - from) * 2, ctx->stream));
+                run0 = run1 + 1;
+            }
+            const int64_t np = (int64_t)prog_list.size();
+            hipLaunchKernelGGL(ke_jpeg_entropy_prog, dim3((unsigned)((np + 63) / 64)), dim3(64), 0, ctx->stream, (const KeJpegDev *)d_imgs,
+                               (const int32_t *)d_list, np, (const uint8_t *)d_files, (const KeJpegScan *)d_scans, (int16_t *)d_coef,
+                               (int32_t *)d_status);
+        }
         hipLaunchKernelGGL(ke_jpeg_idct, dim3((unsigned)((max_blocks + 255) / 256), (unsigned)m), dim3(256), 0, ctx->stream,
                            (const KeJpegDev *)d_imgs, (const int16_t *)d_coef, (uint8_t *)d_planes);
         hipLaunchKernelGGL(ke_jpeg_colour, dim3((unsigned)((max_quads + 255) / 256), (unsigned)m), dim3(256), 0, ctx->stream,

@@ -9,7 +9,8 @@
 //   upsampling         : jdsample.c "fancy" triangle filters h2v1 / h2v2 (do_fancy_upsampling is libjpeg's default), edge
 //                        rows and columns replicated as jdmainct.c presents them;
 //   colour             : jdcolor.c YCbCr -> RGB with its 16-bit fixed-point tables.
-// Progressive, arithmetic-coded, 12-bit, CMYK/YCCK, RGB-coded and 4:4:0 / 4:1:1-style files are refused by the parser
+//   progressive files  : T.81 G.1.2 (spectral selection, successive approximation), scan by scan into one coefficient array;
+// Arithmetic-coded, 12-bit, CMYK/YCCK, RGB-coded and 4:4:0 / 4:1:1-style files are refused by the parser
 // (KE_JPEG_UNSUPPORTED) and stay with Pillow.
 #pragma once
 
@@ -44,6 +45,20 @@ struct KeJpegInfo {
     uint32_t scan_offset, scan_end;    // entropy-coded bytes [scan_offset, scan_end) inside the file
     int32_t huff_dc[3], huff_ac[3];    // indices into the batch's table pool
     uint16_t quant[3][64];             // per component, natural (row-major) order
+    int32_t progressive;               // SOF2: the scans below instead of the one [scan_offset, scan_end)
+    int32_t nscans;
+    uint32_t first_scan;               // index of the image's first KeJpegScan in the batch's scan list
+};
+
+// One scan of a progressive file (T.81 G.1): a band [ss, se] of the zigzag sequence at bit position al (ah: the position the
+// previous scan of the band stopped at; 0 = first scan), for one component (any AC scan) or several (DC scans).
+struct KeJpegScan {
+    uint32_t offset, end;              // entropy-coded bytes [offset, end) inside the file
+    int32_t restart_interval;
+    int32_t ncomp, comp[3];            // component indices of the frame
+    int32_t ss, se, ah, al;
+    int32_t dc_tab[3], ac_tab[3];      // per scan component: indices into the batch's table pool (host-side decoding)
+    uint32_t dc_dht[3], ac_dht[3];     // ... and where the table's DHT payload (16 counts, then the symbols) lies in the file
 };
 
 // zigzag position -> natural (row-major) index
@@ -166,6 +181,97 @@ KE_HD int ke_decode_block(KeBits &b, const KeHuffTable &dc, const KeHuffTable &a
         const int nat = zz[k];
         blk[nat] = ke_receive_extend(b, s) * (int)quant[nat];
         ++k;
+    }
+    return KE_JPEG_OK;
+}
+
+// ---- progressive scans (T.81 G.1.2, as jdphuff.c decodes them).  Rd is the caller's reader: sym(slot) = one Huffman symbol
+// of the scan's table `slot` (-1 = invalid code), bits(k) = k raw bits (k <= 16), bit().  Blk holds the block's 64
+// coefficients in natural order (int16 values); zz is the zigzag table.
+
+// first DC scan: the difference is coded as in a sequential file, the coefficient is stored shifted left by al
+template <typename Rd>
+KE_HD int ke_prog_dc_first(Rd &rd, int slot, int &pred, int al, int *value) {
+    const int s = rd.sym(slot);
+    if (s < 0 || s > 11) return KE_JPEG_CORRUPT;     // 11 bits of DC difference at most for 8-bit samples
+    int diff = 0;
+    if (s) {
+        const int v = (int)rd.bits(s);
+        diff = v < (1 << (s - 1)) ? v - (1 << s) + 1 : v;
+    }
+    pred += diff;
+    *value = (int)((uint32_t)pred << al);
+    return KE_JPEG_OK;
+}
+
+// first scan of an AC band (G.1.2.2): run/size symbols, end-of-band runs that span blocks
+template <typename Rd, typename Blk>
+KE_HD int ke_prog_ac_first(Rd &rd, int slot, Blk &blk, const uint8_t *zz, int ss, int se, int al, uint32_t &eobrun) {
+    if (eobrun > 0) { --eobrun; return KE_JPEG_OK; }
+    for (int k = ss; k <= se; ++k) {
+        const int rs = rd.sym(slot);
+        if (rs < 0) return KE_JPEG_CORRUPT;
+        const int r = rs >> 4, s = rs & 15;
+        if (s) {
+            k += r;
+            if (k > 63) return KE_JPEG_CORRUPT;
+            const int v = (int)rd.bits(s);
+            const int coef = v < (1 << (s - 1)) ? v - (1 << s) + 1 : v;
+            blk[zz[k]] = (int16_t)((uint32_t)coef << al);
+        } else if (r == 15) {
+            k += 15;                                 // sixteen zeros
+        } else {
+            eobrun = 1u << r;                        // this block and eobrun - 1 more end here
+            if (r) eobrun += rd.bits(r);
+            --eobrun;
+            break;
+        }
+    }
+    return KE_JPEG_OK;
+}
+
+// refinement scan of an AC band (G.1.2.3): one more bit for every coefficient that is already nonzero, new +-1 << al
+// coefficients in between
+template <typename Rd, typename Blk>
+KE_HD int ke_prog_ac_refine(Rd &rd, int slot, Blk &blk, const uint8_t *zz, int ss, int se, int al, uint32_t &eobrun) {
+    const int p1 = 1 << al, m1 = -(1 << al);
+    int k = ss;
+    if (eobrun == 0) {
+        for (; k <= se; ++k) {
+            const int rs = rd.sym(slot);
+            if (rs < 0) return KE_JPEG_CORRUPT;
+            int r = rs >> 4, s = rs & 15;
+            if (s) {
+                s = rd.bit() ? p1 : m1;              // the size of a new coefficient is always 1; its sign follows
+            } else if (r != 15) {
+                eobrun = 1u << r;
+                if (r) eobrun += rd.bits(r);
+                break;                               // the rest of the band belongs to the end-of-band run
+            }
+            // skip r still-zero coefficients; every nonzero one passed on the way takes a correction bit
+            do {
+                const int pos = zz[k];
+                const int c = blk[pos];
+                if (c != 0) {
+                    if (rd.bit() && (c & p1) == 0) blk[pos] = (int16_t)(c + (c >= 0 ? p1 : m1));
+                } else if (--r < 0) {
+                    break;
+                }
+                ++k;
+            } while (k <= se);
+            if (s) {
+                if (k > 63) return KE_JPEG_CORRUPT;
+                blk[zz[k]] = (int16_t)s;
+            }
+        }
+    }
+    if (eobrun > 0) {
+        for (; k <= se; ++k) {
+            const int pos = zz[k];
+            const int c = blk[pos];
+            if (c != 0 && rd.bit() && (c & p1) == 0) blk[pos] = (int16_t)(c + (c >= 0 ? p1 : m1));
+        }
+        --eobrun;
     }
     return KE_JPEG_OK;
 }

@@ -6,13 +6,92 @@
 
 #include "../kobato-eyes_amd/csrc/ke_jpeg_parse.h"
 
+namespace {
+
+struct TableReader {       // the reader of ke_prog_*: Huffman symbols through the parsed look-up tables
+    KeBits &b;
+    const KeJpegTables &tables;
+    const int32_t *ids;    // table of each slot
+    int sym(int slot) { return ke_huff_decode(b, tables.pool[(size_t)ids[slot]]); }
+    uint32_t bits(int k) {
+        ke_bits_fill(b);
+        const uint32_t v = ke_bits_peek(b, k);
+        ke_bits_skip(b, k);
+        return v;
+    }
+    int bit() { return (int)bits(1); }
+};
+
+// every scan of a progressive file into coef[c] (blocks of the padded planes, 64 int16 each, natural order)
+int decode_progressive(const uint8_t *file, const KeJpegTables &tables, const KeJpegInfo &info, const std::vector<KeJpegScan> &scans,
+                       std::vector<int16_t> *coef) {
+    for (int si = 0; si < info.nscans; ++si) {
+        const KeJpegScan &sc = scans[info.first_scan + (size_t)si];
+        KeBits bits;
+        ke_bits_init(bits, file, sc.offset, sc.end);
+        TableReader rd{bits, tables, sc.ss == 0 ? sc.dc_tab : sc.ac_tab};
+        int pred[3] = {0, 0, 0};
+        uint32_t eobrun = 0;
+        int restart_left = sc.restart_interval;
+        auto block = [&](int k, int c, int brow, int bcol) -> int {
+            int16_t *blk = coef[c].data() + ((size_t)brow * (info.plane_w[c] >> 3) + bcol) * 64;
+            if (sc.ss == 0) {
+                if (sc.ah == 0) {
+                    int v;
+                    if (ke_prog_dc_first(rd, k, pred[k], sc.al, &v) != KE_JPEG_OK) return KE_JPEG_CORRUPT;
+                    blk[0] = (int16_t)v;
+                } else if (rd.bit()) {
+                    blk[0] = (int16_t)(blk[0] | (1 << sc.al));
+                }
+                return KE_JPEG_OK;
+            }
+            return sc.ah == 0 ? ke_prog_ac_first(rd, k, blk, kKeZigzag, sc.ss, sc.se, sc.al, eobrun)
+                              : ke_prog_ac_refine(rd, k, blk, kKeZigzag, sc.ss, sc.se, sc.al, eobrun);
+        };
+        auto restart = [&]() -> int {
+            if (sc.restart_interval && restart_left == 0) {
+                if (ke_bits_restart(bits) != KE_JPEG_OK) return KE_JPEG_CORRUPT;
+                pred[0] = pred[1] = pred[2] = 0;
+                eobrun = 0;
+                restart_left = sc.restart_interval;
+            }
+            return KE_JPEG_OK;
+        };
+        if (sc.ncomp > 1) {                                  // interleaved: MCUs of hs x vs blocks per component, padding blocks coded
+            for (int my = 0; my < info.mcus_y; ++my)
+                for (int mx = 0; mx < info.mcus_x; ++mx) {
+                    if (restart() != KE_JPEG_OK) return KE_JPEG_CORRUPT;
+                    for (int k = 0; k < sc.ncomp; ++k) {
+                        const int c = sc.comp[k];
+                        for (int by = 0; by < info.vs[c]; ++by)
+                            for (int bx = 0; bx < info.hs[c]; ++bx)
+                                if (block(k, c, my * info.vs[c] + by, mx * info.hs[c] + bx) != KE_JPEG_OK) return KE_JPEG_CORRUPT;
+                    }
+                    --restart_left;
+                }
+        } else {                                             // one component: an MCU is one block, only the blocks that hold samples
+            const int c = sc.comp[0], bw = (info.comp_w[c] + 7) >> 3, bh = (info.comp_h[c] + 7) >> 3;
+            for (int brow = 0; brow < bh; ++brow)
+                for (int bcol = 0; bcol < bw; ++bcol) {
+                    if (restart() != KE_JPEG_OK) return KE_JPEG_CORRUPT;
+                    if (block(0, c, brow, bcol) != KE_JPEG_OK) return KE_JPEG_CORRUPT;
+                    --restart_left;
+                }
+        }
+        if (bits.overrun > 8) return KE_JPEG_CORRUPT;
+    }
+    return KE_JPEG_OK;
+}
+
+}  // namespace
+
 extern "C" {
 
 // widths/heights/channels/status of one file (status KE_JPEG_*)
 int ko_jpeg_probe(const uint8_t *file, uint64_t size, int32_t *w, int32_t *h, int32_t *ch) {
     KeJpegTables tables;
     KeJpegInfo info;
-    ke_parse_jpeg(file, (size_t)size, tables, info);
+    ke_parse_jpeg(file, (size_t)size, tables, info, false);
     *w = info.width; *h = info.height; *ch = info.ncomp;
     return info.status;
 }
@@ -21,16 +100,32 @@ int ko_jpeg_probe(const uint8_t *file, uint64_t size, int32_t *w, int32_t *h, in
 int ko_jpeg_decode(const uint8_t *file, uint64_t size, uint8_t *out) {
     KeJpegTables tables;
     KeJpegInfo info;
-    ke_parse_jpeg(file, (size_t)size, tables, info);
+    std::vector<KeJpegScan> scans;
+    ke_parse_jpeg(file, (size_t)size, tables, info, true, &scans);
     if (info.status != KE_JPEG_OK) return info.status;
     std::vector<uint8_t> planes[3];
     for (int c = 0; c < info.ncomp; ++c) planes[c].assign((size_t)info.plane_w[c] * info.plane_h[c], 0);
+    if (info.progressive) {
+        std::vector<int16_t> coef[3];
+        for (int c = 0; c < info.ncomp; ++c) coef[c].assign((size_t)info.plane_w[c] * info.plane_h[c], 0);
+        if (decode_progressive(file, tables, info, scans, coef) != KE_JPEG_OK) return KE_JPEG_CORRUPT;
+        for (int c = 0; c < info.ncomp; ++c) {
+            const int bpr = info.plane_w[c] >> 3, rows = info.plane_h[c] >> 3;
+            for (int brow = 0; brow < rows; ++brow)
+                for (int bcol = 0; bcol < bpr; ++bcol) {
+                    int32_t blk[64];
+                    const int16_t *src = coef[c].data() + ((size_t)brow * bpr + bcol) * 64;
+                    for (int k = 0; k < 64; ++k) blk[k] = (int32_t)src[k] * (int32_t)info.quant[c][k];
+                    ke_idct_islow(blk, planes[c].data() + (size_t)brow * 8 * info.plane_w[c] + bcol * 8, info.plane_w[c]);
+                }
+        }
+    }
     KeBits bits;
     ke_bits_init(bits, file, info.scan_offset, info.scan_end);
     int pred[3] = {0, 0, 0};
     int32_t blk[64];
     int restart_left = info.restart_interval;
-    for (int my = 0; my < info.mcus_y; ++my)
+    for (int my = 0; my < (info.progressive ? 0 : info.mcus_y); ++my)
         for (int mx = 0; mx < info.mcus_x; ++mx) {
             if (info.restart_interval && restart_left == 0) {
                 if (ke_bits_restart(bits) != KE_JPEG_OK) return KE_JPEG_CORRUPT;
@@ -48,7 +143,7 @@ int ko_jpeg_decode(const uint8_t *file, uint64_t size, uint8_t *out) {
                     }
             --restart_left;
         }
-    if (bits.overrun > 8) return KE_JPEG_CORRUPT;          // ran past the data (a few zero bytes of look-ahead are normal)
+    if (!info.progressive && bits.overrun > 8) return KE_JPEG_CORRUPT;          // ran past the data (a few zero bytes of look-ahead are normal)
     for (int y = 0; y < info.height; ++y)
         for (int x = 0; x < info.width; ++x) {
             const int Y = planes[0][(size_t)y * info.plane_w[0] + x];

@@ -43,21 +43,32 @@ def supported(full: bool = False):
                     yield f"{w}x{h}_k{kind}_s{sub}_q{q}", data, np.asarray(Image.open(io.BytesIO(data)))
             data = _save(a[:, :, 1], quality=80)
             yield f"{w}x{h}_k{kind}_gray", data, np.asarray(Image.open(io.BytesIO(data)))
+            # progressive files (libjpeg's default script: spectral selection + successive approximation, optimised tables)
+            for sub in (0, 1, 2):
+                for q in (30, 85, 100) if full or kind == 2 else (85,):
+                    data = _save(a, quality=q, subsampling=sub, progressive=True)
+                    yield f"{w}x{h}_k{kind}_s{sub}_q{q}_progressive", data, np.asarray(Image.open(io.BytesIO(data)))
+            data = _save(a[:, :, 1], quality=80, progressive=True)
+            yield f"{w}x{h}_k{kind}_gray_progressive", data, np.asarray(Image.open(io.BytesIO(data)))
     a = _image(rng, 200, 120, 2)
     for kw in ({"restart_marker_blocks": 1}, {"restart_marker_blocks": 7}, {"restart_marker_rows": 1}, {"restart_marker_rows": 3}):
         for sub in (0, 2):
-            try:
-                data = _save(a, quality=85, subsampling=sub, **kw)
-            except TypeError:                      # a Pillow without the restart options
-                continue
-            yield f"restart_{list(kw)[0]}_{list(kw.values())[0]}_s{sub}", data, np.asarray(Image.open(io.BytesIO(data)))
+            for prog in (False, True):
+                try:
+                    data = _save(a, quality=85, subsampling=sub, progressive=prog, **kw)
+                except TypeError:                      # a Pillow without the restart options
+                    continue
+                yield f"restart_{list(kw)[0]}_{list(kw.values())[0]}_s{sub}_p{int(prog)}", data, np.asarray(Image.open(io.BytesIO(data)))
 
 
 def refused():
     """Yields (name, file bytes, expected status): 1 = left to Pillow, 2 = damaged."""
     rng = np.random.default_rng(2)
     a = _image(rng, 96, 64, 2)
-    yield "progressive", _save(a, quality=85, progressive=True), 1
+    prog = _save(a, quality=85, progressive=True)
+    yield "progressive_truncated", prog[: len(prog) * 2 // 3], 2
+    cut = prog.rindex(b"\xff\xda")                       # the last scan (a refinement) dropped: libjpeg would smooth the blocks
+    yield "progressive_last_scan_missing", prog[:cut] + b"\xff\xd9", 1
     yield "cmyk", (lambda b: (Image.fromarray(a).convert("CMYK").save(b, "JPEG"), b.getvalue())[1])(io.BytesIO()), 1
     try:
         yield "rgb_coded", _save(a, quality=90, keep_rgb=True), 1

@@ -154,11 +154,13 @@ int ke_stage_submit_hash(ke_ctx *ctx, int32_t slot, const uint64_t *offsets, con
 int ke_stage_wait(ke_ctx *ctx, int32_t slot);
 
 /* ---- JPEG decode on the GPU: `Image.open(path)` + pixel access of the reference's batch hasher (src/core/fastsig.py:31-34;
- * the decode half of north-star step 1) for baseline sequential Huffman JPEGs with 8-bit samples and one scan -- grayscale
- * ("L") or YCbCr at 4:4:4 / 4:2:2 / 4:2:0 ("RGB").  The pixels are libjpeg's as Pillow drives it (islow IDCT, fancy
- * upsampling, jdcolor's fixed-point YCbCr -> RGB), bit for bit; everything else (progressive, arithmetic, 12-bit, CMYK/YCCK,
- * RGB-coded, other samplings, several scans) is reported KE_JPEG_UNSUPPORTED per file and stays with Pillow, truncated or
- * damaged entropy data KE_JPEG_CORRUPT (Pillow raises on those).  EXIF orientation is not applied -- nor does Image.open.
+ * the decode half of north-star step 1) for Huffman-coded JPEGs with 8-bit samples -- sequential files with one interleaved
+ * scan and progressive files (spectral selection + successive approximation, any scan script) -- grayscale ("L") or YCbCr at
+ * 4:4:4 / 4:2:2 / 4:2:0 ("RGB").  The pixels are libjpeg's as Pillow drives it (islow IDCT, fancy upsampling, jdcolor's
+ * fixed-point YCbCr -> RGB), bit for bit; everything else (arithmetic coding, 12-bit, CMYK/YCCK, RGB-coded, other samplings,
+ * sequential files in several scans, progressive files whose first AC coefficients are not refined to the last bit -- libjpeg
+ * smooths those) is reported KE_JPEG_UNSUPPORTED per file and stays with Pillow, truncated or damaged entropy data
+ * KE_JPEG_CORRUPT (Pillow raises on those).  EXIF orientation is not applied -- nor does Image.open.
  *
  * ke_jpeg_probe  : host only.  files + offsets[i] .. + sizes[i] = file i.  widths/heights/channels (1 or 3)/status per file,
  *                  so that the caller can lay out the pixel buffer.

@@ -1,4 +1,4 @@
-// ke_jpeg.hip -- baseline JPEG decoding on the GPU: the decode step in front of the hash path (north-star step 1; SURVEY 8 f2,
+// ke_jpeg.hip -- JPEG decoding on the GPU (sequential and progressive Huffman files): the decode step in front of the hash path (north-star step 1; SURVEY 8 f2,
 // "GPU-side JPEG decode").  Replaces `Image.open(path)` + pixel access of the reference's batch hasher
 // (src/core/fastsig.py:31-34) for the files it can take; the pixels are libjpeg's, bit for bit (ke_jpeg_core.h says which
 // of its routines are restated), so the hashes are those of the Pillow route.
@@ -6,11 +6,12 @@
 // Three kernels per batch:
 //   ke_jpeg_entropy : ONE THREAD PER IMAGE walks the image's entropy-coded segment (Huffman decoding is sequential within a
 //                     scan; the parallelism is across the batch -- a 16 384-image batch is one wave per CU, 100 000 images
-//                     fill the chip) and writes the non-zero coefficients into a zero-filled int16 array;
+//                     fill the chip) and writes every block's coefficients (int16) whole;
+//   ke_jpeg_entropy_prog : the same for progressive files, scan after scan into a zeroed coefficient array;
 //   ke_jpeg_idct    : one thread per 8x8 block: dequantise, jpeg_idct_islow, samples into padded component planes;
 //   ke_jpeg_colour  : one thread per 4 output pixels: fancy upsampling + YCbCr -> RGB (or the luma plane as it is), packed
 //                     8-bit pixels where ke_hash_images / ke_ssim_pairs expect them.
-// Compressed bytes cross PCIe (a tenth of the pixels); files the parser refuses (progressive, CMYK, ...) are reported per
+// Compressed bytes cross PCIe (a tenth of the pixels); files the parser refuses (arithmetic coding, CMYK, ...) are reported per
 // image and stay with Pillow.
 #include <algorithm>
 

@@ -1,7 +1,7 @@
 // ke_jpeg_parse.h -- host-side JPEG header parsing for the GPU decoder (and for the CPU build the tests compare against
-// Pillow): markers up to the first scan, Huffman tables into decoding form, the geometry the kernels need.  Everything
-// outside baseline sequential Huffman JPEG with 8-bit samples, one scan, grayscale or YCbCr at 4:4:4 / 4:2:2 / 4:2:0 is
-// reported as KE_JPEG_UNSUPPORTED so that the caller decodes such a file with Pillow, as the reference does for every file
+// Pillow): markers up to the first scan (every scan of a progressive file), Huffman tables into decoding form, the geometry
+// the kernels need.  Everything outside Huffman-coded JPEG with 8-bit samples -- sequential with one interleaved scan, or
+// progressive -- grayscale or YCbCr at 4:4:4 / 4:2:2 / 4:2:0 is reported as KE_JPEG_UNSUPPORTED so that the caller decodes such a file with Pillow, as the reference does for every file
 // (src/core/fastsig.py:31-34).
 #pragma once
 

@@ -212,3 +212,39 @@ def test_decode_batches_beyond_the_byte_limits_are_halved(ctx, tmp_path):
     finally:
         ctx.pack_limit, ctx.decode_limit = saved
         ctx.release_decode_buffers()
+
+
+def test_jpeg_damage_is_survived(ctx):
+    """Hundreds of damaged variants of sequential and progressive files in one call (flipped bits and random runs inside the
+    entropy-coded data, tables and scan headers overwritten, truncations): the kernels come back with a status for each and
+    the context decodes a clean batch afterwards.  (What libjpeg makes of damaged data is its own; such files go to Pillow.)"""
+    import io
+
+    from PIL import Image
+
+    rng = np.random.default_rng(33)
+    good = [c for c in J.supported() if c[2].shape[0] >= 64 and c[2].shape[1] >= 64][:24]
+    assert any("progressive" in c[0] for c in good) and any("progressive" not in c[0] for c in good)
+    blobs = []
+    for name, data, _ in good:
+        sos = data.index(b"\xff\xda")
+        for v in range(36):
+            d = bytearray(data)
+            kind = v % 4
+            if kind == 0:
+                pos = int(rng.integers(sos, len(d) - 2))
+                d[pos] ^= 1 << int(rng.integers(0, 8))
+            elif kind == 1:
+                pos = int(rng.integers(sos, max(sos + 1, len(d) - 40)))
+                d[pos:pos + 24] = rng.integers(0, 256, 24, dtype=np.uint8).tobytes()
+            elif kind == 2:                                # anywhere in the file, headers and tables included
+                pos = int(rng.integers(2, len(d) - 2))
+                d[pos] = int(rng.integers(0, 256))
+            else:
+                d = d[: int(rng.integers(sos, len(d)))]
+            blobs.append(bytes(d))
+    out, status = ctx.jpeg_decode(blobs)
+    assert set(np.unique(status).tolist()) <= {0, 1, 2}
+    assert all((a is None) == (s != 0) for a, s in zip(out, status))
+    clean, st = ctx.jpeg_decode([g[1] for g in good])
+    assert (st == 0).all() and all(np.array_equal(a, g[2]) for a, g in zip(clean, good))

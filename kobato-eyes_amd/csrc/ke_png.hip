@@ -201,7 +201,7 @@ __global__ __launch_bounds__(64) void ke_png_inflate(const KePngDev *__restrict_
     tab.dsym_ = s_dsym + threadIdx.x;
     tab.nib_ = reinterpret_cast<uint32_t *>(work + (size_t)i * kWorkBytes);
     tab.lim0 = tab.lim1 = tab.base0 = tab.base1 = Oct{0, 0, 0, 0, 0, 0, 0, 0};
-    const uint32_t want = (uint32_t)(d.info.width * d.info.channels + 1) * (uint32_t)d.info.height;
+    const uint32_t want = (uint32_t)(d.info.row_bytes + 1) * (uint32_t)d.info.height;
     uint32_t trailer = 0;
     int rc = ke_inflate_zlib(bits, sink, d.info.zlen, want, tab, &trailer);
     if (rc == KE_PNG_OK && sink.n != want) rc = KE_PNG_CORRUPT;
@@ -297,16 +297,24 @@ __device__ __forceinline__ uint32_t recon_pixel(uint32_t ft, uint32_t x, uint32_
     return o;
 }
 
-template <int BPP>
+// MAPPED: palette files and grayscale below 8 bits.  The filters work on the packed bytes (one byte is the filter unit);
+// every byte then unpacks to 8 / depth samples, most significant bits first, and each sample goes out as the luma in the
+// image's table.
+template <int BPP, bool MAPPED>
 __global__ __launch_bounds__(64) void ke_png_unfilter(const KePngDev *__restrict__ imgs, const uint8_t *__restrict__ raw,
                                                       uint8_t *__restrict__ out, int32_t *__restrict__ status,
                                                       const uint32_t *__restrict__ adler) {
     extern __shared__ uint32_t s_row[];               // the pixels of lane 63's row, for lane 0's next one
+    __shared__ uint8_t s_lut[MAPPED ? 256 : 4];
     const int64_t i = blockIdx.x;
     const KePngDev &d = imgs[i];
-    if (d.info.channels != BPP || status[i] != KE_PNG_OK) return;
+    if (d.info.channels != BPP || (d.info.mapped != 0) != MAPPED || status[i] != KE_PNG_OK) return;
     const int lane = threadIdx.x;
-    const int W = d.info.width, H = d.info.height;
+    if (MAPPED) {
+        for (int k = lane; k < 256; k += 64) s_lut[k] = d.info.lut[k];
+        __syncthreads();
+    }
+    const int W = d.info.row_bytes / BPP, H = d.info.height;      // filter units per row (pixels, or packed bytes)
     const uint32_t rb = (uint32_t)W * BPP, stride = rb + 1;
     const int groups = (W + 3) >> 2;                  // four pixels at a time
     const int period = groups > 64 ? groups : 64;     // lane 0 starts its next row only after lane 63 has started the one above
@@ -396,12 +404,23 @@ __global__ __launch_bounds__(64) void ke_png_unfilter(const KePngDev *__restrict
             } else {
                 ow[0] = o[0] | (o[1] << 8) | (o[2] << 16) | (o[3] << 24);
             }
-            uint8_t *wp = dst + (size_t)row * rb + (size_t)g * (4 * BPP);
-            if (valid == 4) {
-#pragma unroll
-                for (int q = 0; q < kWords; ++q) __builtin_memcpy(wp + 4 * q, &ow[q], 4);
+            if (MAPPED) {
+                const int depth = d.info.depth, per = 8 / depth, px = d.info.width;
+                const uint32_t top = (1u << depth) - 1u;
+                uint8_t *wp = dst + (size_t)row * px;
+                for (int e = 0; e < valid; ++e) {
+                    const uint32_t byte = (ow[0] >> (8 * e)) & 255u;
+                    const int x0 = (4 * g + e) * per;
+                    for (int q = 0; q < per && x0 + q < px; ++q) wp[x0 + q] = s_lut[(byte >> (8 - depth * (q + 1))) & top];
+                }
             } else {
-                for (int e = 0; e < valid * BPP; ++e) wp[e] = (uint8_t)(ow[e >> 2] >> (8 * (e & 3)));
+                uint8_t *wp = dst + (size_t)row * rb + (size_t)g * (4 * BPP);
+                if (valid == 4) {
+#pragma unroll
+                    for (int q = 0; q < kWords; ++q) __builtin_memcpy(wp + 4 * q, &ow[q], 4);
+                } else {
+                    for (int e = 0; e < valid * BPP; ++e) wp[e] = (uint8_t)(ow[e >> 2] >> (8 * (e & 3)));
+                }
             }
             if (lane == 63) {
 #pragma unroll
@@ -520,7 +539,7 @@ KE_API int ke_png_decode(ke_ctx *ctx, const uint8_t *files, const uint64_t *offs
         while (last < items.size()) {
             Item &it = items[last];
             const uint64_t zl = ((uint64_t)it.d.info.zlen + 15) & ~15ull;
-            const uint64_t want = ((uint64_t)it.d.info.width * it.d.info.channels + 1) * it.d.info.height;
+            const uint64_t want = ((uint64_t)it.d.info.row_bytes + 1) * it.d.info.height;
             const uint64_t rw = (want + 32 + 15) & ~15ull, rc = want / 3 + 2;      // a copy covers at least 3 bytes
             if (last > first && (zbytes + zl > 0xE0000000ull || zbytes + zl + raw_bytes + rw + (nrecs + rc) * 8 > budget)) break;
             if (zbytes + zl > 0xF0000000ull) return ke_fail(ctx, KE_EUNSUPPORTED, "a PNG with more than 3.7 GB of compressed data");
@@ -537,7 +556,7 @@ KE_API int ke_png_decode(ke_ctx *ctx, const uint8_t *files, const uint64_t *offs
                 }
             zbytes += zl;
             raw_bytes += rw;
-            max_groups = std::max(max_groups, (it.d.info.width + 3) >> 2);
+            max_groups = std::max(max_groups, (it.d.info.row_bytes / (it.d.info.mapped ? 1 : it.d.info.channels) + 3) >> 2);
             devs.push_back(it.d);
             ++last;
         }
@@ -562,12 +581,17 @@ KE_API int ke_png_decode(ke_ctx *ctx, const uint8_t *files, const uint64_t *offs
         hipLaunchKernelGGL(ke_png_matches, dim3((unsigned)m), dim3(64), 0, ctx->stream, (const KePngDev *)d_imgs, (uint8_t *)d_raw,
                            (const uint2 *)d_rec, (const int32_t *)d_status, (const uint32_t *)d_nrec);
         const size_t row_lds = (size_t)max_groups * 16;
-        hipLaunchKernelGGL(ke_png_unfilter<1>, dim3((unsigned)m), dim3(64), row_lds, ctx->stream, (const KePngDev *)d_imgs,
-                           (const uint8_t *)d_raw, pixels_out, (int32_t *)d_status, (const uint32_t *)d_adler);
-        hipLaunchKernelGGL(ke_png_unfilter<3>, dim3((unsigned)m), dim3(64), row_lds, ctx->stream, (const KePngDev *)d_imgs,
-                           (const uint8_t *)d_raw, pixels_out, (int32_t *)d_status, (const uint32_t *)d_adler);
-        hipLaunchKernelGGL(ke_png_unfilter<4>, dim3((unsigned)m), dim3(64), row_lds, ctx->stream, (const KePngDev *)d_imgs,
-                           (const uint8_t *)d_raw, pixels_out, (int32_t *)d_status, (const uint32_t *)d_adler);
+        // one launch per kind present in the sub-batch (a workgroup whose image is of another kind returns at once)
+        bool kinds[4] = {false, false, false, false};
+        for (const KePngDev &d : devs) kinds[d.info.mapped ? 3 : d.info.channels == 1 ? 0 : d.info.channels == 3 ? 1 : 2] = true;
+#define KE_UNFILTER(BPP, MAPPED)                                                                                                    \
+    hipLaunchKernelGGL((ke_png_unfilter<BPP, MAPPED>), dim3((unsigned)m), dim3(64), row_lds, ctx->stream, (const KePngDev *)d_imgs,  \
+                       (const uint8_t *)d_raw, pixels_out, (int32_t *)d_status, (const uint32_t *)d_adler)
+        if (kinds[0]) KE_UNFILTER(1, false);
+        if (kinds[1]) KE_UNFILTER(3, false);
+        if (kinds[2]) KE_UNFILTER(4, false);
+        if (kinds[3]) KE_UNFILTER(1, true);
+#undef KE_UNFILTER
         KE_HIP(ctx, hipGetLastError());
         st.resize((size_t)m);
         KE_HIP(ctx, hipMemcpyAsync(st.data(), d_status, (size_t)m * 4, hipMemcpyDeviceToHost, ctx->stream));

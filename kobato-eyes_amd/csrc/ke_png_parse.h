@@ -57,7 +57,7 @@ static inline void ke_parse_png(const uint8_t *p, size_t size, std::vector<KePng
     if (size < 8 + 25 || std::memcmp(p, sig, 8) != 0) return;
     auto be32 = [&](size_t o) { return ((uint32_t)p[o] << 24) | ((uint32_t)p[o + 1] << 16) | ((uint32_t)p[o + 2] << 8) | p[o + 3]; };
     size_t pos = 8;
-    bool have_ihdr = false, ended = false;
+    bool have_ihdr = false, ended = false, palette = false, have_plte = false;
     const size_t s0 = segs ? segs->size() : 0;
     uint64_t zlen = 0;
     while (pos + 12 <= size) {
@@ -72,17 +72,34 @@ static inline void ke_parse_png(const uint8_t *p, size_t size, std::vector<KePng
             info.height = (int32_t)be32(pos + 12);
             const int depth = data[8], ctype = data[9], comp = data[10], filt = data[11], lace = data[12];
             if (info.width <= 0 || info.height <= 0 || comp != 0 || filt != 0) return;
-            info.channels = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 6 ? 4 : 0;
-            if (depth != 8 || info.channels == 0 || lace != 0 || info.width > KE_PNG_MAX_WIDTH ||
+            info.channels = (ctype == 0 || ctype == 3) ? 1 : ctype == 2 ? 3 : ctype == 6 ? 4 : 0;
+            const bool sub8 = (ctype == 0 || ctype == 3) && (depth == 1 || depth == 2 || depth == 4);
+            if (!(depth == 8 || sub8) || info.channels == 0 || lace != 0 || info.width > KE_PNG_MAX_WIDTH ||
                 (uint64_t)info.width * info.height > (1ull << 28)) {
                 info.status = KE_PNG_UNSUPPORTED;
                 if (!(depth == 1 || depth == 2 || depth == 4 || depth == 8 || depth == 16) || ctype > 6 || ctype == 1 || ctype == 5 || lace > 1)
                     info.status = KE_PNG_CORRUPT;
                 return;
             }
+            info.depth = depth;
+            info.mapped = (ctype == 3 || sub8) ? 1 : 0;
+            info.row_bytes = (int32_t)(((int64_t)info.width * info.channels * depth + 7) / 8);
+            palette = ctype == 3;
+            if (info.mapped && !palette)                      // 1 / 2 / 4-bit gray: Pillow's "1", "L;2", "L;4" unpackers scale to 0..255
+                for (int v = 0; v < (1 << depth); ++v) info.lut[v] = (uint8_t)(v * 255 / ((1 << depth) - 1));
             have_ihdr = true;
             if (!segs) { info.status = KE_PNG_OK; return; }
+        } else if (std::memcmp(type, "PLTE", 4) == 0) {
+            if (len % 3 != 0 || len > 768 || zlen != 0) break;               // Pillow: "broken PNG file" / palette after the image data
+            if (palette) {
+                // what convert("L") makes of a palette entry: ImagingConvert's L24, (19595 R + 38470 G + 7471 B + 0x8000) >> 16;
+                // indices beyond the palette read as black
+                for (uint32_t k = 0; k < len / 3; ++k)
+                    info.lut[k] = (uint8_t)((data[3 * k] * 19595u + data[3 * k + 1] * 38470u + data[3 * k + 2] * 7471u + 0x8000u) >> 16);
+                have_plte = true;
+            }
         } else if (idat) {
+            if (palette && !have_plte) break;
             if (len) segs->push_back(KePngSeg{(uint64_t)(pos + 8), len});
             zlen += len;
         } else if (std::memcmp(type, "IEND", 4) == 0) {

@@ -44,7 +44,7 @@ int ko_png_decode(const uint8_t *file, uint64_t size, uint8_t *out) {
     if (info.status != KE_PNG_OK) return info.status;
     std::vector<uint8_t> stream;
     for (const KePngSeg &s : segs) stream.insert(stream.end(), file + s.off, file + s.off + s.len);
-    const int rb = info.width * info.channels;
+    const int rb = info.row_bytes;
     const size_t want = (size_t)(rb + 1) * info.height;
     std::vector<uint8_t> raw;
     raw.reserve(want);
@@ -55,6 +55,20 @@ int ko_png_decode(const uint8_t *file, uint64_t size, uint8_t *out) {
     uint32_t adler = 0;
     if (ke_inflate_zlib(bits, sink, info.zlen, (uint32_t)want, t, &adler) != KE_PNG_OK) return KE_PNG_CORRUPT;
     if (raw.size() != want || ke_adler32(raw.data(), raw.size()) != adler) return KE_PNG_CORRUPT;
+    if (info.mapped) {                                       // packed samples: unfilter the bytes, unpack, map to luma
+        std::vector<uint8_t> rows((size_t)rb * info.height);
+        for (int y = 0; y < info.height; ++y) {
+            const uint8_t *row = raw.data() + (size_t)y * (rb + 1);
+            if (ke_png_unfilter_row(row[0], row + 1, y ? rows.data() + (size_t)(y - 1) * rb : nullptr, rows.data() + (size_t)y * rb, rb, 1) != KE_PNG_OK)
+                return KE_PNG_CORRUPT;
+            for (int x = 0; x < info.width; ++x) {
+                const int bit = x * info.depth;
+                const uint32_t byte = rows[(size_t)y * rb + (bit >> 3)];
+                out[(size_t)y * info.width + x] = info.lut[(byte >> (8 - info.depth - (bit & 7))) & ((1u << info.depth) - 1u)];
+            }
+        }
+        return KE_PNG_OK;
+    }
     for (int y = 0; y < info.height; ++y) {
         const uint8_t *row = raw.data() + (size_t)y * (rb + 1);
         if (ke_png_unfilter_row(row[0], row + 1, y ? out + (size_t)(y - 1) * rb : nullptr, out + (size_t)y * rb, rb, info.channels) != KE_PNG_OK)

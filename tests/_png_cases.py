@@ -39,7 +39,46 @@ def supported(full: bool = False):
                     yield f"{w}x{h}_k{kind}_{mode}_{kw}", data, np.asarray(Image.open(io.BytesIO(data)))
 
 
-def _container(raw: bytes, w: int, h: int, ctype: int, level: int, strategy: int, chunk: int) -> bytes:
+def mapped(full: bool = False):
+    """Yields (name, file bytes, luma as the reference's hashes see it: Image.open(...).convert("L")): palette files of every
+    depth Pillow writes (2 / 4 / 16 / 256 colours -> 1 / 2 / 4 / 8 bits), with and without transparency, mode "1", and
+    hand-packed 2- and 4-bit grayscale."""
+    rng = np.random.default_rng(8)
+    sizes = [(1, 1), (5, 3), (13, 9), (64, 64), (101, 77), (300, 200)] + ([(1000, 31), (33, 1000), (517, 389)] if full else [])
+    for (w, h) in sizes:
+        for ncol in (2, 4, 16, 256):
+            pal = rng.integers(0, 256, ncol * 3, dtype=np.uint8)
+            kinds = (0, 1) if full or (w, h) == (101, 77) else (0,)
+            for kind in kinds:
+                idx = rng.integers(0, ncol, (h, w), dtype=np.uint8) if kind == 0 else \
+                    np.repeat(np.repeat(rng.integers(0, ncol, (h // 8 + 1, w // 8 + 1), dtype=np.uint8), 8, 0), 8, 1)[:h, :w]
+                im = Image.fromarray(np.ascontiguousarray(idx), "P")
+                im.putpalette(pal.tolist())
+                for kw in ({}, {"transparency": 1}):
+                    b = io.BytesIO()
+                    im.save(b, "PNG", **kw)
+                    data = b.getvalue()
+                    yield f"P{ncol}_{w}x{h}_k{kind}_{kw}", data, np.asarray(Image.open(io.BytesIO(data)).convert("L"))
+        b = io.BytesIO()
+        Image.fromarray(rng.integers(0, 2, (h, w), dtype=np.uint8) * 255).convert("1").save(b, "PNG")
+        data = b.getvalue()
+        yield f"bilevel_{w}x{h}", data, np.asarray(Image.open(io.BytesIO(data)).convert("L"))
+        for depth in (2, 4):                                         # grayscale below 8 bits: rows packed by hand
+            per = 8 // depth
+            vals = rng.integers(0, 1 << depth, (h, w), dtype=np.uint8)
+            padded = np.zeros((h, (w + per - 1) // per * per), np.uint8)
+            padded[:, :w] = vals
+            packed = np.zeros((h, padded.shape[1] // per), np.uint8)
+            for q in range(per):
+                packed |= padded[:, q::per] << (8 - depth * (q + 1))
+            rows = np.concatenate([rng.integers(0, 5, (h, 1), dtype=np.uint8), packed], 1)
+            # the filter byte says how the row is stored; undo nothing here: store rows as filter 0 to keep the values as packed
+            rows[:, 0] = 0
+            data = _container(rows.tobytes(), w, h, 0, 6, 0, 1 << 30, depth=depth)
+            yield f"gray{depth}_{w}x{h}", data, np.asarray(Image.open(io.BytesIO(data)).convert("L"))
+
+
+def _container(raw: bytes, w: int, h: int, ctype: int, level: int, strategy: int, chunk: int, depth: int = 8) -> bytes:
     """A PNG around filtered scanlines given as they are, with control over what Pillow's writer never varies: the zlib
     strategy and the size of the IDAT chunks."""
     co = zlib.compressobj(level, zlib.DEFLATED, 15, 9, strategy)
@@ -48,7 +87,7 @@ def _container(raw: bytes, w: int, h: int, ctype: int, level: int, strategy: int
     def ch(t, d):
         return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d))
 
-    out = b"\x89PNG\r\n\x1a\n" + ch(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, ctype, 0, 0, 0))
+    out = b"\x89PNG\r\n\x1a\n" + ch(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, 0))
     for o in range(0, len(z), chunk):
         out += ch(b"IDAT", z[o:o + chunk])
     return out + ch(b"IEND", b"")
@@ -87,10 +126,16 @@ def refused():
     """Yields (name, file bytes, expected status): 1 = left to Pillow, 2 = damaged."""
     rng = np.random.default_rng(4)
     a = rng.integers(0, 256, (20, 30, 3), dtype=np.uint8)
-    for mode in ("P", "LA", "1"):
+    for mode in ("LA",):
         b = io.BytesIO()
         Image.fromarray(a).convert(mode).save(b, "PNG")
         yield f"mode_{mode}", b.getvalue(), 1
+    b = io.BytesIO()
+    Image.fromarray(a).convert("P").save(b, "PNG")
+    pal = b.getvalue()
+    cut = pal.index(b"PLTE") - 4
+    n = struct.unpack(">I", pal[cut:cut + 4])[0]
+    yield "palette_missing", pal[:cut] + pal[cut + 12 + n:], 2
     b = io.BytesIO()
     Image.fromarray(rng.integers(0, 65535, (20, 30)).astype(np.uint16)).save(b, "PNG")
     yield "16bit", b.getvalue(), 1

@@ -124,7 +124,7 @@ def test_fast_fill_takes_the_gpu_route_for_jpeg_files(tmp_path, monkeypatch):
 def test_png_decode_matches_pillow_in_one_mixed_batch(ctx):
     """ke_png_decode: 8-bit L / RGB / RGBA files of every compression level in one call -- stored, fixed and dynamic deflate
     blocks, all five filters -- equal to Pillow's pixels; palette / 16-bit / gray+alpha / damaged files reported per file."""
-    cases = list(P.supported(full=True)) + list(P.handmade(full=True))
+    cases = list(P.supported(full=True)) + list(P.handmade(full=True)) + list(P.mapped(full=True))
     refused = list(P.refused())
     blobs = [c[1] for c in cases] + [r[1] for r in refused]
     out, status = ctx.png_decode(blobs)

@@ -283,19 +283,33 @@ __device__ __forceinline__ bool prog_build(const ProgTables &t, int slot, const 
     return ok;
 }
 
-struct ProgReader {            // the reader of ke_prog_*
+// the reader of ke_prog_*.  AC scans have one table: its limits are taken into registers for the length of the scan (one LDS
+// round trip less per symbol); the tables of a DC scan (one per component) stay in LDS, a DC symbol being one per block.
+template <bool AC>
+struct ProgReader {
     KeBits &b;
     Stream &st;
     const ProgTables &t;
     int sym_mask;              // symbols a slot can hold - 1
+    uint32_t l0, l1, l2, l3, l4, l5, l6, l7;
+    __device__ __forceinline__ void latch() {
+        l0 = t.lim[0]; l1 = t.lim[64]; l2 = t.lim[128]; l3 = t.lim[192]; l4 = t.lim[256]; l5 = t.lim[320]; l6 = t.lim[384]; l7 = t.lim[448];
+    }
     __device__ __forceinline__ int sym(int slot) {
         bits_fill(b, st);
         const uint32_t v = ke_bits_peek(b, 16);
         int reached = 0;
+        if (AC) {
+            slot = 0;
+#define KE_REACH(w) reached += (int)(v >= ((w) & 0xFFFFu)) + (int)(v >= ((w) >> 16))
+            KE_REACH(l0); KE_REACH(l1); KE_REACH(l2); KE_REACH(l3); KE_REACH(l4); KE_REACH(l5); KE_REACH(l6); KE_REACH(l7);
+#undef KE_REACH
+        } else {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const uint32_t w = t.lim[64 * (8 * slot + k)];
-            reached += (int)(v >= (w & 0xFFFFu)) + (int)(v >= (w >> 16));
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t w = t.lim[64 * (8 * slot + k)];
+                reached += (int)(v >= (w & 0xFFFFu)) + (int)(v >= (w >> 16));
+            }
         }
         if (reached >= 16) return -1;                              // beyond the last code
         const int len = reached + 1;
@@ -359,11 +373,11 @@ __global__ __launch_bounds__(64) void ke_jpeg_entropy_prog(const KeJpegDev *__re
         ke_bits_init(bits, file, sc.offset, sc.end);
         st.end = sc.end;
         stream_load(st, sc.offset);
-        ProgReader rd{bits, st, tab, dc ? 15 : 255};
         int pred[3] = {0, 0, 0};
         uint32_t eobrun = 0;
         int restart_left = ri;
         if (dc) {
+            ProgReader<false> rd{bits, st, tab, 15, 0, 0, 0, 0, 0, 0, 0, 0};
             // MCUs of hs x vs blocks per component when several components share the scan, single blocks otherwise
             const bool inter = ns > 1;
             const int c0 = sc.comp[0];
@@ -394,6 +408,8 @@ __global__ __launch_bounds__(64) void ke_jpeg_entropy_prog(const KeJpegDev *__re
                     --restart_left;
                 }
         } else {
+            ProgReader<true> rd{bits, st, tab, 255, 0, 0, 0, 0, 0, 0, 0, 0};
+            rd.latch();
             const int c = sc.comp[0], bpr = in.plane_w[c] >> 3;
             const int bw = (in.comp_w[c] + 7) >> 3, bh = (in.comp_h[c] + 7) >> 3;
             for (int brow = 0; brow < bh && rc == KE_JPEG_OK; ++brow)

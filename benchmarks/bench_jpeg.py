@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--quality", type=int, default=85)
     ap.add_argument("--subsampling", type=int, default=2)
     ap.add_argument("--format", choices=["jpeg", "png"], default="jpeg")
+    ap.add_argument("--distinct", type=int, default=256, help="distinct images encoded (the batch cycles through them)")
     ap.add_argument("--progressive", action="store_true", help="JPEG: progressive files (libjpeg's default scan script)")
     ap.add_argument("--content", choices=["corpus", "drawing"], default="corpus",
                     help="corpus: the synthetic corpus images (textured, photograph-like: PNG stays near half its raw size); "
@@ -36,7 +37,7 @@ def main():
     from kobato_eyes_amd import _native
 
     ctx = _native.Context(0)
-    distinct = 256
+    distinct = args.distinct
     px = ctx.synth_rgb(20260604, 0, distinct, args.side, args.side)
     if args.content == "drawing":
         rng = np.random.default_rng(11)
@@ -47,14 +48,16 @@ def main():
         px[:, s // 3: s // 2, :, 1] = ramp[None, None, :]                 # a band with a horizontal ramp in one channel
         px[:, ::48, :, :] = 0                                             # outlines
         px[:, :, ::64, :] = 0
-    files = []
-    for k in range(distinct):
+    def encode(k):
         b = io.BytesIO()
         if args.format == "png":
             Image.fromarray(px[k]).save(b, "PNG")
         else:
             Image.fromarray(px[k]).save(b, "JPEG", quality=args.quality, subsampling=args.subsampling, progressive=args.progressive)
-        files.append(b.getvalue())
+        return b.getvalue()
+
+    with ThreadPoolExecutor(16) as ex:
+        files = list(ex.map(encode, range(distinct)))
     blobs = [files[k % distinct] for k in range(args.images)]
     comp_bytes = sum(len(b) for b in blobs)
     ctx.jpeg_hash(blobs[:512], kind=args.format)                 # warm-up: allocations, tables
@@ -83,7 +86,7 @@ def main():
         list(ex.map(dec, sample, chunksize=8))
     t_cpu = time.perf_counter() - t0
     wall, kern = float(np.median(t_wall)), float(np.median(t_kern))
-    print(json.dumps({"case": args.format + ("_progressive" if args.progressive else "") + "_decode", "content": args.content, "images": args.images, "side": args.side, "quality": args.quality,
+    print(json.dumps({"case": args.format + ("_progressive" if args.progressive else "") + "_decode", "content": args.content, "distinct": distinct, "images": args.images, "side": args.side, "quality": args.quality,
                       "subsampling": ["4:4:4", "4:2:2", "4:2:0"][args.subsampling], "compressed_mb": comp_bytes / 1e6,
                       "decode_kernels_ms": kern, "decode_images_per_s": args.images / (kern * 1e-3),
                       "decode_plus_hash_wall_ms": wall * 1e3, "decode_plus_hash_images_per_s": args.images / wall,

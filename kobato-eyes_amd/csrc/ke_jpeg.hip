@@ -14,6 +14,7 @@
 // Compressed bytes cross PCIe (a tenth of the pixels); files the parser refuses (arithmetic coding, CMYK, ...) are reported per
 // image and stay with Pillow.
 #include <algorithm>
+#include <numeric>
 
 #include "ke_internal.h"
 #include "ke_jpeg_parse.h"
@@ -594,6 +595,22 @@ KE_API int ke_jpeg_decode(ke_ctx *ctx, const uint8_t *files, const uint64_t *off
         hi = std::max(hi, p.hi);
     }
     if (devs.empty()) return KE_OK;
+    // The 64 lanes of a wave step through their images block by block and finish together at best: neighbours in the device
+    // order should be images of like geometry and like compressed size (like amounts of work per block).
+    if (!std::getenv("KE_JPEG_KEEP_ORDER")) {
+        std::vector<size_t> order(devs.size());
+        std::iota(order.begin(), order.end(), (size_t)0);
+        auto key = [&](size_t k) {
+            const KeJpegInfo &in = devs[k].info;
+            return std::make_tuple(in.progressive, -(int64_t)in.mcus_x * in.mcus_y * in.ncomp, -(int64_t)(in.scan_end - in.scan_offset));
+        };
+        std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return key(a) < key(b); });
+        std::vector<KeJpegDev> sorted_devs(devs.size());
+        std::vector<int64_t> sorted_which(devs.size());
+        for (size_t k = 0; k < order.size(); ++k) { sorted_devs[k] = devs[order[k]]; sorted_which[k] = which[order[k]]; }
+        devs.swap(sorted_devs);
+        which.swap(sorted_which);
+    }
     // compressed bytes of the decodable files (one contiguous range of the caller's buffer) -> device
     void *d_files;
     KE_TRY(ke_reserve(ctx, KE_BUF_PIXELS, (size_t)(hi - lo) + 256, &d_files));   // the stream windows read up to 64 bytes past a file

@@ -190,6 +190,15 @@ int ke_png_probe(const uint8_t *files, const uint64_t *offsets, const uint64_t *
 int ke_png_decode(ke_ctx *ctx, const uint8_t *files, const uint64_t *offsets, const uint64_t *sizes, int64_t n,
                   uint8_t *pixels_out, const uint64_t *out_offsets, int32_t *status_out);
 
+/* What `Image.open` alone does not tell about a file but the reference's defensive loader acts on (src/utils/image_io.py:60-138:
+ * EXIF orientation applied, alpha composited over white): per file a set of KE_CAVEAT_* bits, so that a caller who wants that
+ * loader's pixels sends flagged files through it and only the rest through ke_jpeg_decode / ke_png_decode.  ORIENTATION: the
+ * file carries an EXIF orientation of 2..8 (JPEG APP1; PNG eXIf or a "Raw profile type ..." text chunk -- or EXIF data that
+ * cannot be followed); TRANSPARENCY: a PNG tRNS chunk.  Host only. */
+enum { KE_CAVEAT_ORIENTATION = 1, KE_CAVEAT_TRANSPARENCY = 2 };
+int ke_jpeg_caveats(const uint8_t *files, const uint64_t *offsets, const uint64_t *sizes, int64_t n, int32_t *flags_out);
+int ke_png_caveats(const uint8_t *files, const uint64_t *offsets, const uint64_t *sizes, int64_t n, int32_t *flags_out);
+
 /* Debug/parity hook: the resampled luma tiles the hashes are computed from
  * (reference sig.phash._to_grayscale, src/sig/phash.py:21-26).  tile32_out: n*1024 bytes
  * ([y][x]); tile98_out: n*72 bytes (8 rows x 9 columns); either may be NULL. */

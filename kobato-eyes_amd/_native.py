@@ -28,7 +28,7 @@ EXPORTS = (
     "ke_hash_images", "ke_hash_uniform", "ke_hash_images_ex", "ke_hash_uniform_ex", "ke_luma_tiles_uniform", "ke_hamming_scan",
     "ke_stage_create", "ke_stage_create_shared", "ke_stage_destroy", "ke_stage_acquire", "ke_stage_submit_hash", "ke_stage_wait",
     "ke_comm_unique_id", "ke_comm_create", "ke_comm_destroy", "ke_allgather_u64", "ke_allgather_hashes", "ke_allgather_edges",
-    "ke_interleave_shards", "ke_host_alloc", "ke_host_free", "ke_host_pack", "ke_host_read_files", "ke_jpeg_probe", "ke_jpeg_decode", "ke_png_probe", "ke_png_decode", "ke_cluster_labels", "ke_ssim_pairs_uniform", "ke_ssim_pairs", "ke_ssim_set_mode", "ke_resize_luma_uniform", "ke_fit_luma_uniform", "ke_tile_ahash", "ke_sad_pairs", "ke_synth_rgb",
+    "ke_interleave_shards", "ke_host_alloc", "ke_host_free", "ke_host_pack", "ke_host_read_files", "ke_jpeg_probe", "ke_jpeg_decode", "ke_png_probe", "ke_png_decode", "ke_jpeg_caveats", "ke_png_caveats", "ke_cluster_labels", "ke_ssim_pairs_uniform", "ke_ssim_pairs", "ke_ssim_set_mode", "ke_resize_luma_uniform", "ke_fit_luma_uniform", "ke_tile_ahash", "ke_sad_pairs", "ke_synth_rgb",
     "ke_synth_rgb_indexed",
     "ke_synth_hashes", "ke_last_kernel_ms",
 )
@@ -128,6 +128,8 @@ def load_library() -> C.CDLL:
         lib.ke_jpeg_decode.argtypes = [vp, vp, vp, vp, i64, vp, vp, vp]
         lib.ke_png_probe.argtypes = [vp, vp, vp, i64, vp, vp, vp, vp]
         lib.ke_png_decode.argtypes = [vp, vp, vp, vp, i64, vp, vp, vp]
+        lib.ke_jpeg_caveats.argtypes = [vp, vp, vp, i64, vp]
+        lib.ke_png_caveats.argtypes = [vp, vp, vp, i64, vp]
         lib.ke_hamming_scan.argtypes = [vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, dbl, i64, vp, i64,
                                         C.POINTER(i64), vp]
         lib.ke_cluster_labels.argtypes = [vp, i64, i64, vp]
@@ -147,7 +149,7 @@ def load_library() -> C.CDLL:
                      "ke_hash_images", "ke_hash_uniform", "ke_hash_images_ex", "ke_hash_uniform_ex", "ke_luma_tiles_uniform", "ke_hamming_scan",
                      "ke_stage_create", "ke_stage_create_shared", "ke_stage_destroy", "ke_stage_acquire", "ke_stage_submit_hash", "ke_stage_wait",
                      "ke_comm_unique_id", "ke_comm_create", "ke_comm_destroy", "ke_allgather_u64", "ke_allgather_hashes", "ke_allgather_edges",
-                     "ke_interleave_shards", "ke_host_alloc", "ke_host_free", "ke_host_pack", "ke_host_read_files", "ke_jpeg_probe", "ke_jpeg_decode", "ke_png_probe", "ke_png_decode", "ke_cluster_labels", "ke_ssim_pairs_uniform", "ke_ssim_pairs", "ke_ssim_set_mode", "ke_resize_luma_uniform", "ke_fit_luma_uniform", "ke_tile_ahash",
+                     "ke_interleave_shards", "ke_host_alloc", "ke_host_free", "ke_host_pack", "ke_host_read_files", "ke_jpeg_probe", "ke_jpeg_decode", "ke_png_probe", "ke_png_decode", "ke_jpeg_caveats", "ke_png_caveats", "ke_cluster_labels", "ke_ssim_pairs_uniform", "ke_ssim_pairs", "ke_ssim_set_mode", "ke_resize_luma_uniform", "ke_fit_luma_uniform", "ke_tile_ahash",
                      "ke_sad_pairs", "ke_synth_rgb", "ke_synth_rgb_indexed", "ke_synth_hashes"):
             getattr(lib, name).restype = C.c_int
         _lib = lib
@@ -388,7 +390,7 @@ class Context:
             self._check(self._lib.ke_host_alloc(self._h, cap, C.byref(p)), "ke_host_alloc")
             self._pack_ptr, self._pack_cap = int(p.value), cap
 
-    def _read_files_pinned(self, paths):
+    def _read_files_pinned(self, paths, bounded: bool = True):
         """The files themselves, read by the library's host threads straight into the page-locked buffer (no bytes objects, no
         interpreter loop over the files); unreadable files get size 0.  Call with the lock held."""
         n = len(paths)
@@ -397,7 +399,7 @@ class Context:
         needed = C.c_uint64(0)
         rc = self._lib.ke_host_read_files(names, n, self._pack_ptr, self._pack_cap, _addr(offsets), _addr(sizes), C.byref(needed))
         if rc == -4:                                       # KE_ENOMEM: the buffer is too small for this batch
-            if int(needed.value) > self.pack_limit and n > 1:
+            if bounded and int(needed.value) > self.pack_limit and n > 1:
                 raise _BatchTooLarge
             self._grow_pack(int(needed.value))
             rc = self._lib.ke_host_read_files(names, n, self._pack_ptr, self._pack_cap, _addr(offsets), _addr(sizes), C.byref(needed))
@@ -477,6 +479,38 @@ class Context:
             self._check(getattr(self._lib, f"ke_{kind}_decode")(self._h, _addr(flat), _addr(offsets), _addr(sizes), n, dev,
                                                                 _addr(out_off), _addr(st)), f"ke_{kind}_decode")
         return dev, out_off, w, h, c, st
+
+    def decode_files_owned(self, paths, kind: str = "jpeg"):
+        """Files on disk decoded into a device buffer of their own (the caller frees it with ``free``): (device ptr or 0, byte
+        offsets, widths, heights, channels, status, caveat flags).  ``flags`` are ke_jpeg_caveats / ke_png_caveats' bits: what
+        the reference's defensive loader would do to the file beyond Image.open (EXIF orientation, transparency)."""
+        paths = list(paths)
+        n = len(paths)
+        w, h, c, st, flags = (np.zeros(n, np.int32) for _ in range(5))
+        out_off = np.zeros(n, np.uint64)
+        if n == 0:
+            return 0, out_off, w, h, c, st, flags
+        with self._lock:
+            flat, offsets, sizes = self._read_files_pinned(paths, bounded=False)     # the caller paces its batches
+            probe = getattr(self._lib, f"ke_{kind}_probe")
+            if probe(_addr(flat), _addr(offsets), _addr(sizes), n, _addr(w), _addr(h), _addr(c), _addr(st)) != KE_OK:
+                raise ValueError(f"ke_{kind}_probe: bad arguments")
+            if getattr(self._lib, f"ke_{kind}_caveats")(_addr(flat), _addr(offsets), _addr(sizes), n, _addr(flags)) != KE_OK:
+                raise ValueError(f"ke_{kind}_caveats: bad arguments")
+            nbytes = np.where(st == 0, w.astype(np.int64) * h * c, 0)
+            padded = (nbytes + 15) & ~np.int64(15)
+            out_off[1:] = np.cumsum(padded[:-1]).astype(np.uint64)
+            total = int(padded.sum())
+            if total == 0:
+                return 0, out_off, w, h, c, st, flags
+            dev = self.malloc(total + 64)
+            try:
+                self._check(getattr(self._lib, f"ke_{kind}_decode")(self._h, _addr(flat), _addr(offsets), _addr(sizes), n, dev,
+                                                                    _addr(out_off), _addr(st)), f"ke_{kind}_decode")
+            except Exception:
+                self.free(dev)
+                raise
+        return dev, out_off, w, h, c, st, flags
 
     def release_decode_buffers(self) -> None:
         """Give back the page-locked packing buffer and the device decode buffer (they are kept between calls otherwise)."""
@@ -617,6 +651,22 @@ class Context:
         status = np.empty(len(pa), np.int32)
         with self._lock:
             self._check(self._lib.ke_ssim_pairs(self._h, _addr(flat), _addr(offsets), _addr(widths), _addr(heights), ch, n, _addr(pa),
+                                                _addr(pb), len(pa), _addr(out), _addr(status)), "ke_ssim_pairs")
+        return out, status
+
+    def ssim_pairs_on_device(self, pointers, widths, heights, channels: int, pair_a, pair_b):
+        """ssim_pairs for images that already lie in device memory, each at its own address (decoded there, or uploaded)."""
+        ptrs = np.asarray(pointers, np.uint64)
+        base = int(ptrs.min())
+        offsets = np.ascontiguousarray(ptrs - np.uint64(base))
+        widths = np.ascontiguousarray(widths, np.int32)
+        heights = np.ascontiguousarray(heights, np.int32)
+        pa = np.ascontiguousarray(pair_a, dtype=np.int64)
+        pb = np.ascontiguousarray(pair_b, dtype=np.int64)
+        out = np.empty(len(pa), np.float64)
+        status = np.empty(len(pa), np.int32)
+        with self._lock:
+            self._check(self._lib.ke_ssim_pairs(self._h, base, _addr(offsets), _addr(widths), _addr(heights), channels, len(ptrs), _addr(pa),
                                                 _addr(pb), len(pa), _addr(out), _addr(status)), "ke_ssim_pairs")
         return out, status
 

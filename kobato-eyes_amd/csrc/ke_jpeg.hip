@@ -531,6 +531,56 @@ KE_API int ke_jpeg_probe(const uint8_t *files, const uint64_t *offsets, const ui
     return KE_OK;
 }
 
+// EXIF orientation of a JPEG as ImageOps.exif_transpose reads it (tag 0x0112 of IFD0 in the first APP1 "Exif" segment): 1 when
+// there is none, -1 when the segment cannot be followed
+static int jpeg_orientation(const uint8_t *p, size_t size) {
+    size_t pos = 2;
+    int found = 1, exif_segments = 0;
+    while (pos + 4 <= size && p[pos] == 0xFF) {
+        const int m = p[pos + 1];
+        if (m == 0xDA || m == 0xD9) break;
+        if (m == 0xFF) { ++pos; continue; }
+        if ((m >= 0xD0 && m <= 0xD8) || m == 0x01) { pos += 2; continue; }
+        const size_t len = ((size_t)p[pos + 2] << 8) | p[pos + 3];
+        if (len < 2 || pos + 2 + len > size) return -1;
+        if (m == 0xE1 && len >= 8 && std::memcmp(p + pos + 4, "Exif\0\0", 6) == 0) {
+            if (++exif_segments > 1) return -1;                   // Pillow strings several segments together
+            const uint8_t *t = p + pos + 10;
+            const size_t tl = len - 8;
+            if (tl < 8) return -1;
+            const bool le = t[0] == 'I' && t[1] == 'I', be = t[0] == 'M' && t[1] == 'M';
+            if (!le && !be) return -1;
+            auto rd16 = [&](size_t o) -> uint32_t { return le ? (uint32_t)(t[o] | (t[o + 1] << 8)) : (uint32_t)((t[o] << 8) | t[o + 1]); };
+            auto rd32 = [&](size_t o) -> uint32_t { return le ? rd16(o) | (rd16(o + 2) << 16) : (rd16(o) << 16) | rd16(o + 2); };
+            if (rd16(2) != 42) return -1;
+            const size_t ifd = rd32(4);
+            if (ifd + 2 > tl) return -1;
+            const uint32_t entries = rd16(ifd);
+            if (ifd + 2 + 12 * (size_t)entries > tl) return -1;
+            for (uint32_t e = 0; e < entries; ++e) {
+                const size_t o = ifd + 2 + 12 * (size_t)e;
+                if (rd16(o) != 0x0112) continue;
+                const uint32_t type = rd16(o + 2);
+                if (rd32(o + 4) != 1 || (type != 3 && type != 4)) return -1;
+                found = (int)(type == 3 ? rd16(o + 8) : rd32(o + 8));
+            }
+        }
+        pos += 2 + len;
+    }
+    return found;
+}
+
+KE_API int ke_jpeg_caveats(const uint8_t *files, const uint64_t *offsets, const uint64_t *sizes, int64_t n, int32_t *flags_out) {
+    if (n < 0 || (n > 0 && (!files || !offsets || !sizes || !flags_out))) return KE_EINVAL;
+    ke_parallel_ranges(n, [=](int64_t lo, int64_t hi, int) {
+        for (int64_t i = lo; i < hi; ++i) {
+            const int o = sizes[i] >= 4 ? jpeg_orientation(files + offsets[i], (size_t)sizes[i]) : 1;
+            flags_out[i] = (o < 0 || (o >= 2 && o <= 8)) ? KE_CAVEAT_ORIENTATION : 0;
+        }
+    });
+    return KE_OK;
+}
+
 KE_API int ke_jpeg_decode(ke_ctx *ctx, const uint8_t *files, const uint64_t *offsets, const uint64_t *sizes, int64_t n,
                           uint8_t *pixels_out, const uint64_t *out_offsets, int32_t *status_out) {
     if (!ctx) return KE_EINVAL;

@@ -466,6 +466,32 @@ KE_API int ke_png_probe(const uint8_t *files, const uint64_t *offsets, const uin
     return KE_OK;
 }
 
+KE_API int ke_png_caveats(const uint8_t *files, const uint64_t *offsets, const uint64_t *sizes, int64_t n, int32_t *flags_out) {
+    if (n < 0 || (n > 0 && (!files || !offsets || !sizes || !flags_out))) return KE_EINVAL;
+    ke_parallel_ranges(n, [=](int64_t lo, int64_t hi, int) {
+        for (int64_t i = lo; i < hi; ++i) {
+            const uint8_t *p = files + offsets[i];
+            const size_t size = (size_t)sizes[i];
+            int32_t flags = 0;
+            size_t pos = 8;
+            while (pos + 12 <= size) {
+                const size_t len = ((size_t)p[pos] << 24) | ((size_t)p[pos + 1] << 16) | ((size_t)p[pos + 2] << 8) | p[pos + 3];
+                const uint8_t *type = p + pos + 4, *data = p + pos + 8;
+                if (len > 0x7fffffffu || pos + 12 + len > size || std::memcmp(type, "IEND", 4) == 0) break;
+                if (std::memcmp(type, "tRNS", 4) == 0) flags |= KE_CAVEAT_TRANSPARENCY;
+                if (std::memcmp(type, "eXIf", 4) == 0) flags |= KE_CAVEAT_ORIENTATION;
+                // EXIF blocks that ImageMagick-style writers put into text chunks ("Raw profile type exif" / "... APP1"): Pillow reads them
+                if ((std::memcmp(type, "tEXt", 4) == 0 || std::memcmp(type, "zTXt", 4) == 0 || std::memcmp(type, "iTXt", 4) == 0) && len >= 16 &&
+                    std::memcmp(data, "Raw profile type", 16) == 0)
+                    flags |= KE_CAVEAT_ORIENTATION;
+                pos += 12 + len;
+            }
+            flags_out[i] = flags;
+        }
+    });
+    return KE_OK;
+}
+
 KE_API int ke_png_decode(ke_ctx *ctx, const uint8_t *files, const uint64_t *offsets, const uint64_t *sizes, int64_t n,
                          uint8_t *pixels_out, const uint64_t *out_offsets, int32_t *status_out) {
     if (!ctx) return KE_EINVAL;

@@ -17,7 +17,7 @@ from typing import Optional, Sequence
 import numpy as np
 
 from . import _native
-from .image_io import load_rgb
+from .image_io import MAX_SIDE, load_rgb
 
 _phash = importlib.import_module(".phash", __package__)   # the package also exports a function named phash
 
@@ -104,24 +104,62 @@ def refine_pairs(pairs: Sequence[tuple], *, thresholds: Optional[RefinementThres
     cfg = thresholds or RefinementThresholds()
     ctx = _native.get_context(device)
     out: list = [None] * len(pairs)
-    count = {"decodes": 0, "fit_launches": 0, "ssim_launches": 0, "pairs": len(pairs)}
+    count = {"decodes": 0, "gpu_decodes": 0, "fit_launches": 0, "ssim_launches": 0, "pairs": len(pairs)}
 
-    def run(chunk: list, decoded: dict) -> None:
+    gpu_kinds = {}
+    if os.environ.get("KE_GPU_REFINE_DECODE", "1") != "0":
+        if os.environ.get("KE_GPU_JPEG", "1") != "0":
+            gpu_kinds["jpeg"] = (".jpg", ".jpeg", ".jpe", ".jfif")
+        if os.environ.get("KE_GPU_PNG", "1") != "0":
+            gpu_kinds["png"] = (".png",)
+
+    def decode_on_gpu(need: list, placed: dict, buffers: list) -> None:
+        """JPEG / PNG files whose pixels the reference's loader would hand over exactly as Image.open yields them -- RGB, no
+        EXIF orientation to apply, nothing to shrink (src/utils/image_io.py:107-138 are all no-ops then) -- are decoded on the
+        GPU and stay there: placed[path] = (device address, width, height).  Everything else is left for Pillow."""
+        for kind, suffixes in gpu_kinds.items():
+            paths = [p for p in need if p.lower().endswith(suffixes)]
+            if not paths:
+                continue
+            dev, off, w, h, c, st, flags = ctx.decode_files_owned(paths, kind)
+            if not dev:
+                continue
+            buffers.append(dev)
+            ok = (st == 0) & (c == 3) & (flags == 0) & (np.maximum(w, h) <= MAX_SIDE)
+            for p, good, o, ww, hh in zip(paths, ok.tolist(), off.tolist(), w.tolist(), h.tolist()):
+                if good:
+                    placed[p] = (dev + int(o), ww, hh)
+            count["gpu_decodes"] += int(ok.sum())
+
+    def run(chunk: list, placed: dict, arrays: dict, buffers: list) -> None:
         """One ``ke_ssim_pairs`` call for the pairs of this run (the library groups them: one fit launch per (source size,
-        common size), one SSIM launch per common size)."""
-        paths = [p for p, a in decoded.items() if a is not None]
-        index = {p: i for i, p in enumerate(paths)}
+        common size), one SSIM launch per common size).  Images decoded by Pillow are uploaded next to the ones decoded on
+        the GPU."""
+        host = [(p, a) for p, a in arrays.items() if a is not None]
+        if host:
+            sizes = [(a.size + 15) & ~15 for _, a in host]
+            flat = np.zeros(sum(sizes), np.uint8)
+            at = 0
+            dev = ctx.malloc(len(flat) + 64)
+            buffers.append(dev)
+            for (p, a), sz in zip(host, sizes):
+                flat[at:at + a.size] = a.reshape(-1)
+                placed[p] = (dev + at, a.shape[1], a.shape[0])
+                at += sz
+            ctx.memcpy(dev, flat, len(flat))
         live = []
         for k in chunk:
             fid_a, fid_b, pa, pb = pairs[k]
-            if decoded.get(str(pa)) is None or decoded.get(str(pb)) is None:
+            if str(pa) not in placed or str(pb) not in placed:
                 out[k] = None                                      # unreadable file: src/dup/refine.py:82-85
             else:
                 live.append(k)
         if not live:
             return
-        images = [decoded[p] for p in paths]
-        scores, status = ctx.ssim_pairs(images, [index[str(pairs[k][2])] for k in live], [index[str(pairs[k][3])] for k in live])
+        paths = list(placed)
+        index = {p: i for i, p in enumerate(paths)}
+        scores, status = ctx.ssim_pairs_on_device([placed[p][0] for p in paths], [placed[p][1] for p in paths], [placed[p][2] for p in paths],
+                                                  3, [index[str(pairs[k][2])] for k in live], [index[str(pairs[k][3])] for k in live])
         common, fits = set(), set()
         for k, sc, st in zip(live, scores.tolist(), status.tolist()):
             fid_a, fid_b, pa, pb = pairs[k]
@@ -130,16 +168,19 @@ def refine_pairs(pairs: Sequence[tuple], *, thresholds: Optional[RefinementThres
                 out[k] = _decide(fid_a, fid_b, None, ["ssim unavailable"], cfg)
                 continue
             out[k] = _decide(fid_a, fid_b, float(sc), [], cfg)
-            sa, sb = decoded[str(pa)].shape, decoded[str(pb)].shape
-            size = (min(sa[1], sb[1]), min(sa[0], sb[0]))
+            (_, wa, ha), (_, wb, hb) = placed[str(pa)], placed[str(pb)]
+            size = (min(wa, wb), min(ha, hb))
             common.add(size)
-            fits.update({(sa[:2], size), (sb[:2], size)})
+            fits.update({((ha, wa), size), ((hb, wb), size)})
         count["fit_launches"] += len(fits)
         count["ssim_launches"] += len(common)
 
     def load(p: str):
         img = load_rgb(p)
-        return None if img is None else _phash.image_to_array(img)
+        if img is None:
+            return None
+        arr = _phash.image_to_array(img)
+        return arr if arr.ndim == 3 and arr.shape[2] == 3 else None
 
     with ThreadPoolExecutor(max_workers=max(1, io_workers)) as pool:
         start = 0
@@ -156,9 +197,17 @@ def refine_pairs(pairs: Sequence[tuple], *, thresholds: Optional[RefinementThres
                         except OSError:
                             pass
                 stop += 1
-            arrays = list(pool.map(load, need))
-            count["decodes"] += len(need)
-            run(list(range(start, stop)), dict(zip(need, arrays)))
+            placed: dict = {}
+            buffers: list = []
+            try:
+                decode_on_gpu(need, placed, buffers)
+                rest = [p for p in need if p not in placed]
+                arrays = dict(zip(rest, pool.map(load, rest)))
+                count["decodes"] += len(need)
+                run(list(range(start, stop)), placed, arrays, buffers)
+            finally:
+                for dev in buffers:
+                    ctx.free(dev)
             start = stop
     if stats is not None:
         stats.update(count)

@@ -6,6 +6,8 @@ src/ui/dup_workers.py:148-239).  They read like the reference's own tests
 (tests/core/test_fastsig.py, tests/core/test_image_signature.py, tests/dup/test_refine.py)."""
 from __future__ import annotations
 
+import os
+
 import sqlite3
 from pathlib import Path
 
@@ -220,6 +222,55 @@ def test_refine_pairs_batches_the_seam(K, tmp_path):
     assert stats["fit_launches"] + stats["ssim_launches"] == 2 and 3 * len(same_size) >= 10 * 2, stats   # 36 launches -> 2
     # a decode budget of one file per run: many runs, same answers
     assert K.refine_pairs(pairs, thresholds=th, max_decoded_bytes=1) == one_by_one
+
+
+def test_refine_pairs_decodes_on_the_gpu_only_what_the_loader_leaves_alone(K, tmp_path):
+    """refine_pairs takes JPEG / PNG files through the GPU decoders when the reference's defensive loader
+    (src/utils/image_io.py:60-138) would hand over Image.open's pixels unchanged -- RGB, no EXIF orientation, no side over
+    4096 -- and through that loader otherwise (rotated by EXIF, alpha over white, gray, palette with transparency, shrunk):
+    the answers are refine_pair's either way."""
+    from PIL import Image
+
+    rng = np.random.default_rng(12)
+    base = O.synth_rgb(2000, 320, 240)
+    noisy = np.clip(base.astype(np.int16) + rng.integers(-4, 5, base.shape), 0, 255).astype(np.uint8)
+    files = {}
+
+    def put(k, name, img, **kw):
+        files[k] = tmp_path / name
+        img.save(files[k], **kw)
+
+    put(0, "a.jpg", Image.fromarray(base), quality=92)
+    put(1, "b.jpg", Image.fromarray(noisy), quality=85, progressive=True)
+    put(2, "c.png", Image.fromarray(noisy))
+    exif = Image.Exif()
+    exif[0x0112] = 6                                            # stored rotated: the loader turns it, Image.open does not
+    put(3, "rotated.jpg", Image.fromarray(base), quality=92, exif=exif.tobytes())
+    rgba = np.dstack([base, np.full(base.shape[:2], 128, np.uint8)])
+    put(4, "alpha.png", Image.fromarray(rgba, "RGBA"))
+    put(5, "gray.jpg", Image.fromarray(base[:, :, 1]), quality=90)
+    pal = Image.fromarray(base).convert("P")
+    put(6, "palette_trns.png", pal, transparency=3)
+    put(7, "palette.png", pal)
+    wide = np.repeat(base[:40], 13, 1)[:, :4100]
+    put(8, "wide.jpg", Image.fromarray(wide), quality=80)
+    exif1 = Image.Exif()
+    exif1[0x0112] = 1
+    put(9, "upright.jpg", Image.fromarray(noisy), quality=88, exif=exif1.tobytes())
+    pairs = [(a, b, files[a], files[b]) for a, b in [(0, 1), (0, 2), (1, 2), (0, 3), (3, 2), (0, 4), (4, 2), (0, 5), (5, 1), (6, 0), (7, 2),
+                                                      (6, 7), (8, 0), (8, 8), (9, 0), (9, 2)]]
+    th = K.RefinementThresholds(ssim=0.8)
+    one_by_one = [K.refine_pair(a, b, pa, pb, thresholds=th) for a, b, pa, pb in pairs]
+    stats = {}
+    assert K.refine_pairs(pairs, thresholds=th, stats=stats) == one_by_one
+    assert stats["decodes"] == 10 and stats["gpu_decodes"] == 4, stats          # a.jpg, b.jpg, c.png, upright.jpg
+    assert any(m.is_duplicate for m in one_by_one) and any(not m.is_duplicate for m in one_by_one)
+    os.environ["KE_GPU_REFINE_DECODE"] = "0"
+    try:
+        stats = {}
+        assert K.refine_pairs(pairs, thresholds=th, stats=stats) == one_by_one and stats["gpu_decodes"] == 0
+    finally:
+        del os.environ["KE_GPU_REFINE_DECODE"]
 
 
 def test_shipped_refine_stage_kernels_and_dropins(K, tmp_path):

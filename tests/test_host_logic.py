@@ -83,6 +83,53 @@ def test_host_side_file_batching_needs_no_gpu(K, tmp_path):
     assert bytes(dst) == b"".join(keep)
 
 
+def test_decode_caveats_follow_the_files_markers(K):
+    """ke_jpeg_caveats / ke_png_caveats (host code): the flags say when the reference's loader would turn the image by its EXIF
+    orientation or composite its transparency -- checked against what Pillow itself reads from the same bytes."""
+    import ctypes as C
+    import io
+
+    from PIL import Image, ImageOps
+
+    lib = K._native.load_library()
+    arr = (np.arange(24 * 16 * 3) % 251).astype(np.uint8).reshape(16, 24, 3)
+
+    def save(fmt, img=None, **kw):
+        b = io.BytesIO()
+        (img or Image.fromarray(arr)).save(b, fmt, **kw)
+        return b.getvalue()
+
+    def exif(value):
+        e = Image.Exif()
+        e[0x0112] = value
+        return e.tobytes()
+
+    jpegs = [save("JPEG")] + [save("JPEG", exif=exif(v)) for v in range(0, 10)]
+    app1 = b"\xff\xe1" + (2 + 6 + 5).to_bytes(2, "big") + b"Exif\0\0" + b"junk!"
+    jpegs.append(jpegs[0][:2] + app1 + jpegs[0][2:])             # an EXIF block that cannot be followed
+    pngs = [save("PNG"), save("PNG", exif=exif(6)), save("PNG", exif=exif(1)), save("PNG", Image.fromarray(arr).convert("P"), transparency=2),
+            save("PNG", Image.fromarray(np.dstack([arr, arr[:, :, :1]]), "RGBA"))]
+    for kind, blobs in (("jpeg", jpegs), ("png", pngs)):
+        flat = np.frombuffer(b"".join(blobs) + bytes(64), np.uint8)
+        sizes = np.array([len(b) for b in blobs], np.uint64)
+        offs = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.uint64)
+        flags = np.full(len(blobs), -1, np.int32)
+        assert getattr(lib, f"ke_{kind}_caveats")(flat.ctypes.data, offs.ctypes.data, sizes.ctypes.data, len(blobs), flags.ctypes.data) == 0
+        for k, blob in enumerate(blobs):
+            try:
+                with Image.open(io.BytesIO(blob)) as im:
+                    turned = ImageOps.exif_transpose(im).size != im.size or im.getexif().get(0x0112, 1) in (2, 3, 4)
+                    has_exif = "exif" in im.info or bool(im.getexif())
+                    transparent = kind == "png" and "transparency" in im.info
+            except Exception:
+                turned, has_exif, transparent = True, True, False
+            if turned:
+                assert flags[k] & 1, (kind, k)
+            if not has_exif:
+                assert not flags[k] & 1, (kind, k)              # nothing to apply: the file may take the GPU decoder
+            assert bool(flags[k] & 2) == transparent, (kind, k)
+
+
 def test_no_cpu_fallback_without_gpu(K):
     import torch
 

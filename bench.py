@@ -47,6 +47,7 @@ def parse_args():
                     help="BASELINE configs[3] flavour: re-check every candidate edge with the SSIM kernel inside the step (pairs sharded over the ranks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-h2d", action="store_true", help="skip the PCIe-inclusive leg (pinned staging -> device -> hash)")
+    ap.add_argument("--no-decode", action="store_true", help="skip the decode-inclusive leg (JPEG files in host memory -> GPU decode -> hash)")
     ap.add_argument("--torch-collectives", action="store_true",
                     help="exchange through torch.distributed (kobato_eyes_amd.distributed) instead of the library's own RCCL entry points")
     ap.add_argument("--phase-timing", action="store_true", help="after the timed run, time each phase of a step with syncs in between (stderr)")
@@ -355,6 +356,45 @@ def main():
         finally:
             ctx.stage_destroy()
 
+    decode_leg = None
+    if rank == 0 and world == 1 and not args.no_decode:
+        # decode-inclusive rate (never `value`): the same corpus images as JPEG files in host memory (what a library scan starts
+        # from) -> page-locked packing -> PCIe (compressed bytes) -> GPU JPEG decode -> the hash kernel on the decoded pixels.
+        # 16 384 files per call; the hashes must be those of Pillow's decode of the same files.
+        try:
+            import io
+
+            from PIL import Image
+
+            from concurrent.futures import ThreadPoolExecutor
+
+            distinct, n_files = 4096, 16384                            # few copies of each file: lanes of a wave hold different images
+            src_px = ctx.synth_rgb(SEED, 0, distinct, side, side)
+
+            def encode(k):
+                b = io.BytesIO()
+                Image.fromarray(src_px[k]).save(b, "JPEG", quality=85, subsampling=2)
+                return b.getvalue()
+
+            with ThreadPoolExecutor(16) as ex:
+                enc = list(ex.map(encode, range(distinct)))
+            del src_px
+            blobs = [enc[k % distinct] for k in range(n_files)]
+            ctx.jpeg_hash(blobs, want_dhash=False)                      # buffers
+            t0 = time.perf_counter()
+            ph_j, _, st_j = ctx.jpeg_hash(blobs, want_dhash=False)
+            dt = time.perf_counter() - t0
+            check = [np.asarray(Image.open(io.BytesIO(enc[k]))) for k in range(4)]
+            ph_ref = ctx.hash_images(check, want_dhash=False)[0]
+            ok = bool((st_j == 0).all()) and np.array_equal(np.asarray(ph_ref, np.uint64), ph_j[:4])
+            decode_leg = {"images_per_s": n_files / dt, "files": n_files, "compressed_mb": sum(len(b) for b in blobs) / 1e6,
+                          "decode_kernels_ms": ctx.last_kernel_ms(4), "matches_pillow_decode": ok,
+                          "what": f"{side}x{side} JPEG (quality 85, 4:2:0) files in host memory -> ke_host_pack -> H2D -> ke_jpeg_decode -> "
+                                  "ke_hash_images, one call, wall clock; file reading not included (benchmarks/bench_fastsig.py: from disk to SQLite rows)"}
+            ctx.release_decode_buffers()
+        except Exception as exc:   # noqa: BLE001 - an informational leg must not cost the bench line
+            print(f"[bench] decode-inclusive leg skipped: {exc}", file=sys.stderr)
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = n_total * args.steps / elapsed
@@ -408,6 +448,7 @@ def main():
             # within 1e-3 / 1e-4 of a tie (another DCT implementation, e.g. OpenCV's float32 one, may flip such a bit)
             "phash_near_ties": near_ties,
             **({"h2d_inclusive": h2d} if h2d else {}),
+            **({"decode_inclusive": decode_leg} if decode_leg else {}),
             "roofline": {"bound": "hbm", "kernel": "ke_phash_fused_mx", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": "profiles/hash_kernel_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE pass of this kernel at this "

@@ -26,7 +26,8 @@ def main():
     ap.add_argument("--quality", type=int, default=85)
     ap.add_argument("--subsampling", type=int, default=2)
     ap.add_argument("--format", choices=["jpeg", "png"], default="jpeg")
-    ap.add_argument("--distinct", type=int, default=256, help="distinct images encoded (the batch cycles through them)")
+    ap.add_argument("--distinct", type=int, default=4096,
+                    help="distinct images encoded (the batch cycles through them; few copies of each, so that the lanes of a wave hold different images)")
     ap.add_argument("--progressive", action="store_true", help="JPEG: progressive files (libjpeg's default scan script)")
     ap.add_argument("--content", choices=["corpus", "drawing"], default="corpus",
                     help="corpus: the synthetic corpus images (textured, photograph-like: PNG stays near half its raw size); "
@@ -37,7 +38,7 @@ def main():
     from kobato_eyes_amd import _native
 
     ctx = _native.Context(0)
-    distinct = args.distinct
+    distinct = min(args.distinct, args.images)
     px = ctx.synth_rgb(20260604, 0, distinct, args.side, args.side)
     if args.content == "drawing":
         rng = np.random.default_rng(11)

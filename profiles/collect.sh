@@ -15,14 +15,14 @@ run() { echo "== $*" >&2; "$@"; echo "rc=$?" >&2; }
 
 # 1. the bench lines themselves
 run python3 "$B" --steps 10 --warmup 3 > "$out/${tag}_bench.json" 2> "$out/${tag}_bench.err"
-run python3 "$B" --steps 10 --warmup 3 --ssim-threshold 0.95 --no-cpu-baseline --no-h2d > "$out/${tag}_bench_ssim095.json" 2> "$out/${tag}_bench_ssim095.err"
+run python3 "$B" --steps 10 --warmup 3 --ssim-threshold 0.95 --no-cpu-baseline --no-h2d --no-decode > "$out/${tag}_bench_ssim095.json" 2> "$out/${tag}_bench_ssim095.err"
 # 2. kernel statistics of the same commands
-run rocprofv3 --kernel-trace --stats --output-format csv -d "$out/${tag}_stats" -- python3 "$B" --steps 10 --warmup 3 --no-cpu-baseline --no-h2d > "$out/${tag}_stats.log" 2>&1
-run rocprofv3 --kernel-trace --stats --output-format csv -d "$out/${tag}_stats_ssim" -- python3 "$B" --steps 10 --warmup 3 --ssim-threshold 0.95 --no-cpu-baseline --no-h2d > "$out/${tag}_stats_ssim.log" 2>&1
+run rocprofv3 --kernel-trace --stats --output-format csv -d "$out/${tag}_stats" -- python3 "$B" --steps 10 --warmup 3 --no-cpu-baseline --no-h2d --no-decode > "$out/${tag}_stats.log" 2>&1
+run rocprofv3 --kernel-trace --stats --output-format csv -d "$out/${tag}_stats_ssim" -- python3 "$B" --steps 10 --warmup 3 --ssim-threshold 0.95 --no-cpu-baseline --no-h2d --no-decode > "$out/${tag}_stats_ssim.log" 2>&1
 # 3. counters, one pass each (hash, scan and SSIM kernels all run in the --ssim-threshold step)
 for c in FETCH_SIZE WRITE_SIZE "SQ_INSTS_VALU SQ_INSTS_VALU_MFMA_MOPS_I8 SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES" "SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY"; do
     name="$(echo "$c" | tr ' ' '+' | cut -c1-40)"
-    run rocprofv3 --pmc $c --output-format csv -d "$out/${tag}_pmc_${name}" -- python3 "$B" --steps 2 --warmup 1 --ssim-threshold 0.95 --no-cpu-baseline --no-h2d > "$out/${tag}_pmc_${name}.log" 2>&1
+    run rocprofv3 --pmc $c --output-format csv -d "$out/${tag}_pmc_${name}" -- python3 "$B" --steps 2 --warmup 1 --ssim-threshold 0.95 --no-cpu-baseline --no-h2d --no-decode > "$out/${tag}_pmc_${name}.log" 2>&1
 done
 # 4. the scan alone at several table sizes (N = 1 000 000 is BASELINE configs[3]'s table), the streaming-read ceiling
 run python3 "$root/benchmarks/scan_sizes.py" > "$out/${tag}_scan_sizes.jsonl" 2> "$out/${tag}_scan_sizes.err"

@@ -18,7 +18,6 @@ import logging
 import os
 import sqlite3
 import sys
-from pathlib import Path
 from typing import Iterator, Optional, Sequence
 
 CSV_HEADER = ["group", "file_id", "path", "size", "width", "height", "keeper", "hamming"]

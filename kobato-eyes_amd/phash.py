@@ -6,7 +6,7 @@ first).  The arithmetic runs in libkeyes_hip.so (csrc/ke_hash.hip); there is no 
 """
 from __future__ import annotations
 
-from typing import Iterable, Optional, Sequence
+from typing import Sequence
 
 import numpy as np
 

@@ -11,7 +11,6 @@ import importlib
 import logging
 import os
 from dataclasses import dataclass
-from pathlib import Path
 from typing import Optional, Sequence
 
 import numpy as np

@@ -480,10 +480,12 @@ class Context:
                                                                 _addr(out_off), _addr(st)), f"ke_{kind}_decode")
         return dev, out_off, w, h, c, st
 
-    def decode_files_owned(self, paths, kind: str = "jpeg"):
+    def decode_files_owned(self, paths, kind: str = "jpeg", *, by_shape: bool = False):
         """Files on disk decoded into a device buffer of their own (the caller frees it with ``free``): (device ptr or 0, byte
         offsets, widths, heights, channels, status, caveat flags).  ``flags`` are ke_jpeg_caveats / ke_png_caveats' bits: what
-        the reference's defensive loader would do to the file beyond Image.open (EXIF orientation, transparency)."""
+        the reference's defensive loader would do to the file beyond Image.open (EXIF orientation, transparency).
+        ``by_shape``: images of one (width, height, channels) lie back to back without padding, so that each such group
+        can go to the uniform-batch kernels as it is (np.unique over (w, h, c) of the decodable files gives the groups)."""
         paths = list(paths)
         n = len(paths)
         w, h, c, st, flags = (np.zeros(n, np.int32) for _ in range(5))
@@ -498,9 +500,26 @@ class Context:
             if getattr(self._lib, f"ke_{kind}_caveats")(_addr(flat), _addr(offsets), _addr(sizes), n, _addr(flags)) != KE_OK:
                 raise ValueError(f"ke_{kind}_caveats: bad arguments")
             nbytes = np.where(st == 0, w.astype(np.int64) * h * c, 0)
-            padded = (nbytes + 15) & ~np.int64(15)
-            out_off[1:] = np.cumsum(padded[:-1]).astype(np.uint64)
-            total = int(padded.sum())
+            if by_shape:
+                order = np.lexsort((w, h, c, st != 0))              # decodable files first, grouped by shape
+                sorted_bytes = nbytes[order]
+                key = np.stack([w[order], h[order], c[order]], 1)
+                new_group = np.ones(n, bool)
+                new_group[1:] = (key[1:] != key[:-1]).any(1)
+                starts = np.zeros(n, np.int64)
+                at = 0
+                for k in range(n):                                  # groups start on 16 bytes, images inside follow tightly
+                    if new_group[k]:
+                        at = (at + 15) & ~15
+                    starts[k] = at
+                    at += int(sorted_bytes[k])
+                out_off[order] = starts.astype(np.uint64)
+                out_off[nbytes == 0] = np.uint64(0xFFFFFFFFFFFFFFFF)   # not laid out (refused by the probe)
+                total = at
+            else:
+                padded = (nbytes + 15) & ~np.int64(15)
+                out_off[1:] = np.cumsum(padded[:-1]).astype(np.uint64)
+                total = int(padded.sum())
             if total == 0:
                 return 0, out_off, w, h, c, st, flags
             dev = self.malloc(total + 64)

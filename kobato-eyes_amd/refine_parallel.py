@@ -70,6 +70,59 @@ def _thumbnails(arrays: Sequence[np.ndarray], side: int, device: int) -> list:
     return out
 
 
+_GPU_SUFFIXES = {"jpeg": (".jpg", ".jpeg", ".jpe", ".jfif"), "png": (".png",)}
+
+
+def _thumbnails_decoded_on_gpu(paths: Sequence[Path], side: int, device: int) -> dict:
+    """{path: side x side BILINEAR luma thumbnail} for the JPEG / PNG files whose pixels ``_decode`` would return exactly as
+    the GPU decoders do -- every kind they take, unless the file carries an EXIF orientation to apply (ke_*_caveats).  The
+    files are read, decoded and shrunk without their pixels ever being in host memory; files left out (other formats,
+    refused, damaged, turned) are for ``_decode``.  ``KE_GPU_REFINE_DECODE=0`` turns the route off."""
+    out: dict = {}
+    if os.environ.get("KE_GPU_REFINE_DECODE", "1") == "0":
+        return out
+    ctx = _native.get_context(device)
+    not_laid = np.uint64(0xFFFFFFFFFFFFFFFF)
+    for kind, suffixes in _GPU_SUFFIXES.items():
+        if os.environ.get({"jpeg": "KE_GPU_JPEG", "png": "KE_GPU_PNG"}[kind], "1") == "0":
+            continue
+        mine = [p for p in paths if str(p).lower().endswith(suffixes)]
+        at = 0
+        while at < len(mine):
+            stop, estimate = at, 0                                   # a few GB of decoded pixels per call
+            while stop < len(mine) and stop - at < 8192 and (estimate < (4 << 30) or stop == at):
+                try:
+                    estimate += 48 * os.path.getsize(mine[stop])
+                except OSError:
+                    pass
+                stop += 1
+            part = mine[at:stop]
+            at = stop
+            try:
+                dev, off, w, h, c, st, flags = ctx.decode_files_owned([str(p) for p in part], kind, by_shape=True)
+            except (RuntimeError, ValueError):
+                continue                                             # the Pillow route decides about these files
+            if not dev:
+                continue
+            try:
+                laid = np.nonzero(off != not_laid)[0]
+                laid = laid[np.argsort(off[laid], kind="stable")]   # layout order: one run per (width, height, channels)
+                shapes = np.stack([w[laid], h[laid], c[laid]], 1)
+                cuts = np.nonzero((shapes[1:] != shapes[:-1]).any(1))[0] + 1
+                for run in np.split(np.arange(len(laid)), cuts):
+                    idx = laid[run]
+                    ww, hh, cc = int(w[idx[0]]), int(h[idx[0]]), int(c[idx[0]])
+                    thumbs = ctx.resize_luma_uniform(dev + int(off[idx[0]]), len(idx), ww, hh, cc, side, side, filter=1)
+                    for k, i in enumerate(idx.tolist()):
+                        if st[i] == 0 and not flags[i] & 1:
+                            out[part[i]] = thumbs[k]
+            except (RuntimeError, ValueError):
+                pass
+            finally:
+                ctx.free(dev)
+    return out
+
+
 def tile_ahash_from_arrays(arrays: Sequence[np.ndarray], grid: int = 4, tile: int = 8, *, device: int = 0) -> list:
     """Tile aHash of decoded images -> Python ints (little-endian packing of the reference)."""
     if not arrays:
@@ -120,12 +173,40 @@ def refine_by_tilehash_parallel(clusters: Sequence, grid: int = 4, tile: int = 8
     # most io_workers decoded images at once and shrinks each to 32x32 immediately; 256 twelve-megapixel files at once
     # would be 9 GB of host memory)
     budget, step = 512 << 20, max(8, 2 * io_workers)
+    side = grid * tile
+
+    def count(n_files: int) -> None:
+        nonlocal done
+        before, done = done, done + n_files
+        if tick:
+            for mark in range((before // 64 + 1) * 64, done + 1, 64):
+                tick(mark, total1, phase=1)
+            if done == total1 and done % 64:
+                tick(done, total1, phase=1)
+
+    # JPEG / PNG files first, thousands at a time, decoded and shrunk on the GPU; what that route leaves goes through Pillow
+    todo = []
+    for lo in range(0, total1, 4096):
+        if is_cancelled and is_cancelled():
+            return []
+        batch = uniq_paths[lo:lo + 4096]
+        thumbs = _thumbnails_decoded_on_gpu(batch, side, device)
+        if thumbs:
+            keys = list(thumbs)
+            try:
+                words = _native.get_context(device).tile_ahash(np.stack([thumbs[p] for p in keys]), len(keys), grid, tile)
+                cache.update({p: int.from_bytes(row.tobytes(), "little") for p, row in zip(keys, words)})
+                count(len(keys))
+            except (RuntimeError, ValueError):
+                thumbs = {}
+        todo.extend(p for p in batch if p not in thumbs)
+    uniq_paths, total_rest = todo, len(todo)
     start = 0
-    while start < total1:
+    while start < total_rest:
         if is_cancelled and is_cancelled():
             return []
         decoded, held = [], 0
-        while start < total1 and held < budget and len(decoded) < 256:
+        while start < total_rest and held < budget and len(decoded) < 256:
             part = _decode_all(uniq_paths[start:start + step], io_workers)
             start += len(part)
             decoded.extend(part)
@@ -142,9 +223,7 @@ def refine_by_tilehash_parallel(clusters: Sequence, grid: int = 4, tile: int = 8
                 key = f"{type(a).__name__}: {a}"
                 failure_counts[key] += 1
                 failure_samples.setdefault(key, p)
-            done += 1
-            if tick and (done % 64 == 0 or done == total1):
-                tick(done, total1, phase=1)
+        count(len(decoded))
     if failure_counts:
         log.warning("TileHash phase1 skipped %d file(s) due to errors: %s", sum(failure_counts.values()),
                     _format_failure_summary(failure_counts, failure_samples))

@@ -302,6 +302,18 @@ def test_shipped_refine_stage_kernels_and_dropins(K, tmp_path):
         assert np.array_equal(lan, O.hash_image(px, want_tiles=True)[2]), name
     for a, b, mae in g["mae"]:
         assert RP._mae01(thumbs[a], thumbs[b]) == mae
+    # the same thumbnails with the files decoded on the GPU (what refine_by_tilehash_parallel does for .jpg / .png), a JPEG
+    # stored rotated excluded: that one is for Image.open + exif_transpose
+    turned = tmp_path / "turned.jpg"
+    exif = Image.Exif()
+    exif[0x0112] = 8
+    Image.fromarray(next(px for _, px in G.refine_corpus() if px.ndim == 3 and px.shape[2] == 3)).save(turned, quality=90, exif=exif.tobytes())
+    plain = tmp_path / "plain.jpg"
+    Image.fromarray(next(px for _, px in G.refine_corpus() if px.ndim == 3 and px.shape[2] == 3)).save(plain, quality=90)
+    on_gpu = RP._thumbnails_decoded_on_gpu(list(paths.values()) + [turned, plain], 32, 0)
+    assert set(on_gpu) == set(paths.values()) | {plain}
+    for p, t in on_gpu.items():
+        assert np.array_equal(t, RP._thumbnails([RP._decode(p)], 32, 0)[0]), p
 
     @dataclass
     class F:

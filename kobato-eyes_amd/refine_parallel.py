@@ -272,13 +272,23 @@ def refine_by_pixels_parallel(clusters: Sequence, mae_thr: float = 0.006, thumb_
     out = []
     ctx = _native.get_context(device)
     pixels = thumb_size * thumb_size
+    # the JPEG / PNG members of all clusters first, thousands at a time: read, decoded and shrunk on the GPU (the per-cluster
+    # loop below then only decodes what that route left out)
+    ready: dict = {}
+    distinct = list(dict.fromkeys(_norm_path(e.file.path) for cl in clusters for e in cl.files))
+    for lo in range(0, len(distinct), 4096):
+        if is_cancelled and is_cancelled():
+            return []
+        ready.update(_thumbnails_decoded_on_gpu(distinct[lo:lo + 4096], thumb_size, device))
     for done, cl in enumerate(clusters, 1):
         if is_cancelled and is_cancelled():
             return []
         keep = next((e for e in cl.files if e.file.file_id == cl.keeper_id), None)
         if keep is not None:
             paths = [keep.file.path] + [e.file.path for e in cl.files]
-            decoded = _decode_all(paths, worker_count)
+            have = [ready.get(_norm_path(p)) for p in paths]
+            rest = dict(_decode_all([p for p, t in zip(paths, have) if t is None], worker_count))
+            decoded = [(p, t if t is not None else rest[p]) for p, t in zip(paths, have)]      # thumbnail, array or Exception
             if isinstance(decoded[0][1], Exception):
                 key = f"{type(decoded[0][1]).__name__}: {decoded[0][1]}"
                 keeper_failures[key] += 1
@@ -291,7 +301,9 @@ def refine_by_pixels_parallel(clusters: Sequence, mae_thr: float = 0.006, thumb_
                         entry_failures[key] += 1
                         entry_samples.setdefault(key, p)
                 try:
-                    thumbs = np.stack(_thumbnails([decoded[k][1] for k in good], thumb_size, device))
+                    todo = [k for k in good if have[k] is None]
+                    made = dict(zip(todo, _thumbnails([decoded[k][1] for k in todo], thumb_size, device))) if todo else {}
+                    thumbs = np.stack([have[k] if have[k] is not None else made[k] for k in good])
                     slot = {k: j for j, k in enumerate(good)}
                     members = [k for k in good if k >= 1]
                     sad = ctx.sad_pairs(thumbs.reshape(len(good), -1), len(good), pixels, [slot[k] for k in members],

@@ -304,7 +304,11 @@ class _Pipeline:
         for kind, (positions, blobs) in coded.items():
             if not blobs:
                 continue
-            ph, dh, st = self.stage.hash_files(blobs, kind) if by_path else self.stage.jpeg_hash(blobs, kind)
+            try:
+                ph, dh, st = self.stage.hash_files(blobs, kind) if by_path else self.stage.jpeg_hash(blobs, kind)
+            except (RuntimeError, ValueError, MemoryError):      # e.g. no room on the device for this batch: Pillow decodes it
+                refused.extend(positions)
+                continue
             signed = zip(np.asarray(ph, np.uint64).view(np.int64).tolist(), np.asarray(dh, np.uint64).view(np.int64).tolist())
             for k, sig, code in zip(positions, signed, np.asarray(st).tolist()):
                 if code == 0:

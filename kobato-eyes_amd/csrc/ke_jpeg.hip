@@ -675,10 +675,12 @@ KE_API int ke_jpeg_decode(ke_ctx *ctx, const uint8_t *files, const uint64_t *off
     }
     std::vector<int32_t> prog_list;
     // sub-batches bounded by scratch: coefficients (2 B per sample) + planes (1 B per sample)
-    // one thread per image: the larger the sub-batch the better the chip is filled -- up to a third of the free HBM
+    // one thread per image: the larger the sub-batch the better the chip is filled (65 536 images are one wave per SIMD) -- the
+    // scratch this context already holds, or half of what is free on top of it, up to 160 GB
     size_t free_b = 0, total_b = 0;
     KE_HIP(ctx, hipMemGetInfo(&free_b, &total_b));
-    const uint64_t budget = std::max<uint64_t>((uint64_t)2 << 30, std::min<uint64_t>((uint64_t)free_b / 3, (uint64_t)80 << 30));
+    const uint64_t held = (uint64_t)ctx->buf[KE_BUF_TMP].bytes + ctx->buf[KE_BUF_SSIM_IN].bytes;
+    const uint64_t budget = std::max<uint64_t>((uint64_t)2 << 30, std::min<uint64_t>(held + (uint64_t)free_b / 2, (uint64_t)160 << 30));
     size_t first = 0;
     std::vector<int32_t> st;
     ke_time_begin(ctx, KE_T_JPEG);
@@ -686,8 +688,12 @@ KE_API int ke_jpeg_decode(ke_ctx *ctx, const uint8_t *files, const uint64_t *off
         uint64_t coef_units = 0, plane_bytes = 0;
         size_t last = first;
         int max_blocks = 0, max_quads = 0;
-        while (last < devs.size() && last - first < 65535) {
+        int64_t progressive_here = 0;
+        while (last < devs.size() && last - first < 65535) {     // the image index is blockIdx.y of the IDCT and colour kernels
             KeJpegDev &d = devs[last];
+            // progressive files: at most two waves of them per CU in one launch (measured: a third wave per CU slows all three
+            // by more than it adds -- 65 536 files 458 ms in one launch, 417 in two)
+            if (d.info.progressive && ++progressive_here > 32768) break;
             uint64_t blocks = 0, pl = 0;
             for (int c = 0; c < d.info.ncomp; ++c) {
                 blocks += (uint64_t)(d.info.plane_w[c] >> 3) * (d.info.plane_h[c] >> 3);

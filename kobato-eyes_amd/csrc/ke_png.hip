@@ -592,7 +592,8 @@ KE_API int ke_png_decode(ke_ctx *ctx, const uint8_t *files, const uint64_t *offs
     // sub-batches bounded by scratch (streams + filtered scanlines) and by 32-bit stream offsets
     size_t free_b = 0, total_b = 0;
     KE_HIP(ctx, hipMemGetInfo(&free_b, &total_b));
-    const uint64_t budget = std::max<uint64_t>((uint64_t)2 << 30, std::min<uint64_t>((uint64_t)free_b / 3, (uint64_t)80 << 30));
+    const uint64_t held = (uint64_t)ctx->buf[KE_BUF_SSIM_IN].bytes + ctx->buf[KE_BUF_TMP].bytes + ctx->buf[KE_BUF_SSIM_AUX].bytes;
+    const uint64_t budget = std::max<uint64_t>((uint64_t)2 << 30, std::min<uint64_t>(held + (uint64_t)free_b / 2, (uint64_t)160 << 30));
     std::vector<KePngDev> devs;
     std::vector<KePngPiece> pieces;
     std::vector<int32_t> st;

@@ -476,6 +476,59 @@ __global__ __launch_bounds__(256) void ke_jpeg_idct(const KeJpegDev *__restrict_
     }
 }
 
+// the four chroma samples around quad x0 of one row pair, columns clamped to the component (jdsample.c's edge cases), each
+// already weighted 3:1 between the nearer and the farther row when the component is subsampled vertically: two dword loads
+__device__ __forceinline__ void chroma4(const uint8_t *in0, const uint8_t *in1, int i0, int cw, bool v2, int *c) {
+    const int from = i0 > 0 ? i0 - 1 : 0;                     // bytes from..from+3 lie inside the padded plane row
+    uint32_t a, b;
+    __builtin_memcpy(&a, in0 + from, 4);
+    __builtin_memcpy(&b, in1 + from, 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int col = i0 - 1 + j;
+        col = col < 0 ? 0 : (col > cw - 1 ? cw - 1 : col);
+        const int sh = 8 * (col - from);                      // 0..24: the clamped column is one of the four loaded
+        const int s0 = (int)((a >> sh) & 255u), s1 = (int)((b >> sh) & 255u);
+        c[j] = v2 ? s0 * 3 + s1 : s0;
+    }
+}
+
+__device__ __forceinline__ int4 upsample4_fast(const uint8_t *plane, int pw, int cw, int ch, int hfac, int vfac, int x0, int y) {
+    if (hfac == 1) {                                          // vfac is 1 too: the samples themselves, x0 a multiple of 4
+        const uint32_t v = *reinterpret_cast<const uint32_t *>(plane + (size_t)y * pw + x0);
+        return make_int4((int)(v & 255u), (int)((v >> 8) & 255u), (int)((v >> 16) & 255u), (int)(v >> 24));
+    }
+    if (cw <= 2) {
+        int t[4];
+        ke_upsample4(plane, pw, cw, ch, hfac, vfac, x0, y, t);
+        return make_int4(t[0], t[1], t[2], t[3]);
+    }
+    const int i0 = x0 >> 1;
+    const int r0 = vfac == 2 ? (y >> 1) : y;
+    int r1 = r0;
+    if (vfac == 2) {
+        r1 = (y & 1) ? r0 + 1 : r0 - 1;
+        r1 = r1 < 0 ? 0 : (r1 > ch - 1 ? ch - 1 : r1);
+    }
+    int c[4];
+    chroma4(plane + (size_t)r0 * pw, plane + (size_t)r1 * pw, i0, cw, vfac == 2, c);
+    const bool first = i0 == 0, last0 = i0 == cw - 1, last1 = i0 + 1 >= cw - 1;
+    if (vfac == 2)
+        return make_int4(first ? (c[1] * 4 + 8) >> 4 : (c[1] * 3 + c[0] + 8) >> 4, last0 ? (c[1] * 4 + 7) >> 4 : (c[1] * 3 + c[2] + 7) >> 4,
+                         (c[2] * 3 + c[1] + 8) >> 4, last1 ? (c[2] * 4 + 7) >> 4 : (c[2] * 3 + c[3] + 7) >> 4);
+    return make_int4(first ? c[1] : (c[1] * 3 + c[0] + 1) >> 2, last0 ? c[1] : (c[1] * 3 + c[2] + 2) >> 2, (c[2] * 3 + c[1] + 1) >> 2,
+                     last1 ? c[2] : (c[2] * 3 + c[3] + 2) >> 2);
+}
+
+// jdcolor.c ycc_rgb_convert for one pixel, as R | G << 8 | B << 16
+__device__ __forceinline__ uint32_t ycc_to_rgb24(int y, int cb, int cr) {
+    const int xb = cb - 128, xr = cr - 128;
+    const int r = y + ((91881 * xr + 32768) >> 16);
+    const int g = y + ((-22554 * xb + 32768 + (-46802) * xr) >> 16);
+    const int b = y + ((116130 * xb + 32768) >> 16);
+    return (uint32_t)min(max(r, 0), 255) | ((uint32_t)min(max(g, 0), 255) << 8) | ((uint32_t)min(max(b, 0), 255) << 16);
+}
+
 __global__ __launch_bounds__(256) void ke_jpeg_colour(const KeJpegDev *__restrict__ imgs, const uint8_t *__restrict__ planes,
                                                       uint8_t *__restrict__ out) {
     const KeJpegDev &d = imgs[blockIdx.y];
@@ -496,20 +549,18 @@ __global__ __launch_bounds__(256) void ke_jpeg_colour(const KeJpegDev *__restric
         return;
     }
     const uint8_t *Cb = planes + d.plane_off[1], *Cr = planes + d.plane_off[2];
-    uint8_t px[12];
-    int cb[4], cr[4];
-    ke_upsample4(Cb, in.plane_w[1], in.comp_w[1], in.comp_h[1], in.hmax, in.vmax, x0, y, cb);
-    ke_upsample4(Cr, in.plane_w[2], in.comp_w[2], in.comp_h[2], in.hmax, in.vmax, x0, y, cr);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) ke_ycc_to_rgb((int)((y4 >> (8 * k)) & 0xFF), cb[k], cr[k], px + 3 * k);
+    const int4 cb = upsample4_fast(Cb, in.plane_w[1], in.comp_w[1], in.comp_h[1], in.hmax, in.vmax, x0, y);
+    const int4 cr = upsample4_fast(Cr, in.plane_w[2], in.comp_w[2], in.comp_h[2], in.hmax, in.vmax, x0, y);
+    const uint32_t p0 = ycc_to_rgb24((int)(y4 & 0xFF), cb.x, cr.x), p1 = ycc_to_rgb24((int)((y4 >> 8) & 0xFF), cb.y, cr.y);
+    const uint32_t p2 = ycc_to_rgb24((int)((y4 >> 16) & 0xFF), cb.z, cr.z), p3 = ycc_to_rgb24((int)(y4 >> 24), cb.w, cr.w);
+    const uint32_t w0 = p0 | (p1 << 24), w1 = (p1 >> 8) | (p2 << 16), w2 = (p2 >> 16) | (p3 << 8);
     uint8_t *o = dst + ((size_t)y * in.width + x0) * 3;
     if (npx == 4) {
-        uint32_t w[3];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) w[j] = px[4 * j] | (px[4 * j + 1] << 8) | (px[4 * j + 2] << 16) | ((uint32_t)px[4 * j + 3] << 24);
-        __builtin_memcpy(o, w, 12);                                       // any alignment (rows of 3*width bytes)
+        __builtin_memcpy(o, &w0, 4);                                      // any alignment (rows of 3*width bytes)
+        __builtin_memcpy(o + 4, &w1, 4);
+        __builtin_memcpy(o + 8, &w2, 4);
     } else {
-        for (int k = 0; k < 3 * npx; ++k) o[k] = px[k];
+        for (int k = 0; k < 3 * npx; ++k) o[k] = (uint8_t)((k < 4 ? w0 : k < 8 ? w1 : w2) >> (8 * (k & 3)));
     }
 }
 

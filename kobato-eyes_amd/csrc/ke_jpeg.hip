@@ -727,11 +727,12 @@ KE_API int ke_jpeg_decode(ke_ctx *ctx, const uint8_t *files, const uint64_t *off
     std::vector<int32_t> prog_list;
     // sub-batches bounded by scratch: coefficients (2 B per sample) + planes (1 B per sample)
     // one thread per image: the larger the sub-batch the better the chip is filled (65 536 images are one wave per SIMD) -- the
-    // scratch this context already holds, or half of what is free on top of it, up to 160 GB
+    // half of what this context's scratch and the free HBM come to together (a sum that does not move when the scratch is
+    // regrown, so that consecutive calls cut their batches alike and keep their buffers), up to 160 GB
     size_t free_b = 0, total_b = 0;
     KE_HIP(ctx, hipMemGetInfo(&free_b, &total_b));
     const uint64_t held = (uint64_t)ctx->buf[KE_BUF_TMP].bytes + ctx->buf[KE_BUF_SSIM_IN].bytes;
-    const uint64_t budget = std::max<uint64_t>((uint64_t)2 << 30, std::min<uint64_t>(held + (uint64_t)free_b / 2, (uint64_t)160 << 30));
+    const uint64_t budget = std::max<uint64_t>((uint64_t)2 << 30, std::min<uint64_t>((held + (uint64_t)free_b) / 2, (uint64_t)160 << 30));
     size_t first = 0;
     std::vector<int32_t> st;
     ke_time_begin(ctx, KE_T_JPEG);

@@ -328,13 +328,20 @@ __global__ __launch_bounds__(64) void ke_png_matches(const KePngDev *__restrict_
 
 // ---- unfilter
 
+// One pixel of BPP bytes reconstructed (ke_png_recon per byte), without a branch: the predictor of every filter type is
+// computed and the row's own picked by masks (m1..m4: all ones for the row's type, Sub / Up / Average / Paeth) -- the lanes of a
+// wave hold 64 different rows, so a branch per type would run every arm anyway, once per channel.
 template <int BPP>
-__device__ __forceinline__ uint32_t recon_pixel(uint32_t ft, uint32_t x, uint32_t a, uint32_t b, uint32_t c) {
+__device__ __forceinline__ uint32_t recon_pixel(int m1, int m2, int m3, int m4, uint32_t x, uint32_t a, uint32_t b, uint32_t c) {
     uint32_t o = 0;
 #pragma unroll
     for (int ch = 0; ch < BPP; ++ch) {
         const int xa = (int)((a >> (8 * ch)) & 255u), xb = (int)((b >> (8 * ch)) & 255u), xc = (int)((c >> (8 * ch)) & 255u);
-        o |= (uint32_t)ke_png_recon((int)ft, (int)((x >> (8 * ch)) & 255u), xa, xb, xc) << (8 * ch);
+        const int pa = abs(xb - xc), pb = abs(xa - xc), pc = abs(xa + xb - 2 * xc);
+        const int nearest_bc = min(pb, pc), nearest = min(pa, nearest_bc);
+        const int paeth = pa == nearest ? xa : (pb == nearest_bc ? xb : xc);      // ties: left, then above, then upper left
+        const int pred = (xa & m1) | (xb & m2) | (((xa + xb) >> 1) & m3) | (paeth & m4);
+        o |= ((((x >> (8 * ch)) & 255u) + (uint32_t)pred) & 255u) << (8 * ch);
     }
     return o;
 }
@@ -371,6 +378,8 @@ __global__ __launch_bounds__(64) void ke_png_unfilter(const KePngDev *__restrict
     uint32_t o[4] = {0, 0, 0, 0};                     // the four pixels of the previous step (what lane + 1 sees above)
     uint32_t up3 = 0;                                 // upper-left of the next group: the last pixel above of this one
     uint32_t a1 = 0, c32 = 0, s1 = 0, s2 = 0;         // Adler: bytes, offset-weighted bytes of this row; totals mod 65521
+    u32x4 ahead[kWords];                              // the filtered bytes of four groups
+    uint32_t behind[4 * kWords];                      // the reconstructed bytes of four groups
     uint64_t b64 = 0;
     const int steps = rounds * period + 63;
     for (int t = 0; t <= steps; ++t) {
@@ -398,14 +407,27 @@ __global__ __launch_bounds__(64) void ke_png_unfilter(const KePngDev *__restrict
             }
             const int valid = min(4, W - 4 * g);      // pixels of this group
             const uint32_t j0 = 1u + (uint32_t)g * (4 * BPP);
+            // The filtered bytes of four groups at a time (16-byte loads): every lane reads its own row, 64 cache lines per
+            // load instruction, and with dword loads each of them is fetched from L2 ten times over (the lines of all the
+            // waves of a CU do not fit its L1).  A read may run up to 63 bytes past the row: the scratch has that slack.
+            if ((g & 3) == 0) {
+#pragma unroll
+                for (int q = 0; q < kWords; ++q) ahead[q] = ld16(rp + j0 + 16 * q);
+            }
             uint32_t xw[kWords];
-            if (valid == 4) {
 #pragma unroll
-                for (int q = 0; q < kWords; ++q) __builtin_memcpy(&xw[q], rp + j0 + 4 * q, 4);
-            } else {
+            for (int q = 0; q < kWords; ++q) {
+                // dword q of group (g & 3) among the 4 * kWords buffered: element (g & 3) * kWords + q
+                uint32_t v = 0;
 #pragma unroll
-                for (int q = 0; q < kWords; ++q) xw[q] = 0;
-                for (int e = 0; e < valid * BPP; ++e) xw[e >> 2] |= (uint32_t)rp[j0 + e] << (8 * (e & 3));
+                for (int part = 0; part < 4; ++part) {
+                    const int at = part * kWords + q;
+                    const u32x4 from = ahead[at >> 2];
+                    const uint32_t w = (at & 3) == 0 ? from.x : (at & 3) == 1 ? from.y : (at & 3) == 2 ? from.z : from.w;
+                    v = (g & 3) == part ? w : v;
+                }
+                const int have = valid * BPP - 4 * q;                     // bytes of this dword that belong to the row
+                xw[q] = have >= 4 ? v : have <= 0 ? 0u : (v & ((1u << (8 * have)) - 1u));
             }
             // Adler-32 terms of these bytes: sum and offset-weighted sum
 #pragma unroll
@@ -427,9 +449,10 @@ __global__ __launch_bounds__(64) void ke_png_unfilter(const KePngDev *__restrict
                 x[k] = v;
             }
             uint32_t left = o[3], ul = up3;
+            const int m1 = -(int)(ft == 1), m2 = -(int)(ft == 2), m3 = -(int)(ft == 3), m4 = -(int)(ft >= 4);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                o[k] = recon_pixel<BPP>(ft, x[k], left, up[k], ul);
+                o[k] = recon_pixel<BPP>(m1, m2, m3, m4, x[k], left, up[k], ul);
                 left = o[k];
                 ul = up[k];
             }
@@ -455,7 +478,21 @@ __global__ __launch_bounds__(64) void ke_png_unfilter(const KePngDev *__restrict
                     const int x0 = (4 * g + e) * per;
                     for (int q = 0; q < per && x0 + q < px; ++q) wp[x0 + q] = s_lut[(byte >> (8 - depth * (q + 1))) & top];
                 }
-            } else {
+            } else if (((g | 3) + 1) * 4 <= W) {
+                // one of four whole groups in a row: gathered, written with 16-byte stores when the fourth is done
+#pragma unroll
+                for (int part = 0; part < 4; ++part)
+#pragma unroll
+                    for (int q = 0; q < kWords; ++q) {
+                        const int at = part * kWords + q;
+                        behind[at] = (g & 3) == part ? ow[q] : behind[at];
+                    }
+                if ((g & 3) == 3) {
+                    uint8_t *wp = dst + (size_t)row * rb + (size_t)(g - 3) * (4 * BPP);
+#pragma unroll
+                    for (int q = 0; q < kWords; ++q) st16(wp + 16 * q, u32x4{behind[4 * q], behind[4 * q + 1], behind[4 * q + 2], behind[4 * q + 3]});
+                }
+            } else {                                      // the groups at the end of a row that do not fill a block of four
                 uint8_t *wp = dst + (size_t)row * rb + (size_t)g * (4 * BPP);
                 if (valid == 4) {
 #pragma unroll
@@ -593,7 +630,7 @@ KE_API int ke_png_decode(ke_ctx *ctx, const uint8_t *files, const uint64_t *offs
     size_t free_b = 0, total_b = 0;
     KE_HIP(ctx, hipMemGetInfo(&free_b, &total_b));
     const uint64_t held = (uint64_t)ctx->buf[KE_BUF_SSIM_IN].bytes + ctx->buf[KE_BUF_TMP].bytes + ctx->buf[KE_BUF_SSIM_AUX].bytes;
-    const uint64_t budget = std::max<uint64_t>((uint64_t)2 << 30, std::min<uint64_t>(held + (uint64_t)free_b / 2, (uint64_t)160 << 30));
+    const uint64_t budget = std::max<uint64_t>((uint64_t)2 << 30, std::min<uint64_t>((held + (uint64_t)free_b) / 2, (uint64_t)160 << 30));
     std::vector<KePngDev> devs;
     std::vector<KePngPiece> pieces;
     std::vector<int32_t> st;
@@ -636,7 +673,7 @@ KE_API int ke_png_decode(ke_ctx *ctx, const uint8_t *files, const uint64_t *offs
         KE_TRY(ke_reserve(ctx, KE_BUF_SSIM_IN, (size_t)zbytes + 256, &d_streams));      // the stream windows read up to 64 bytes past an image's data
         KE_TRY(ke_reserve(ctx, KE_BUF_META, (size_t)m * sizeof(KePngDev), &d_imgs));
         KE_TRY(ke_reserve(ctx, KE_BUF_JPEG_TABLES, pieces.size() * sizeof(KePngPiece), &d_pieces));
-        KE_TRY(ke_reserve(ctx, KE_BUF_TMP, (size_t)raw_bytes + 64, &d_raw));
+        KE_TRY(ke_reserve(ctx, KE_BUF_TMP, (size_t)raw_bytes + 128, &d_raw));
         KE_TRY(ke_reserve(ctx, KE_BUF_OUT1, (size_t)m * kWorkBytes, &d_work));
         KE_TRY(ke_reserve(ctx, KE_BUF_OUT0, (size_t)m * 4, &d_status));
         KE_TRY(ke_reserve(ctx, KE_BUF_OUT2, (size_t)m * 4, &d_adler));

@@ -129,12 +129,11 @@ __device__ __forceinline__ int huff_decode(KeBits &b, Stream &st, const T *t) {
     return t->huffval[(code + t->valoffset[l]) & 0xFF];
 }
 
-__device__ __forceinline__ int receive_extend(KeBits &b, Stream &st, int s) {
-    if (s == 0) return 0;
-    bits_fill(b, st);
-    const int v = (int)ke_bits_peek(b, s);
+// the `s` bits behind a Huffman symbol: huff_decode's fill left more than 32 bits, the code took at most 16, s <= 15
+__device__ __forceinline__ int receive_extend(KeBits &b, Stream &, int s) {
+    const int v = s ? (int)ke_bits_peek(b, s) : 0;
     ke_bits_skip(b, s);
-    return v < (1 << (s - 1)) ? v - (1 << s) + 1 : v;
+    return s == 0 ? 0 : (v < (1 << (s - 1)) ? v - (1 << s) + 1 : v);
 }
 
 constexpr int kLdsTables = 4;      // distinct Huffman tables a workgroup keeps in LDS (a standard-table file uses four)

@@ -360,7 +360,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_decode:
         # decode-inclusive rate (never `value`): the same corpus images as JPEG files in host memory (what a library scan starts
         # from) -> page-locked packing -> PCIe (compressed bytes) -> GPU JPEG decode -> the hash kernel on the decoded pixels.
-        # 16 384 files per call; the hashes must be those of Pillow's decode of the same files.
+        # 65 536 files in one call (one wave of the entropy kernel per SIMD); the hashes must be those of Pillow's decode of the
+        # same files.
         try:
             import io
 
@@ -368,7 +369,7 @@ def main():
 
             from concurrent.futures import ThreadPoolExecutor
 
-            distinct, n_files = 4096, 16384                            # few copies of each file: lanes of a wave hold different images
+            distinct, n_files = 4096, 65536                            # 16 copies of each file, spread out: lanes of a wave hold different images
             src_px = ctx.synth_rgb(SEED, 0, distinct, side, side)
 
             def encode(k):

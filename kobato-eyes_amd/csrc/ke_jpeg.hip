@@ -142,7 +142,7 @@ constexpr int kLdsTables = 4;      // distinct Huffman tables a workgroup keeps 
 // dequantises.
 __global__ __launch_bounds__(64) void ke_jpeg_entropy(const KeJpegDev *__restrict__ imgs, int64_t n, const uint8_t *__restrict__ files,
                                                       const KeHuffTable *__restrict__ tables, int16_t *__restrict__ coefs,
-                                                      int32_t *__restrict__ status) {
+                                                      int32_t *__restrict__ status, int lanes) {
     __shared__ KeHuffTable s_tab[kLdsTables];
     __shared__ int s_ids[kLdsTables];
     __shared__ int s_count, s_all;
@@ -150,10 +150,12 @@ __global__ __launch_bounds__(64) void ke_jpeg_entropy(const KeJpegDev *__restric
     __shared__ __attribute__((aligned(16))) uint8_t s_win[64 * kWinPitch];
     __shared__ __attribute__((aligned(16))) uint8_t s_blk[64 * kBlkPitch];
     const int lane = threadIdx.x;
-    const int64_t i = (int64_t)blockIdx.x * 64 + lane;
+    // `lanes` images per wave (the rest of the wave idles): a wave pays the largest block of its lanes at every block, so while
+    // there are SIMDs to spare a batch is spread over more, narrower waves
+    const int64_t i = (int64_t)blockIdx.x * lanes + lane;
     const KeJpegDev &d = imgs[i < n ? i : n - 1];
     const KeJpegInfo &in = d.info;
-    const bool live = i < n && !in.progressive;          // progressive files are ke_jpeg_entropy_prog's
+    const bool live = lane < lanes && i < n && !in.progressive;          // progressive files are ke_jpeg_entropy_prog's
     // the workgroup's distinct tables (files of one encoder share them): up to four go to LDS
     if (lane == 0) { s_count = 0; s_all = 1; }
     s_zz[lane] = c_zigzag[lane];
@@ -338,7 +340,7 @@ struct StoreBlock {            // a block that is only written: coefficients go 
 
 __global__ __launch_bounds__(64) void ke_jpeg_entropy_prog(const KeJpegDev *__restrict__ imgs, const int32_t *__restrict__ list, int64_t n,
                                                            const uint8_t *__restrict__ files, const KeJpegScan *__restrict__ scans,
-                                                           int16_t *__restrict__ coefs, int32_t *__restrict__ status) {
+                                                           int16_t *__restrict__ coefs, int32_t *__restrict__ status, int lanes) {
     __shared__ uint32_t s_lim[24 * 64], s_base[24 * 64];
     __shared__ uint8_t s_sym[256 * 64];
     __shared__ uint8_t s_zz[64];
@@ -347,8 +349,8 @@ __global__ __launch_bounds__(64) void ke_jpeg_entropy_prog(const KeJpegDev *__re
     const int lane = threadIdx.x;
     s_zz[lane] = c_zigzag[lane];
     __syncthreads();
-    const int64_t slot_i = (int64_t)blockIdx.x * 64 + lane;
-    if (slot_i >= n) return;
+    const int64_t slot_i = (int64_t)blockIdx.x * lanes + lane;
+    if (lane >= lanes || slot_i >= n) return;
     const int32_t i = list[slot_i];
     const KeJpegDev &d = imgs[i];
     const KeJpegInfo &in = d.info;
@@ -781,9 +783,17 @@ KE_API int ke_jpeg_decode(ke_ctx *ctx, const uint8_t *files, const uint64_t *off
         prog_list.clear();
         for (int64_t k = 0; k < m; ++k)
             if (devs[first + (size_t)k].info.progressive) prog_list.push_back((int32_t)k);
-        if ((int64_t)prog_list.size() < m)
-            hipLaunchKernelGGL(ke_jpeg_entropy, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, ctx->stream, (const KeJpegDev *)d_imgs, m,
-                               (const uint8_t *)d_files, (const KeHuffTable *)d_tables, (int16_t *)d_coef, (int32_t *)d_status);
+        // images per wave: 64 once there is a wave for every SIMD, fewer (down to 8) while SIMDs would idle
+        auto lanes_for = [&](int64_t images, int64_t waves_wanted) {
+            int lanes = 64;
+            while (lanes > 8 && (images + lanes / 2 - 1) / (lanes / 2) <= waves_wanted) lanes /= 2;
+            return lanes;
+        };
+        if ((int64_t)prog_list.size() < m) {
+            const int lanes = lanes_for(m, (int64_t)ctx->cu_count * 4);
+            hipLaunchKernelGGL(ke_jpeg_entropy, dim3((unsigned)((m + lanes - 1) / lanes)), dim3(64), 0, ctx->stream, (const KeJpegDev *)d_imgs, m,
+                               (const uint8_t *)d_files, (const KeHuffTable *)d_tables, (int16_t *)d_coef, (int32_t *)d_status, lanes);
+        }
         if (!prog_list.empty()) {
             void *d_list;
             KE_TRY(ke_reserve(ctx, KE_BUF_OUT1, prog_list.size() * 4, &d_list));
@@ -798,9 +808,10 @@ KE_API int ke_jpeg_decode(ke_ctx *ctx, const uint8_t *files, const uint64_t *off
                 run0 = run1 + 1;
             }
             const int64_t np = (int64_t)prog_list.size();
-            hipLaunchKernelGGL(ke_jpeg_entropy_prog, dim3((unsigned)((np + 63) / 64)), dim3(64), 0, ctx->stream, (const KeJpegDev *)d_imgs,
+            const int lanes = lanes_for(np, (int64_t)ctx->cu_count * 2);      // two waves of these per CU (see above)
+            hipLaunchKernelGGL(ke_jpeg_entropy_prog, dim3((unsigned)((np + lanes - 1) / lanes)), dim3(64), 0, ctx->stream, (const KeJpegDev *)d_imgs,
                                (const int32_t *)d_list, np, (const uint8_t *)d_files, (const KeJpegScan *)d_scans, (int16_t *)d_coef,
-                               (int32_t *)d_status);
+                               (int32_t *)d_status, lanes);
         }
         hipLaunchKernelGGL(ke_jpeg_idct, dim3((unsigned)((max_blocks + 255) / 256), (unsigned)m), dim3(256), 0, ctx->stream,
                            (const KeJpegDev *)d_imgs, (const int16_t *)d_coef, (uint8_t *)d_planes);

@@ -150,6 +150,13 @@ class _SharedBuffers:
 
     def __init__(self, nbytes: int, count: int = 2) -> None:
         self.paths, self.maps = [], []
+        for stale in os.listdir("/dev/shm"):                 # what a process that died left behind
+            parts = stale.split("_")
+            if stale.startswith("ke_stage_") and len(parts) >= 3 and parts[2].isdigit() and not os.path.exists(f"/proc/{parts[2]}"):
+                try:
+                    os.unlink(os.path.join("/dev/shm", stale))
+                except OSError:
+                    pass
         for k in range(count):
             path = f"/dev/shm/ke_stage_{os.getpid()}_{id(self):x}_{k}"
             fd = os.open(path, os.O_CREAT | os.O_EXCL | os.O_RDWR, 0o600)

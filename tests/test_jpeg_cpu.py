@@ -54,3 +54,46 @@ def test_quad_upsampler_equals_the_per_sample_one():
     """ke_upsample4 (the colour kernel's) == ke_upsample_at (the one held against Pillow above) for every component width 1..21,
     height 1..9 and sampling 1x1 / 2x1 / 2x2."""
     assert _lib().ko_jpeg_upsample_selftest() == 0
+
+
+def test_random_files_decode_as_pillow_does():
+    """Property: whatever Pillow (libjpeg-turbo) writes as a Huffman JPEG -- any size up to 90 x 70, grayscale or colour at
+    4:4:4 / 4:2:2 / 4:2:0, any quality, sequential or progressive, optimised tables or not, restart intervals -- the decoder
+    arithmetic yields Pillow's pixels."""
+    import io
+
+    from hypothesis import given, settings
+    from hypothesis import strategies as st
+    from PIL import Image
+
+    L = _lib()
+
+    @settings(max_examples=120, deadline=None, derandomize=True)
+    @given(st.integers(1, 90), st.integers(1, 70), st.booleans(), st.integers(0, 2), st.integers(1, 100), st.booleans(), st.booleans(),
+           st.integers(0, 9), st.integers(0, 2), st.integers(0, 2 ** 32 - 1))
+    def check(w, h, gray, sub, quality, progressive, optimize, restart, texture, seed):
+        rng = np.random.default_rng(seed)
+        if texture == 0:
+            a = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        elif texture == 1:
+            a = np.repeat(np.repeat(rng.integers(0, 256, (h // 8 + 1, w // 8 + 1, 3), dtype=np.uint8), 8, 0), 8, 1)[:h, :w]
+        else:
+            yy, xx = np.mgrid[0:h, 0:w]
+            a = np.stack([xx * 3 % 256, yy * 5 % 256, (xx + yy) % 256], -1).astype(np.uint8)
+        kw = {"quality": quality, "progressive": progressive, "optimize": optimize}
+        if not gray:
+            kw["subsampling"] = sub
+        if restart:
+            kw["restart_marker_blocks"] = restart
+        b = io.BytesIO()
+        try:
+            Image.fromarray(a[:, :, 0] if gray else a).save(b, "JPEG", **kw)
+        except TypeError:                                   # a Pillow without the restart options
+            kw.pop("restart_marker_blocks")
+            Image.fromarray(a[:, :, 0] if gray else a).save(b, "JPEG", **kw)
+        data = b.getvalue()
+        ref = np.asarray(Image.open(io.BytesIO(data)))
+        status, out = _decode(L, data)
+        assert status == 0 and out.shape == ref.shape and np.array_equal(out, ref)
+
+    check()

@@ -48,3 +48,49 @@ def test_files_outside_the_decoder_are_refused():
     for name, data, expected in P.refused():
         st, _ = _decode(L, data)
         assert st == expected, name
+
+
+def test_random_files_decode_as_pillow_does():
+    """Property: whatever 8-bit image Pillow writes as a non-interlaced PNG -- any size up to 80 x 60, L / RGB / RGBA / P /
+    bilevel, any compression level, optimised or not, with transparency for palette files -- the decoder arithmetic yields what
+    the reference's hashes see (the pixels, or convert("L") of them for the mapped kinds)."""
+    import io
+
+    from hypothesis import given, settings
+    from hypothesis import strategies as st
+    from PIL import Image
+
+    L = _lib()
+
+    @settings(max_examples=120, deadline=None, derandomize=True)
+    @given(st.integers(1, 80), st.integers(1, 60), st.sampled_from(["L", "RGB", "RGBA", "P", "1"]), st.integers(0, 9), st.booleans(),
+           st.integers(0, 3), st.integers(0, 2 ** 32 - 1))
+    def check(w, h, mode, level, optimize, texture, seed):
+        rng = np.random.default_rng(seed)
+        if texture == 0:
+            a = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+        elif texture == 1:
+            a = np.repeat(np.repeat(rng.integers(0, 256, (h // 8 + 1, w // 8 + 1, 4), dtype=np.uint8), 8, 0), 8, 1)[:h, :w]
+        elif texture == 2:
+            a = np.broadcast_to(rng.integers(0, 256, (1, 1, 4), dtype=np.uint8), (h, w, 4)).copy()
+        else:
+            yy, xx = np.mgrid[0:h, 0:w]
+            a = np.stack([xx * 3 % 256, yy * 5 % 256, (xx + yy) % 256, (xx * yy) % 256], -1).astype(np.uint8)
+        if mode == "P":
+            im = Image.fromarray(a[:, :, :3]).quantize(int(rng.integers(2, 257)))
+        elif mode == "1":
+            im = Image.fromarray(a[:, :, 0]).convert("1")
+        else:
+            im = Image.fromarray({"L": a[:, :, 0], "RGB": a[:, :, :3], "RGBA": a}[mode])
+        kw = {"compress_level": level, "optimize": optimize}
+        if mode == "P" and seed & 1:
+            kw["transparency"] = int(seed >> 8) % 2
+        b = io.BytesIO()
+        im.save(b, "PNG", **kw)
+        data = b.getvalue()
+        with Image.open(io.BytesIO(data)) as back:
+            ref = np.asarray(back.convert("L") if back.mode in ("P", "1") else back)
+        status, out = _decode(L, data)
+        assert status == 0 and out.shape == ref.shape and np.array_equal(out, ref)
+
+    check()

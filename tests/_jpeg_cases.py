@@ -78,3 +78,18 @@ def refused():
     yield "truncated", good[: len(good) * 2 // 3], 2
     yield "not_a_jpeg", b"\\x89PNG\\r\\n\\x1a\\n" + bytes(64), 2
     yield "empty", b"", 2
+
+
+def random_cases(n: int, seed: int = 0):
+    """n random Huffman JPEGs as Pillow writes them (sizes up to 200 x 150, gray / 4:4:4 / 4:2:2 / 4:2:0, any quality,
+    sequential or progressive, optimised or not): (name, file bytes, Pillow's pixels)."""
+    rng = np.random.default_rng(seed)
+    for k in range(n):
+        w, h = int(rng.integers(1, 201)), int(rng.integers(1, 151))
+        a = _image(rng, w, h, int(rng.integers(0, 3)))
+        gray = bool(rng.integers(0, 4) == 0)
+        kw = {"quality": int(rng.integers(1, 101)), "progressive": bool(rng.integers(0, 2)), "optimize": bool(rng.integers(0, 2))}
+        if not gray:
+            kw["subsampling"] = int(rng.integers(0, 3))
+        data = _save(a[:, :, 1] if gray else a, **kw)
+        yield f"random{k}_{w}x{h}_{kw}", data, np.asarray(Image.open(io.BytesIO(data)))

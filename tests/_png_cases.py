@@ -144,3 +144,32 @@ def refused():
     yield "truncated", good[: len(good) // 2], 2
     yield "bit_flip_in_idat", good[:100] + bytes([good[100] ^ 1]) + good[101:], 2
     yield "not_a_png", b"GIF89a" + bytes(64), 2
+
+
+def random_cases(n: int, seed: int = 0):
+    """n random files of the kinds the decoder takes (sizes up to 200 x 150, every mode, compression level and texture):
+    (name, file bytes, what the reference's hashes see)."""
+    rng = np.random.default_rng(seed)
+    for k in range(n):
+        w, h = int(rng.integers(1, 201)), int(rng.integers(1, 151))
+        mode = ("L", "RGB", "RGBA", "P", "1")[int(rng.integers(0, 5))]
+        texture = int(rng.integers(0, 3))
+        if texture == 0:
+            a = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+        elif texture == 1:
+            a = np.repeat(np.repeat(rng.integers(0, 256, (h // 8 + 1, w // 8 + 1, 4), dtype=np.uint8), 8, 0), 8, 1)[:h, :w]
+        else:
+            yy, xx = np.mgrid[0:h, 0:w]
+            a = np.stack([xx * 3 % 256, yy * 5 % 256, (xx + yy) % 256, (xx * yy) % 256], -1).astype(np.uint8)
+        if mode == "P":
+            im = Image.fromarray(np.ascontiguousarray(a[:, :, :3])).quantize(int(rng.integers(2, 257)))
+        elif mode == "1":
+            im = Image.fromarray(np.ascontiguousarray(a[:, :, 0])).convert("1")
+        else:
+            im = Image.fromarray(np.ascontiguousarray({"L": a[:, :, 0], "RGB": a[:, :, :3], "RGBA": a}[mode]))
+        b = io.BytesIO()
+        im.save(b, "PNG", compress_level=int(rng.integers(0, 10)), optimize=bool(rng.integers(0, 2)))
+        data = b.getvalue()
+        with Image.open(io.BytesIO(data)) as back:
+            ref = np.asarray(back.convert("L") if back.mode in ("P", "1") else back)
+        yield f"random{k}_{mode}_{w}x{h}", data, ref

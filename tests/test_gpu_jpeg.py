@@ -248,3 +248,13 @@ def test_jpeg_damage_is_survived(ctx):
     assert all((a is None) == (s != 0) for a, s in zip(out, status))
     clean, st = ctx.jpeg_decode([g[1] for g in good])
     assert (st == 0).all() and all(np.array_equal(a, g[2]) for a, g in zip(clean, good))
+
+
+def test_random_files_in_one_batch(ctx):
+    """300 random JPEGs and 300 random PNGs (every kind the decoders take, random sizes, qualities, scripts, compression
+    levels) in one call each: Pillow's pixels, file by file."""
+    for cases, decode in ((list(J.random_cases(300, 41)), ctx.jpeg_decode), (list(P.random_cases(300, 42)), ctx.png_decode)):
+        out, status = decode([c[1] for c in cases])
+        for k, (name, _, ref) in enumerate(cases):
+            assert status[k] == 0, name
+            assert out[k].shape == ref.shape and np.array_equal(out[k], ref), name

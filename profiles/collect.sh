@@ -43,5 +43,6 @@ for n in 16384 65536; do
     run python3 "$D" --format jpeg --progressive --images "$n" >> "$out/${tag}_decode.jsonl" 2>> "$out/${tag}_decode.err"
 done
 run rocprofv3 --kernel-trace --stats --output-format csv -d "$out/${tag}_stats_png" -- python3 "$D" --format png --images 4096 > "$out/${tag}_stats_png.log" 2>&1
-run rocprofv3 --kernel-trace --stats --output-format csv -d "$out/${tag}_stats_jpeg" -- python3 "$D" --format jpeg --images 16384 > "$out/${tag}_stats_jpeg.log" 2>&1
+run rocprofv3 --kernel-trace --stats --output-format csv -d "$out/${tag}_stats_jpeg" -- python3 "$D" --format jpeg --images 65536 > "$out/${tag}_stats_jpeg.log" 2>&1
+run rocprofv3 --kernel-trace --stats --output-format csv -d "$out/${tag}_stats_pngdrawing" -- python3 "$D" --format png --content drawing --images 16384 > "$out/${tag}_stats_pngdrawing.log" 2>&1
 ls "$out" | grep "^${tag}_" | head -40

@@ -25,8 +25,10 @@ if os.path.exists(os.path.join(g, f"{tag}_decode.jsonl")):
     open(os.path.join(here, f"{tag}_decode.jsonl"), "w").writelines(l for l in open(os.path.join(g, f"{tag}_decode.jsonl")) if l.startswith("{"))
     if os.path.exists(os.path.join(g, f"{tag}_fastsig.jsonl")):
         open(os.path.join(here, f"{tag}_fastsig.jsonl"), "w").writelines(l for l in open(os.path.join(g, f"{tag}_fastsig.jsonl")) if l.startswith("{"))
-    for fmt in ("png", "jpeg"):
-        shutil.copy(newest(os.path.join(g, f"{tag}_stats_{fmt}", "**", "*_kernel_stats.csv")), os.path.join(here, f"{tag}_{fmt}_decode_kernel_stats.csv"))
+    for fmt in ("png", "jpeg", "pngdrawing"):
+        found = glob.glob(os.path.join(g, f"{tag}_stats_{fmt}", "**", "*_kernel_stats.csv"), recursive=True)
+        if found:
+            shutil.copy(sorted(found, key=os.path.getmtime)[-1], os.path.join(here, f"{tag}_{fmt}_decode_kernel_stats.csv"))
 h = json.load(open(os.path.join(here, f"{tag}_pmc.json")))["hash"]
 json.dump({"kernel": "ke_phash_fused_mx<8,5,false,false,3,false>", "images_per_launch": 100000, "side": 512,
            "source": f"profiles/{tag}_pmc.json: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, bench.py --steps 2 --warmup 1 "

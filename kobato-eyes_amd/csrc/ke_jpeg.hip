@@ -136,6 +136,7 @@ __device__ __forceinline__ int receive_extend(KeBits &b, Stream &, int s) {
     return s == 0 ? 0 : (v < (1 << (s - 1)) ? v - (1 << s) + 1 : v);
 }
 
+constexpr int kColourRows = 32;    // rows of a workgroup of ke_jpeg_colour
 constexpr int kLdsTables = 4;      // distinct Huffman tables a workgroup keeps in LDS (a standard-table file uses four)
 
 // One thread per image.  Coefficients are stored as decoded (int16, natural order, every block written whole); the IDCT kernel
@@ -477,26 +478,27 @@ __global__ __launch_bounds__(256) void ke_jpeg_idct(const KeJpegDev *__restrict_
     }
 }
 
-// the four chroma samples around quad x0 of one row pair, columns clamped to the component (jdsample.c's edge cases), each
-// already weighted 3:1 between the nearer and the farther row when the component is subsampled vertically: two dword loads
-__device__ __forceinline__ void chroma4(const uint8_t *in0, const uint8_t *in1, int i0, int cw, bool v2, int *c) {
-    const int from = i0 > 0 ? i0 - 1 : 0;                     // bytes from..from+3 lie inside the padded plane row
+// the four chroma samples around quad x0 (columns i0 - 1 .. i0 + 2) of one row pair, each already weighted 3:1 between the
+// nearer and the farther row when the component is subsampled vertically: two dword loads.  No clamping of the columns: the
+// callers' edge cases (jdsample.c's first / last column) never use the samples that would lie outside the component -- at
+// i0 = 0 the load starts at column 0 and the bytes move up one place, c[0] unused; at the right edge c[2] / c[3] are unused.
+__device__ __forceinline__ void chroma4(const uint8_t *in0, const uint8_t *in1, int i0, bool v2, int *c) {
+    const bool first = i0 == 0;
     uint32_t a, b;
-    __builtin_memcpy(&a, in0 + from, 4);
-    __builtin_memcpy(&b, in1 + from, 4);
+    __builtin_memcpy(&a, in0 + (first ? 0 : i0 - 1), 4);      // bytes from..from+3 lie inside the padded plane row
+    __builtin_memcpy(&b, in1 + (first ? 0 : i0 - 1), 4);      // (aligned dwords + a funnel shift instead: no faster, 14.0 against 13.7 ms)
+    a = first ? a << 8 : a;
+    b = first ? b << 8 : b;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        int col = i0 - 1 + j;
-        col = col < 0 ? 0 : (col > cw - 1 ? cw - 1 : col);
-        const int sh = 8 * (col - from);                      // 0..24: the clamped column is one of the four loaded
-        const int s0 = (int)((a >> sh) & 255u), s1 = (int)((b >> sh) & 255u);
+        const int s0 = (int)((a >> (8 * j)) & 255u), s1 = (int)((b >> (8 * j)) & 255u);
         c[j] = v2 ? s0 * 3 + s1 : s0;
     }
 }
 
 __device__ __forceinline__ int4 upsample4_fast(const uint8_t *plane, int pw, int cw, int ch, int hfac, int vfac, int x0, int y) {
     if (hfac == 1) {                                          // vfac is 1 too: the samples themselves, x0 a multiple of 4
-        const uint32_t v = *reinterpret_cast<const uint32_t *>(plane + (size_t)y * pw + x0);
+        const uint32_t v = *reinterpret_cast<const uint32_t *>(plane + (__umul24(y, pw) + (uint32_t)x0));
         return make_int4((int)(v & 255u), (int)((v >> 8) & 255u), (int)((v >> 16) & 255u), (int)(v >> 24));
     }
     if (cw <= 2) {
@@ -512,7 +514,7 @@ __device__ __forceinline__ int4 upsample4_fast(const uint8_t *plane, int pw, int
         r1 = r1 < 0 ? 0 : (r1 > ch - 1 ? ch - 1 : r1);
     }
     int c[4];
-    chroma4(plane + (size_t)r0 * pw, plane + (size_t)r1 * pw, i0, cw, vfac == 2, c);
+    chroma4(plane + __umul24(r0, pw), plane + __umul24(r1, pw), i0, vfac == 2, c);      // rows and widths are far below 2^24
     const bool first = i0 == 0, last0 = i0 == cw - 1, last1 = i0 + 1 >= cw - 1;
     if (vfac == 2)
         return make_int4(first ? (c[1] * 4 + 8) >> 4 : (c[1] * 3 + c[0] + 8) >> 4, last0 ? (c[1] * 4 + 7) >> 4 : (c[1] * 3 + c[2] + 7) >> 4,
@@ -523,45 +525,51 @@ __device__ __forceinline__ int4 upsample4_fast(const uint8_t *plane, int pw, int
 
 // jdcolor.c ycc_rgb_convert for one pixel, as R | G << 8 | B << 16
 __device__ __forceinline__ uint32_t ycc_to_rgb24(int y, int cb, int cr) {
-    const int xb = cb - 128, xr = cr - 128;
-    const int r = y + ((91881 * xr + 32768) >> 16);
-    const int g = y + ((-22554 * xb + 32768 + (-46802) * xr) >> 16);
-    const int b = y + ((116130 * xb + 32768) >> 16);
+    const int xb = cb - 128, xr = cr - 128;                   // 24-bit multiplies (full rate; 32-bit ones take four times as long)
+    const int r = y + ((__mul24(91881, xr) + 32768) >> 16);
+    const int g = y + ((__mul24(-22554, xb) + 32768 + __mul24(-46802, xr)) >> 16);
+    const int b = y + ((__mul24(116130, xb) + 32768) >> 16);
     return (uint32_t)min(max(r, 0), 255) | ((uint32_t)min(max(g, 0), 255) << 8) | ((uint32_t)min(max(b, 0), 255) << 16);
 }
 
 __global__ __launch_bounds__(256) void ke_jpeg_colour(const KeJpegDev *__restrict__ imgs, const uint8_t *__restrict__ planes,
                                                       uint8_t *__restrict__ out) {
-    const KeJpegDev &d = imgs[blockIdx.y];
+    // A workgroup takes 256 columns of kColourRows rows, four rows at a time (65 536 images of 512 x 512 are 16.7 M groups of
+    // four rows: one workgroup each was bound by the rate workgroups can be started at); the turns are independent, so their
+    // loads overlap.
+    const KeJpegDev &d = imgs[blockIdx.z];
     const KeJpegInfo &in = d.info;
-    const int quads_per_row = (in.width + 3) >> 2;
-    const int q = blockIdx.x * 256 + threadIdx.x;
-    if (q >= quads_per_row * in.height) return;
-    const int y = q / quads_per_row, x0 = (q - y * quads_per_row) * 4;
-    const uint8_t *Y = planes + d.plane_off[0];
+    const int r = threadIdx.x >> 6, q = threadIdx.x & 63;
+    const int x0 = blockIdx.x * 256 + q * 4;
+    if (x0 >= in.width) return;
+    const uint8_t *Y = planes + d.plane_off[0], *Cb = planes + d.plane_off[1], *Cr = planes + d.plane_off[2];
     uint8_t *dst = out + d.out_off;
-    // four luma samples in one load (plane rows are multiples of 8 bytes, x0 of 4), twelve output bytes in three stores
-    const uint32_t y4 = *reinterpret_cast<const uint32_t *>(Y + (size_t)y * in.plane_w[0] + x0);
     const int npx = min(4, in.width - x0);
-    if (in.ncomp == 1) {
-        uint8_t *o = dst + (size_t)y * in.width + x0;
-        if (npx == 4) __builtin_memcpy(o, &y4, 4);
-        else for (int k = 0; k < npx; ++k) o[k] = (uint8_t)(y4 >> (8 * k));
-        return;
-    }
-    const uint8_t *Cb = planes + d.plane_off[1], *Cr = planes + d.plane_off[2];
-    const int4 cb = upsample4_fast(Cb, in.plane_w[1], in.comp_w[1], in.comp_h[1], in.hmax, in.vmax, x0, y);
-    const int4 cr = upsample4_fast(Cr, in.plane_w[2], in.comp_w[2], in.comp_h[2], in.hmax, in.vmax, x0, y);
-    const uint32_t p0 = ycc_to_rgb24((int)(y4 & 0xFF), cb.x, cr.x), p1 = ycc_to_rgb24((int)((y4 >> 8) & 0xFF), cb.y, cr.y);
-    const uint32_t p2 = ycc_to_rgb24((int)((y4 >> 16) & 0xFF), cb.z, cr.z), p3 = ycc_to_rgb24((int)(y4 >> 24), cb.w, cr.w);
-    const uint32_t w0 = p0 | (p1 << 24), w1 = (p1 >> 8) | (p2 << 16), w2 = (p2 >> 16) | (p3 << 8);
-    uint8_t *o = dst + ((size_t)y * in.width + x0) * 3;
-    if (npx == 4) {
-        __builtin_memcpy(o, &w0, 4);                                      // any alignment (rows of 3*width bytes)
-        __builtin_memcpy(o + 4, &w1, 4);
-        __builtin_memcpy(o + 8, &w2, 4);
-    } else {
-        for (int k = 0; k < 3 * npx; ++k) o[k] = (uint8_t)((k < 4 ? w0 : k < 8 ? w1 : w2) >> (8 * (k & 3)));
+#pragma unroll 4
+    for (int turn = 0; turn < kColourRows / 4; ++turn) {
+        const int y = blockIdx.y * kColourRows + turn * 4 + r;
+        if (y >= in.height) break;
+        // four luma samples in one load (plane rows are multiples of 8 bytes, x0 of 4)
+        const uint32_t y4 = *reinterpret_cast<const uint32_t *>(Y + (__umul24(y, in.plane_w[0]) + (uint32_t)x0));
+        if (in.ncomp == 1) {
+            uint8_t *o = dst + (size_t)y * in.width + x0;
+            if (npx == 4) __builtin_memcpy(o, &y4, 4);
+            else for (int k = 0; k < npx; ++k) o[k] = (uint8_t)(y4 >> (8 * k));
+            continue;
+        }
+        const int4 cb = upsample4_fast(Cb, in.plane_w[1], in.comp_w[1], in.comp_h[1], in.hmax, in.vmax, x0, y);
+        const int4 cr = upsample4_fast(Cr, in.plane_w[2], in.comp_w[2], in.comp_h[2], in.hmax, in.vmax, x0, y);
+        const uint32_t p0 = ycc_to_rgb24((int)(y4 & 0xFF), cb.x, cr.x), p1 = ycc_to_rgb24((int)((y4 >> 8) & 0xFF), cb.y, cr.y);
+        const uint32_t p2 = ycc_to_rgb24((int)((y4 >> 16) & 0xFF), cb.z, cr.z), p3 = ycc_to_rgb24((int)(y4 >> 24), cb.w, cr.w);
+        const uint32_t w0 = p0 | (p1 << 24), w1 = (p1 >> 8) | (p2 << 16), w2 = (p2 >> 16) | (p3 << 8);
+        uint8_t *o = dst + (size_t)(__umul24(y, in.width) + (uint32_t)x0) * 3;
+        if (npx == 4) {
+            typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+            const u32x3 w{w0, w1, w2};
+            __builtin_memcpy(o, &w, 12);                                  // one 12-byte store, any alignment (rows of 3*width bytes)
+        } else {
+            for (int k = 0; k < 3 * npx; ++k) o[k] = (uint8_t)((k < 4 ? w0 : k < 8 ? w1 : w2) >> (8 * (k & 3)));
+        }
     }
 }
 
@@ -740,7 +748,7 @@ KE_API int ke_jpeg_decode(ke_ctx *ctx, const uint8_t *files, const uint64_t *off
     while (first < devs.size()) {
         uint64_t coef_units = 0, plane_bytes = 0;
         size_t last = first;
-        int max_blocks = 0, max_quads = 0;
+        int max_blocks = 0, max_w = 0, max_h = 0;
         int64_t progressive_here = 0;
         while (last < devs.size() && last - first < 65535) {     // the image index is blockIdx.y of the IDCT and colour kernels
             KeJpegDev &d = devs[last];
@@ -767,7 +775,8 @@ KE_API int ke_jpeg_decode(ke_ctx *ctx, const uint8_t *files, const uint64_t *off
             d.blocks_total = (int32_t)blocks;
             coef_units += blocks * 64;
             max_blocks = std::max(max_blocks, (int)blocks);
-            max_quads = std::max(max_quads, ((d.info.width + 3) >> 2) * d.info.height);
+            max_w = std::max(max_w, d.info.width);
+            max_h = std::max(max_h, d.info.height);
             ++last;
         }
         const int64_t m = (int64_t)(last - first);
@@ -815,7 +824,7 @@ KE_API int ke_jpeg_decode(ke_ctx *ctx, const uint8_t *files, const uint64_t *off
         }
         hipLaunchKernelGGL(ke_jpeg_idct, dim3((unsigned)((max_blocks + 255) / 256), (unsigned)m), dim3(256), 0, ctx->stream,
                            (const KeJpegDev *)d_imgs, (const int16_t *)d_coef, (uint8_t *)d_planes);
-        hipLaunchKernelGGL(ke_jpeg_colour, dim3((unsigned)((max_quads + 255) / 256), (unsigned)m), dim3(256), 0, ctx->stream,
+        hipLaunchKernelGGL(ke_jpeg_colour, dim3((unsigned)((max_w + 255) / 256), (unsigned)((max_h + kColourRows - 1) / kColourRows), (unsigned)m), dim3(256), 0, ctx->stream,
                            (const KeJpegDev *)d_imgs, (const uint8_t *)d_planes, pixels_out);
         KE_HIP(ctx, hipGetLastError());
         st.resize((size_t)m);

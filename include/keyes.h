@@ -159,8 +159,9 @@ int ke_stage_wait(ke_ctx *ctx, int32_t slot);
  * 4:4:4 / 4:2:2 / 4:2:0 ("RGB").  The pixels are libjpeg's as Pillow drives it (islow IDCT, fancy upsampling, jdcolor's
  * fixed-point YCbCr -> RGB), bit for bit; everything else (arithmetic coding, 12-bit, CMYK/YCCK, RGB-coded, other samplings,
  * sequential files in several scans, progressive files whose first AC coefficients are not refined to the last bit -- libjpeg
- * smooths those) is reported KE_JPEG_UNSUPPORTED per file and stays with Pillow, truncated or damaged entropy data
- * KE_JPEG_CORRUPT (Pillow raises on those).  EXIF orientation is not applied -- nor does Image.open.
+ * smooths those -- and files with a block whose IDCT leaves 16 bits, which no encoder writes and on which libjpeg's C and SIMD
+ * routines differ: csrc/ke_jpeg_core.h, ke_idct_islow) is reported KE_JPEG_UNSUPPORTED per file and stays with Pillow,
+ * truncated or damaged entropy data KE_JPEG_CORRUPT (Pillow raises on those).  EXIF orientation is not applied -- nor does Image.open.
  *
  * ke_jpeg_probe  : host only.  files + offsets[i] .. + sizes[i] = file i.  widths/heights/channels (1 or 3)/status per file,
  *                  so that the caller can lay out the pixel buffer.

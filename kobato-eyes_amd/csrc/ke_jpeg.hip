@@ -443,8 +443,12 @@ __global__ __launch_bounds__(64) void ke_jpeg_entropy_prog(const KeJpegDev *__re
     status[i] = rc;
 }
 
+struct IdctMul24 {                  // see ke_idct_islow: multiplicands below 2^16 wherever the results are used
+    static __device__ __forceinline__ int mul(int a, int k) { return __mul24(a, k); }
+};
+
 __global__ __launch_bounds__(256) void ke_jpeg_idct(const KeJpegDev *__restrict__ imgs, const int16_t *__restrict__ coefs,
-                                                    uint8_t *__restrict__ planes) {
+                                                    uint8_t *__restrict__ planes, int32_t *status) {
     const KeJpegDev &d = imgs[blockIdx.y];
     const int b = blockIdx.x * 256 + threadIdx.x;
     if (b >= d.blocks_total) return;
@@ -467,7 +471,9 @@ __global__ __launch_bounds__(256) void ke_jpeg_idct(const KeJpegDev *__restrict_
         }
     }
     uint8_t rows[64];
-    ke_idct_islow(blk, rows, 8);
+    // a block outside the bound of ke_idct_islow: the file goes back to the caller (unless the entropy decoder already said
+    // worse of it; every thread that finds one stores the same value)
+    if (!ke_idct_islow<int[64], IdctMul24>(blk, rows, 8) && status[blockIdx.y] == KE_JPEG_OK) status[blockIdx.y] = KE_JPEG_UNSUPPORTED;
     uint8_t *dst = planes + d.plane_off[c] + (size_t)(brow * 8) * in.plane_w[c] + bcol * 8;
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
@@ -524,11 +530,19 @@ __device__ __forceinline__ int4 upsample4_fast(const uint8_t *plane, int pw, int
 }
 
 // jdcolor.c ycc_rgb_convert for one pixel, as R | G << 8 | B << 16
+// a * k + c on the 24-bit multiplier (full rate; a 32-bit multiply takes four times as long).  Spelled out because the compiler
+// rewrites __mul24 on operands it can bound into a plain multiply and then picks the 32-bit instruction for it.
+__device__ __forceinline__ int mad24(int a, int k, int c) {
+    int r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(k), "v"(c));
+    return r;
+}
+
 __device__ __forceinline__ uint32_t ycc_to_rgb24(int y, int cb, int cr) {
-    const int xb = cb - 128, xr = cr - 128;                   // 24-bit multiplies (full rate; 32-bit ones take four times as long)
-    const int r = y + ((__mul24(91881, xr) + 32768) >> 16);
-    const int g = y + ((__mul24(-22554, xb) + 32768 + __mul24(-46802, xr)) >> 16);
-    const int b = y + ((__mul24(116130, xb) + 32768) >> 16);
+    // the chroma offset of 128 folded into the rounding constant: k * (c - 128) + 32768 = k * c + (32768 - 128 k) exactly
+    const int r = y + (mad24(cr, 91881, 32768 - 128 * 91881) >> 16);
+    const int g = y + (mad24(cr, -46802, mad24(cb, -22554, 32768 + 128 * 22554 + 128 * 46802)) >> 16);
+    const int b = y + (mad24(cb, 116130, 32768 - 128 * 116130) >> 16);
     return (uint32_t)min(max(r, 0), 255) | ((uint32_t)min(max(g, 0), 255) << 8) | ((uint32_t)min(max(b, 0), 255) << 16);
 }
 
@@ -824,7 +838,7 @@ KE_API int ke_jpeg_decode(ke_ctx *ctx, const uint8_t *files, const uint64_t *off
                                (int32_t *)d_status, lanes);
         }
         hipLaunchKernelGGL(ke_jpeg_idct, dim3((unsigned)((max_blocks + 255) / 256), (unsigned)m), dim3(256), 0, ctx->stream,
-                           (const KeJpegDev *)d_imgs, (const int16_t *)d_coef, (uint8_t *)d_planes);
+                           (const KeJpegDev *)d_imgs, (const int16_t *)d_coef, (uint8_t *)d_planes, (int32_t *)d_status);
         hipLaunchKernelGGL(ke_jpeg_colour, dim3((unsigned)((max_w + 255) / 256), (unsigned)((max_h + kColourRows - 1) / kColourRows), (unsigned)m), dim3(256), 0, ctx->stream,
                            (const KeJpegDev *)d_imgs, (const uint8_t *)d_planes, pixels_out);
         KE_HIP(ctx, hipGetLastError());

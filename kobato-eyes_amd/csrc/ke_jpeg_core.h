@@ -18,8 +18,10 @@
 
 #ifdef __HIPCC__
 #define KE_HD __host__ __device__ __forceinline__
+#define KE_HD_STATIC static __host__ __device__ __forceinline__
 #else
 #define KE_HD static inline
+#define KE_HD_STATIC static inline
 #endif
 
 enum { KE_JPEG_OK = 0, KE_JPEG_UNSUPPORTED = 1, KE_JPEG_CORRUPT = 2 };
@@ -296,8 +298,31 @@ KE_HD uint8_t ke_range_limit(int x) {      // libjpeg's range_limit table at off
     return (uint8_t)(x < 0 ? 0 : (x > 255 ? 255 : x));
 }
 
-template <typename Blk>
-KE_HD void ke_idct_islow(Blk &blk, uint8_t *out, int stride) {
+// jpeg_idct_islow on one dequantised block.  Returns whether the block is NARROW: every input of the column pass and every
+// input of the row pass inside (-2^14, 2^14).  The function follows jidctint.c's C arithmetic (32-bit ints); the library
+// Pillow links (libjpeg-turbo with its SIMD routines) dequantises and adds sample pairs in 16 bits and saturates the column
+// pass's results to 16 bits, and the two agree exactly as long as nothing leaves 16 bits -- which the bound guarantees (pairs of
+// values below 2^14 add within 16 bits).  Files an encoder wrote stay far inside it (a flat white block is 1016 in, 4064
+// between the passes); a file with a block outside is one whose pixels depend on the build of libjpeg, and the decoders hand
+// it back as KE_JPEG_UNSUPPORTED instead of choosing.  (Seen with quantisation tables overwritten by large steps: the C form
+// and Pillow's differ there, tests/test_gpu_jpeg.py::test_files_with_blocks_beyond_the_16_bit_bound_are_handed_back.)
+//
+// The products go through a policy: under the bound every multiplicand is below 2^16, so the device passes one that uses the
+// 24-bit multiplier (a quarter of the 32-bit one's cost on CDNA; ke_jpeg.hip) -- for a block that is not narrow the results
+// are not used.
+constexpr int kKeIdctBoundBits = 14;
+
+struct KeMulPlain {
+    KE_HD_STATIC int mul(int a, int k) { return a * k; }
+};
+
+template <typename Blk, typename M = KeMulPlain>
+KE_HD bool ke_idct_islow(Blk &blk, uint8_t *out, int stride) {
+    int hi = 0, lo = 0;                               // extremes over both passes' inputs (one max3 / min3 per pair on the GPU)
+    for (int k = 0; k < 64; ++k) {
+        hi = blk[k] > hi ? blk[k] : hi;
+        lo = blk[k] < lo ? blk[k] : lo;
+    }
     // pass 1: columns, results scaled up by 2 bits, in place
     for (int c = 0; c < 8; ++c) {
         const int i0 = blk[c], i1 = blk[8 + c], i2 = blk[16 + c], i3 = blk[24 + c], i4 = blk[32 + c], i5 = blk[40 + c],
@@ -308,18 +333,20 @@ KE_HD void ke_idct_islow(Blk &blk, uint8_t *out, int stride) {
             continue;
         }
         int z2 = i2, z3 = i6;
-        int z1 = (z2 + z3) * KE_FIX_0_541196100;
-        int tmp2 = z1 + z3 * (-KE_FIX_1_847759065);
-        int tmp3 = z1 + z2 * KE_FIX_0_765366865;
+        int z1 = M::mul(z2 + z3, KE_FIX_0_541196100);
+        int tmp2 = z1 + M::mul(z3, -KE_FIX_1_847759065);
+        int tmp3 = z1 + M::mul(z2, KE_FIX_0_765366865);
         z2 = i0; z3 = i4;
         int tmp0 = (z2 + z3) * 8192, tmp1 = (z2 - z3) * 8192;   // << CONST_BITS
         const int tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
         tmp0 = i7; tmp1 = i5; tmp2 = i3; tmp3 = i1;
         z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2;
         int z4 = tmp1 + tmp3;
-        const int z5 = (z3 + z4) * KE_FIX_1_175875602;
-        tmp0 *= KE_FIX_0_298631336; tmp1 *= KE_FIX_2_053119869; tmp2 *= KE_FIX_3_072711026; tmp3 *= KE_FIX_1_501321110;
-        z1 *= -KE_FIX_0_899976223; z2 *= -KE_FIX_2_562915447; z3 *= -KE_FIX_1_961570560; z4 *= -KE_FIX_0_390180644;
+        const int z5 = M::mul(z3 + z4, KE_FIX_1_175875602);
+        tmp0 = M::mul(tmp0, KE_FIX_0_298631336); tmp1 = M::mul(tmp1, KE_FIX_2_053119869);
+        tmp2 = M::mul(tmp2, KE_FIX_3_072711026); tmp3 = M::mul(tmp3, KE_FIX_1_501321110);
+        z1 = M::mul(z1, -KE_FIX_0_899976223); z2 = M::mul(z2, -KE_FIX_2_562915447);
+        z3 = M::mul(z3, -KE_FIX_1_961570560); z4 = M::mul(z4, -KE_FIX_0_390180644);
         z3 += z5; z4 += z5;
         tmp0 += z1 + z3; tmp1 += z2 + z4; tmp2 += z2 + z3; tmp3 += z1 + z4;
         blk[c] = ke_descale(tmp10 + tmp3, 11);       // CONST_BITS - PASS1_BITS
@@ -330,6 +357,10 @@ KE_HD void ke_idct_islow(Blk &blk, uint8_t *out, int stride) {
         blk[40 + c] = ke_descale(tmp12 - tmp1, 11);
         blk[24 + c] = ke_descale(tmp13 + tmp0, 11);
         blk[32 + c] = ke_descale(tmp13 - tmp0, 11);
+    }
+    for (int k = 0; k < 64; ++k) {
+        hi = blk[k] > hi ? blk[k] : hi;
+        lo = blk[k] < lo ? blk[k] : lo;
     }
     // pass 2: rows, descale by CONST_BITS + PASS1_BITS + 3, level shift and clamp
     for (int r = 0; r < 8; ++r) {
@@ -342,17 +373,19 @@ KE_HD void ke_idct_islow(Blk &blk, uint8_t *out, int stride) {
             continue;
         }
         int z2 = w2, z3 = w6;
-        int z1 = (z2 + z3) * KE_FIX_0_541196100;
-        int tmp2 = z1 + z3 * (-KE_FIX_1_847759065);
-        int tmp3 = z1 + z2 * KE_FIX_0_765366865;
+        int z1 = M::mul(z2 + z3, KE_FIX_0_541196100);
+        int tmp2 = z1 + M::mul(z3, -KE_FIX_1_847759065);
+        int tmp3 = z1 + M::mul(z2, KE_FIX_0_765366865);
         int tmp0 = (w0 + w4) * 8192, tmp1 = (w0 - w4) * 8192;
         const int tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
         tmp0 = w7; tmp1 = w5; tmp2 = w3; tmp3 = w1;
         z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2;
         int z4 = tmp1 + tmp3;
-        const int z5 = (z3 + z4) * KE_FIX_1_175875602;
-        tmp0 *= KE_FIX_0_298631336; tmp1 *= KE_FIX_2_053119869; tmp2 *= KE_FIX_3_072711026; tmp3 *= KE_FIX_1_501321110;
-        z1 *= -KE_FIX_0_899976223; z2 *= -KE_FIX_2_562915447; z3 *= -KE_FIX_1_961570560; z4 *= -KE_FIX_0_390180644;
+        const int z5 = M::mul(z3 + z4, KE_FIX_1_175875602);
+        tmp0 = M::mul(tmp0, KE_FIX_0_298631336); tmp1 = M::mul(tmp1, KE_FIX_2_053119869);
+        tmp2 = M::mul(tmp2, KE_FIX_3_072711026); tmp3 = M::mul(tmp3, KE_FIX_1_501321110);
+        z1 = M::mul(z1, -KE_FIX_0_899976223); z2 = M::mul(z2, -KE_FIX_2_562915447);
+        z3 = M::mul(z3, -KE_FIX_1_961570560); z4 = M::mul(z4, -KE_FIX_0_390180644);
         z3 += z5; z4 += z5;
         tmp0 += z1 + z3; tmp1 += z2 + z4; tmp2 += z2 + z3; tmp3 += z1 + z4;
         o[0] = ke_range_limit(ke_descale(tmp10 + tmp3, 18));
@@ -364,6 +397,7 @@ KE_HD void ke_idct_islow(Blk &blk, uint8_t *out, int stride) {
         o[3] = ke_range_limit(ke_descale(tmp13 + tmp0, 18));
         o[4] = ke_range_limit(ke_descale(tmp13 - tmp0, 18));
     }
+    return hi < (1 << kKeIdctBoundBits) && lo > -(1 << kKeIdctBoundBits);
 }
 
 // ---- upsampling (jdsample.c) for one output sample (x, y) of a chroma plane with factors (hs, vs) relative to luma

@@ -103,6 +103,7 @@ int ko_jpeg_decode(const uint8_t *file, uint64_t size, uint8_t *out) {
     std::vector<KeJpegScan> scans;
     ke_parse_jpeg(file, (size_t)size, tables, info, true, &scans);
     if (info.status != KE_JPEG_OK) return info.status;
+    bool narrow = true;                 // every block inside ke_idct_islow's bound (ke_jpeg_core.h); the file is handed back otherwise
     std::vector<uint8_t> planes[3];
     for (int c = 0; c < info.ncomp; ++c) planes[c].assign((size_t)info.plane_w[c] * info.plane_h[c], 0);
     if (info.progressive) {
@@ -116,7 +117,7 @@ int ko_jpeg_decode(const uint8_t *file, uint64_t size, uint8_t *out) {
                     int32_t blk[64];
                     const int16_t *src = coef[c].data() + ((size_t)brow * bpr + bcol) * 64;
                     for (int k = 0; k < 64; ++k) blk[k] = (int32_t)src[k] * (int32_t)info.quant[c][k];
-                    ke_idct_islow(blk, planes[c].data() + (size_t)brow * 8 * info.plane_w[c] + bcol * 8, info.plane_w[c]);
+                    narrow &= ke_idct_islow(blk, planes[c].data() + (size_t)brow * 8 * info.plane_w[c] + bcol * 8, info.plane_w[c]);
                 }
         }
     }
@@ -139,11 +140,12 @@ int ko_jpeg_decode(const uint8_t *file, uint64_t size, uint8_t *out) {
                                             pred[c], blk) != KE_JPEG_OK)
                             return KE_JPEG_CORRUPT;
                         uint8_t *dst = planes[c].data() + (size_t)((my * info.vs[c] + by) * 8) * info.plane_w[c] + (mx * info.hs[c] + bx) * 8;
-                        ke_idct_islow(blk, dst, info.plane_w[c]);
+                        narrow &= ke_idct_islow(blk, dst, info.plane_w[c]);
                     }
             --restart_left;
         }
     if (!info.progressive && bits.overrun > 8) return KE_JPEG_CORRUPT;          // ran past the data (a few zero bytes of look-ahead are normal)
+    if (!narrow) return KE_JPEG_UNSUPPORTED;
     for (int y = 0; y < info.height; ++y)
         for (int x = 0; x < info.width; ++x) {
             const int Y = planes[0][(size_t)y * info.plane_w[0] + x];

@@ -61,6 +61,22 @@ def supported(full: bool = False):
                 yield f"restart_{list(kw)[0]}_{list(kw.values())[0]}_s{sub}_p{int(prog)}", data, np.asarray(Image.open(io.BytesIO(data)))
 
 
+def with_quantisation_tables(data: bytes, value: int) -> bytes:
+    """The file with every entry of its (8-bit) quantisation tables set to `value`."""
+    d = bytearray(data)
+    pos = 2
+    while d[pos + 1] != 0xDA:
+        length = int.from_bytes(d[pos + 2:pos + 4], "big")
+        if d[pos + 1] == 0xDB:
+            q = pos + 4
+            while q < pos + 2 + length:
+                assert d[q] >> 4 == 0
+                d[q + 1:q + 65] = bytes([value]) * 64
+                q += 65
+        pos += 2 + length
+    return bytes(d)
+
+
 def refused():
     """Yields (name, file bytes, expected status): 1 = left to Pillow, 2 = damaged."""
     rng = np.random.default_rng(2)

@@ -217,7 +217,8 @@ def test_decode_batches_beyond_the_byte_limits_are_halved(ctx, tmp_path):
 def test_jpeg_damage_is_survived(ctx):
     """Hundreds of damaged variants of sequential and progressive files in one call (flipped bits and random runs inside the
     entropy-coded data, tables and scan headers overwritten, truncations): the kernels come back with a status for each and
-    the context decodes a clean batch afterwards.  (What libjpeg makes of damaged data is its own; such files go to Pillow.)"""
+    the context decodes a clean batch afterwards; the damaged files it does take (a flipped bit often leaves a valid stream) carry
+    Pillow's pixels."""
     import io
 
     from PIL import Image
@@ -246,6 +247,19 @@ def test_jpeg_damage_is_survived(ctx):
     out, status = ctx.jpeg_decode(blobs)
     assert set(np.unique(status).tolist()) <= {0, 1, 2}
     assert all((a is None) == (s != 0) for a, s in zip(out, status))
+    same = 0
+    for blob, a in zip(blobs, out):                  # a damaged file the decoder takes has the pixels Pillow makes of it
+        if a is None:
+            continue
+        try:
+            im = Image.open(io.BytesIO(blob))
+            im.load()
+        except Exception:                            # Pillow gives up on some the decoder reads to the end
+            continue
+        ref = np.asarray(im)
+        assert ref.shape == a.shape and np.array_equal(ref, a)
+        same += 1
+    assert same > 100
     clean, st = ctx.jpeg_decode([g[1] for g in good])
     assert (st == 0).all() and all(np.array_equal(a, g[2]) for a, g in zip(clean, good))
 
@@ -258,3 +272,32 @@ def test_random_files_in_one_batch(ctx):
         for k, (name, _, ref) in enumerate(cases):
             assert status[k] == 0, name
             assert out[k].shape == ref.shape and np.array_equal(out[k], ref), name
+
+
+def test_files_with_blocks_beyond_the_16_bit_bound_are_handed_back(ctx):
+    """ke_idct_islow's bound (csrc/ke_jpeg_core.h): files whose quantisation tables are overwritten with larger and larger
+    steps.  Below the bound the pixels are Pillow's; beyond it libjpeg's C arithmetic and Pillow's SIMD build differ, and the
+    decoder answers KE_JPEG_UNSUPPORTED (the CPU restatement the same, file by file) -- never other pixels than Pillow's."""
+    import io
+
+    from PIL import Image
+
+    import test_jpeg_cpu as T
+
+    L = T._lib()
+    good = [c for c in J.supported() if c[2].shape[0] >= 64 and c[2].shape[1] >= 64 and "q100" not in c[0]][:12]
+    good += [c for c in J.supported() if "q100" in c[0] and c[2].shape[0] >= 64][:4]
+    assert any("progressive" in c[0] for c in good) and any("gray" in c[0] for c in good)
+    steps = (255, 64, 33, 16, 8, 4, 2, 1)
+    blobs = [J.with_quantisation_tables(data, v) for _, data, _ in good for v in steps]
+    out, status = ctx.jpeg_decode(blobs)
+    taken = {v: 0 for v in steps}
+    for k, blob in enumerate(blobs):
+        st, ref = T._decode(L, blob)
+        assert status[k] == st and st in (0, 1), k
+        if st == 0:
+            assert np.array_equal(out[k], ref) and np.array_equal(out[k], np.asarray(Image.open(io.BytesIO(blob)))), k
+            taken[steps[k % len(steps)]] += 1
+    assert taken[255] == 0 and taken[64] == 0 and taken[1] == len(good) and 0 < taken[16] < len(good)
+    clean, st = ctx.jpeg_decode([g[1] for g in good])                    # the status is per file and per call
+    assert (st == 0).all() and all(np.array_equal(a, g[2]) for a, g in zip(clean, good))

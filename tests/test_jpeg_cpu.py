@@ -4,9 +4,11 @@ refusal for the rest.  The GPU kernels are then held against Pillow directly (te
 from __future__ import annotations
 
 import ctypes as C
+import io
 import os
 
 import numpy as np
+from PIL import Image
 
 import _jpeg_cases as J
 from oracle import oracle as O
@@ -41,6 +43,23 @@ def test_decoder_arithmetic_matches_pillow():
         assert out.shape == ref.shape and np.array_equal(out, ref), name
         n += 1
     assert n > 150
+
+
+def test_blocks_beyond_the_idct_bound_hand_the_file_back():
+    """ke_idct_islow's bound: with the quantisation tables overwritten by larger and larger steps the decode is Pillow's until
+    a block leaves 16 bits, and KE_JPEG_UNSUPPORTED from there (libjpeg's C form and Pillow's SIMD build differ beyond)."""
+    L = _lib()
+    good = [c for c in J.supported() if c[2].shape[0] >= 64 and "gray" not in c[0]][:6] + [c for c in J.supported() if "q100" in c[0] and c[2].shape[0] >= 64][:2]
+    taken = {}
+    for _, data, _ in good:
+        for v in (255, 16, 4, 1):
+            blob = J.with_quantisation_tables(data, v)
+            st, out = _decode(L, blob)
+            assert st in (0, 1)
+            if st == 0:
+                assert np.array_equal(out, np.asarray(Image.open(io.BytesIO(blob))))
+            taken[v] = taken.get(v, 0) + (st == 0)
+    assert taken[255] == 0 and taken[1] == len(good) and 0 < taken[16] < len(good)
 
 
 def test_files_outside_the_decoder_are_refused():

@@ -169,6 +169,22 @@ def _addr(buf) -> Optional[int]:
     raise TypeError(f"unsupported buffer type {type(buf)!r}")
 
 
+class FilesAhead:
+    """The files of a batch in one of a context's read-ahead buffers (Context.read_files_ahead): file i is
+    ``flat[offsets[i]:offsets[i] + sizes[i]]`` (size 0 = unreadable).  ``release()`` hands the buffer back."""
+
+    def __init__(self, ctx, slot: int, flat, offsets, sizes) -> None:
+        self._ctx, self._slot, self.flat, self.offsets, self.sizes = ctx, slot, flat, offsets, sizes
+
+    def __len__(self) -> int:
+        return len(self.sizes)
+
+    def release(self) -> None:
+        if self._ctx is not None:
+            self._ctx._ahead[self._slot][2] = False
+            self._ctx, self.flat = None, None
+
+
 class Context:
     """One ke_ctx: a device, a stream, scratch buffers.  Not re-entrant."""
 
@@ -182,6 +198,8 @@ class Context:
         self._lock = threading.RLock()
         self._pack_ptr, self._pack_cap = 0, 0
         self._decoded_ptr, self._decoded_cap = 0, 0
+        self._ahead = [[0, 0, False], [0, 0, False]]         # read-ahead buffers: [page-locked ptr, capacity, taken]
+        self._ahead_lock = threading.Lock()
         # a decode call beyond these is split in halves: compressed bytes in page-locked memory, decoded pixels on the device
         self.pack_limit = int(os.environ.get("KE_PACK_LIMIT_BYTES", str(8 << 30)))
         self.decode_limit = int(os.environ.get("KE_DECODE_LIMIT_BYTES", str(48 << 30)))
@@ -195,6 +213,10 @@ class Context:
             if getattr(self, "_decoded_ptr", 0):
                 self._lib.ke_free(self._h, self._decoded_ptr)
                 self._decoded_ptr, self._decoded_cap = 0, 0
+            for buf in getattr(self, "_ahead", []):
+                if buf[0]:
+                    self._lib.ke_host_free(self._h, buf[0])
+                    buf[0], buf[1] = 0, 0
             self._lib.ke_destroy(self._h)
             self._h = None
 
@@ -409,6 +431,48 @@ class Context:
         flat = np.ctypeslib.as_array((C.c_uint8 * total).from_address(self._pack_ptr))
         return flat, offsets, sizes
 
+    def read_files_ahead(self, paths):
+        """Read files into one of the context's two page-locked read-ahead buffers -- from any thread, while another call of the
+        context is decoding the previous batch on the GPU (nothing here touches the stream or the context's lock).  Returns a
+        FilesAhead to pass to ``jpeg_hash(..., ahead=(it, lo, hi))`` and to ``release()`` afterwards, or None when both buffers
+        are taken or the files exceed ``pack_limit`` (the caller then lets the decode call read them itself)."""
+        paths = list(paths)
+        n = len(paths)
+        if n == 0:
+            return None
+        with self._ahead_lock:
+            slot = next((k for k, buf in enumerate(self._ahead) if not buf[2]), None)
+            if slot is None:
+                return None
+            self._ahead[slot][2] = True
+        buf = self._ahead[slot]
+        try:
+            names = (C.c_char_p * n)(*[os.fsencode(p) for p in paths])
+            offsets, sizes = np.zeros(n, np.uint64), np.zeros(n, np.uint64)
+            needed = C.c_uint64(0)
+            rc = self._lib.ke_host_read_files(names, n, buf[0], buf[1], _addr(offsets), _addr(sizes), C.byref(needed))
+            if rc == -4:                                   # KE_ENOMEM: the buffer is too small for this batch
+                if int(needed.value) > self.pack_limit and n > 1:
+                    raise _BatchTooLarge
+                if buf[0]:
+                    self._check(self._lib.ke_host_free(self._h, buf[0]), "ke_host_free")
+                    buf[0], buf[1] = 0, 0
+                cap = max(int(needed.value) + int(needed.value) // 4, 1 << 24)
+                p = C.c_void_p()
+                self._check(self._lib.ke_host_alloc(self._h, cap, C.byref(p)), "ke_host_alloc")
+                buf[0], buf[1] = int(p.value), cap
+                rc = self._lib.ke_host_read_files(names, n, buf[0], buf[1], _addr(offsets), _addr(sizes), C.byref(needed))
+            if rc != KE_OK:
+                raise ValueError("ke_host_read_files: bad arguments")
+        except _BatchTooLarge:
+            buf[2] = False
+            return None
+        except BaseException:
+            buf[2] = False
+            raise
+        flat = np.ctypeslib.as_array((C.c_uint8 * int(needed.value)).from_address(buf[0]))
+        return FilesAhead(self, slot, flat, offsets, sizes)
+
     def _pack_blobs_pinned(self, blobs):
         """The files back to back in the context's page-locked buffer (grown on demand, reused from call to call): the copy
         to the device then runs at link speed.  Call with the lock held; the buffer is busy until the decode has returned."""
@@ -449,14 +513,18 @@ class Context:
     def png_hash(self, blobs, *, want_dhash=True):
         return self.jpeg_hash(blobs, want_dhash=want_dhash, kind="png")
 
-    def _jpeg_to_device(self, blobs, kind: str = "jpeg", *, paths=None):
+    def _jpeg_to_device(self, blobs, kind: str = "jpeg", *, paths=None, ahead=None):
         """Decode what the GPU decoder takes into the context's decode buffer (device memory, grown on demand and kept:
         allocating tens of GB per call costs up to a second): (device ptr or 0, byte offsets, widths, heights, channels,
         status).  Call with the lock held and keep it until the pixels have been used."""
-        n = len(blobs) if paths is None else len(paths)
+        n = ahead[2] - ahead[1] if ahead is not None else len(blobs) if paths is None else len(paths)
         w, h, c, st = (np.zeros(n, np.int32) for _ in range(4))
         with self._lock:
-            flat, offsets, sizes = self._pack_blobs_pinned(blobs) if paths is None else self._read_files_pinned(paths)
+            if ahead is not None:                        # files lo..hi of a batch some thread has read already
+                held, lo, hi = ahead
+                flat, offsets, sizes = held.flat, np.ascontiguousarray(held.offsets[lo:hi]), np.ascontiguousarray(held.sizes[lo:hi])
+            else:
+                flat, offsets, sizes = self._pack_blobs_pinned(blobs) if paths is None else self._read_files_pinned(paths)
             rc = getattr(self._lib, f"ke_{kind}_probe")(_addr(flat), _addr(offsets), _addr(sizes), n, _addr(w), _addr(h), _addr(c), _addr(st))
             if rc != KE_OK:
                 raise ValueError(f"ke_{kind}_probe: bad arguments")
@@ -540,6 +608,11 @@ class Context:
             if self._decoded_ptr:
                 self.free(self._decoded_ptr)
                 self._decoded_ptr, self._decoded_cap = 0, 0
+            with self._ahead_lock:
+                for buf in self._ahead:
+                    if buf[0] and not buf[2]:
+                        self._check(self._lib.ke_host_free(self._h, buf[0]), "ke_host_free")
+                        buf[0], buf[1] = 0, 0
 
     def jpeg_decode(self, blobs, kind: str = "jpeg"):
         """Pixels of JPEG files decoded on the GPU: list of ndarrays (HxW or HxWx3, what np.asarray(Image.open(f)) gives) with
@@ -564,21 +637,25 @@ class Context:
         """jpeg_hash for files on disk: read (host threads, page-locked buffer), decoded and hashed on the GPU."""
         return self.jpeg_hash(None, want_dhash=want_dhash, kind=kind, paths=list(paths))
 
-    def jpeg_hash(self, blobs, *, want_dhash=True, kind: str = "jpeg", paths=None):
+    def jpeg_hash(self, blobs, *, want_dhash=True, kind: str = "jpeg", paths=None, ahead=None):
         """pHash / dHash of JPEG files, decoded and hashed without the pixels leaving the GPU.  Returns (phash u64[n],
-        dhash u64[n] | None, status int32[n]); status != 0 = not handled here (decode the file with Pillow)."""
-        n = len(blobs) if paths is None else len(paths)
+        dhash u64[n] | None, status int32[n]); status != 0 = not handled here (decode the file with Pillow).  The files come
+        as bytes (``blobs``), as ``paths`` the library reads, or as ``ahead = (FilesAhead, lo, hi)``: files lo..hi of a batch
+        read beforehand."""
+        n = ahead[2] - ahead[1] if ahead is not None else len(blobs) if paths is None else len(paths)
         ph = np.zeros(n, np.uint64)
         dh = np.zeros(n, np.uint64) if want_dhash else None
         if n == 0:
             return ph, dh, np.zeros(0, np.int32)
         with self._lock:
             try:
-                dev, out_off, w, h, c, st = self._jpeg_to_device(blobs, kind, paths=paths)
+                dev, out_off, w, h, c, st = self._jpeg_to_device(blobs, kind, paths=paths, ahead=ahead)
             except _BatchTooLarge:
                 half = n // 2
                 parts = [self.jpeg_hash(None if blobs is None else blobs[lo:hi], want_dhash=want_dhash, kind=kind,
-                                        paths=None if paths is None else paths[lo:hi]) for lo, hi in ((0, half), (half, n))]
+                                        paths=None if paths is None else paths[lo:hi],
+                                        ahead=None if ahead is None else (ahead[0], ahead[1] + lo, ahead[1] + hi))
+                         for lo, hi in ((0, half), (half, n))]
                 return (np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts]) if want_dhash else None,
                         np.concatenate([p[2] for p in parts]))
             for ch in (1, 3, 4):

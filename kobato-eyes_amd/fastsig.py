@@ -229,6 +229,14 @@ class _GpuStage:
         """jpeg_hash for files on disk: the library reads them (host threads, page-locked memory), no bytes objects."""
         return self.ctx.hash_files(paths, want_dhash=True, kind=kind)
 
+    def read_ahead(self, paths):
+        """The files read into one of the context's read-ahead buffers (any thread; None if none is free)."""
+        return self.ctx.read_files_ahead(paths)
+
+    def hash_ahead(self, held, lo: int, hi: int, kind: str = "jpeg"):
+        """hash_files for files lo..hi of what read_ahead returned."""
+        return self.ctx.jpeg_hash(None, want_dhash=True, kind=kind, ahead=(held, lo, hi))
+
     def hash_one(self, arr):
         """(phash, dhash) or None for an image that did not fit a staging buffer."""
         ph, dh, ok = _phash.hash_batch([arr], want_dhash=True, device=self.device)
@@ -245,10 +253,10 @@ class _Pipeline:
     Files are taken ``KE_GPU_BATCH`` (default 32768) at a time (a batch whose compressed bytes exceed ``KE_PACK_LIMIT_BYTES`` or
     whose pixels exceed ``KE_DECODE_LIMIT_BYTES`` is halved by the context until it fits).  Within such a batch:
 
-    * JPEG and PNG files (by suffix) skip Pillow altogether: the threads only read the bytes -- the next batch's files while
-      this one is on the GPU -- and ONE ``ke_jpeg_decode`` / ``ke_png_decode`` call per kind decodes them all, pixel-identical to
-      ``Image.open`` for baseline JPEGs and for 8-bit L / RGB / RGBA PNGs; the hash kernels run on the decoded pixels where
-      they lie.  The batch is large because those decoders are one thread per image: a wave of 64 files takes as long as
+    * JPEG and PNG files (by suffix) skip Pillow altogether: the library's host threads read the next batch's files into one
+      of the context's two page-locked read-ahead buffers (``Context.read_files_ahead``; ``KE_READ_AHEAD=0``: inside the decode
+      call instead) while this one is on the GPU, and ONE ``ke_jpeg_decode`` / ``ke_png_decode`` call per kind decodes them all,
+      pixel-identical to ``Image.open`` for the files the decoders take; the hash kernels run on the decoded pixels where they lie.  The batch is large because those decoders are one thread per image: a wave of 64 files takes as long as
       thousands of waves side by side.  ``KE_GPU_JPEG=0`` / ``KE_GPU_PNG=0`` turn the routes off.
     * every other file, and what the GPU decoders refuse (progressive, CMYK, palette, 16-bit, damaged ...), is decoded by
       Pillow on the thread pool ``chunk`` files at a time: the threads of chunk k write their pixels straight into one of the
@@ -285,43 +293,65 @@ class _Pipeline:
 
     # ---- the GPU decoders' share of a batch
     def _start_reads(self, start: int) -> dict:
-        """position -> (kind, future of the file's bytes) for the JPEG / PNG files of the batch that begins at ``start``."""
+        """The JPEG / PNG files of the batch that begins at ``start``, on their way into memory while the batch before is on
+        the GPU: {"files": position -> (kind, future of the file's bytes | None), "ahead": future of the context's FilesAhead
+        | None, "order": the positions in that buffer's order, JPEG files first}."""
         gpu_jpeg = os.environ.get("KE_GPU_JPEG", "1") != "0"
         gpu_png = os.environ.get("KE_GPU_PNG", "1") != "0"
-        by_path = hasattr(self.stage, "hash_files")          # the library reads the files itself: nothing to start here
-        reads = {}
+        by_path = hasattr(self.stage, "hash_files")          # the library reads the files itself, into page-locked memory
+        files = {}
         for k in range(start, min(start + self.batch, len(self.tasks))):
             low = str(self.tasks[k][1]).lower()
             if gpu_jpeg and low.endswith(JPEG_SUFFIXES):
-                reads[k] = ("jpeg", None if by_path else self.pool.submit(_read_bytes, self.tasks[k][1]))
+                files[k] = ("jpeg", None if by_path else self.pool.submit(_read_bytes, self.tasks[k][1]))
             elif gpu_png and low.endswith(PNG_SUFFIXES):
-                reads[k] = ("png", None if by_path else self.pool.submit(_read_bytes, self.tasks[k][1]))
-        return reads
+                files[k] = ("png", None if by_path else self.pool.submit(_read_bytes, self.tasks[k][1]))
+        order = [k for k, v in files.items() if v[0] == "jpeg"] + [k for k, v in files.items() if v[0] == "png"]
+        ahead = None
+        if by_path and order and hasattr(self.stage, "read_ahead") and os.environ.get("KE_READ_AHEAD", "1") != "0":
+            ahead = self.pool.submit(self.stage.read_ahead, [str(self.tasks[k][1]) for k in order])
+        return {"files": files, "ahead": ahead, "order": order}
 
     def _decode_on_gpu(self, reads: dict, out: dict) -> list:
         """Fills ``out[position]`` for the files the GPU decoders take; returns the positions they left to Pillow."""
         coded: dict = {"jpeg": ([], []), "png": ([], [])}
-        for k, (kind, fut) in reads.items():
+        for k, (kind, fut) in reads["files"].items():
             res = str(self.tasks[k][1]) if fut is None else fut.result()
             if res is not None:
                 coded[kind][0].append(k)
                 coded[kind][1].append(res)
         by_path = hasattr(self.stage, "hash_files")
-        refused = []
-        for kind, (positions, blobs) in coded.items():
-            if not blobs:
-                continue
+        held = None
+        if reads["ahead"] is not None:
             try:
-                ph, dh, st = self.stage.hash_files(blobs, kind) if by_path else self.stage.jpeg_hash(blobs, kind)
-            except (RuntimeError, ValueError, MemoryError):      # e.g. no room on the device for this batch: Pillow decodes it
-                refused.extend(positions)
-                continue
-            signed = zip(np.asarray(ph, np.uint64).view(np.int64).tolist(), np.asarray(dh, np.uint64).view(np.int64).tolist())
-            for k, sig, code in zip(positions, signed, np.asarray(st).tolist()):
-                if code == 0:
-                    out[k] = sig
-                else:                                  # outside the GPU decoder: Pillow decodes it, as the reference does
-                    refused.append(k)
+                held = reads["ahead"].result()             # None: both buffers taken or too many bytes; the call reads the files
+            except Exception:
+                held = None
+        refused = []
+        first = 0
+        try:
+            for kind, (positions, blobs) in coded.items():
+                if not blobs:
+                    continue
+                try:
+                    if held is not None:                   # this kind's files are first .. first + len(positions) of the buffer
+                        ph, dh, st = self.stage.hash_ahead(held, first, first + len(positions), kind)
+                    else:
+                        ph, dh, st = self.stage.hash_files(blobs, kind) if by_path else self.stage.jpeg_hash(blobs, kind)
+                except (RuntimeError, ValueError, MemoryError):      # e.g. no room on the device for this batch: Pillow decodes it
+                    refused.extend(positions)
+                    continue
+                finally:
+                    first += len(positions)
+                signed = zip(np.asarray(ph, np.uint64).view(np.int64).tolist(), np.asarray(dh, np.uint64).view(np.int64).tolist())
+                for k, sig, code in zip(positions, signed, np.asarray(st).tolist()):
+                    if code == 0:
+                        out[k] = sig
+                    else:                                  # outside the GPU decoder: Pillow decodes it, as the reference does
+                        refused.append(k)
+        finally:
+            if held is not None:
+                held.release()
         return refused
 
     # ---- the Pillow share: chunks through the two staging buffers
@@ -429,19 +459,23 @@ class _Pipeline:
 
     def run_batches(self) -> Iterator[Tuple[List[int], List[Optional[Tuple[int, int]]]]]:
         """Yields ([file_id], [hashes | None]) batch by batch, in task order."""
+        reads_next = None
         try:
             reads_next = self._start_reads(0)
             for start in range(0, len(self.tasks), self.batch):
                 stop = min(start + self.batch, len(self.tasks))
                 reads = reads_next
-                reads_next = self._start_reads(stop) if stop < len(self.tasks) else {}
+                reads_next = self._start_reads(stop) if stop < len(self.tasks) else None
                 out: dict = {}
                 refused = self._decode_on_gpu(reads, out)
-                todo = sorted([k for k in range(start, stop) if k not in reads] + refused)
+                todo = sorted([k for k in range(start, stop) if k not in reads["files"]] + refused)
                 self._decode_with_pillow(todo, out)
                 yield [int(t[0]) for t in self.tasks[start:stop]], [out.get(k) for k in range(start, stop)]
         finally:
             self.pool.shutdown(wait=True, cancel_futures=True)    # no thread may still be writing into a staging buffer
+            ahead = reads_next["ahead"] if reads_next else None   # abandoned half way: the batch read ahead gives its buffer back
+            if ahead is not None and ahead.done() and not ahead.cancelled() and ahead.exception() is None and ahead.result() is not None:
+                ahead.result().release()
             try:
                 self.stage.wait(-1)
             except Exception:

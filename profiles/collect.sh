@@ -35,7 +35,7 @@ for spec in "jpeg corpus 4096" "jpeg corpus 16384" "jpeg corpus 65536" "png corp
     run python3 "$D" --format "$1" --content "$2" --images "$3" >> "$out/${tag}_decode.jsonl" 2>> "$out/${tag}_decode.err"
 done
 : > "$out/${tag}_fastsig.jsonl"
-for spec in "jpeg corpus 16384" "jpeg corpus 65536" "mixed drawing 16384" "png drawing 65536" "png corpus 4096"; do
+for spec in "jpeg corpus 16384" "jpeg corpus 65536" "jpeg corpus 131072" "mixed drawing 16384" "png drawing 65536" "png corpus 4096"; do
     set -- $spec
     run python3 "$root/benchmarks/bench_fastsig.py" --format "$1" --content "$2" --images "$3" >> "$out/${tag}_fastsig.jsonl" 2>> "$out/${tag}_decode.err"
 done

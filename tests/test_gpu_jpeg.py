@@ -112,6 +112,19 @@ def test_fast_fill_takes_the_gpu_route_for_jpeg_files(tmp_path, monkeypatch):
     monkeypatch.setenv("KE_GPU_BATCH", "5")                        # GPU batches of 16 (never below the chunk size), then of 7
     assert K.compute_signatures_mp(items, max_workers=4, chunksize=16) == rows
     assert K.compute_signatures_mp(items, max_workers=4, chunksize=7) == rows
+    # the batches above were read ahead of their decode (Context.read_files_ahead); without, and with a run given up half way
+    from kobato_eyes_amd import _native, fastsig
+
+    context = _native.get_context(0)
+    assert context._ahead[0][0] and not any(buf[2] for buf in context._ahead)
+    monkeypatch.setenv("KE_READ_AHEAD", "0")
+    assert K.compute_signatures_mp(items, max_workers=4, chunksize=7) == rows
+    monkeypatch.delenv("KE_READ_AHEAD")
+    batches = fastsig._Pipeline(items, 4, 7, 0).run_batches()
+    next(batches)
+    batches.close()                                                # the batch being read ahead gives its buffer back
+    assert not any(buf[2] for buf in context._ahead)
+    assert K.compute_signatures_mp(items, max_workers=4, chunksize=7) == rows
     monkeypatch.setenv("KE_GPU_JPEG", "0")
     monkeypatch.setenv("KE_GPU_PNG", "0")
     rows_pillow = K.compute_signatures_mp(items, max_workers=4, chunksize=16)

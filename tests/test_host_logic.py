@@ -422,3 +422,72 @@ def test_cluster_maintenance_matches_reference(K):
     assert [[e.file.file_id for e in K.default_checked_entries(c)] for c in clusters] == g["default_checked"]
     assert K.rebuild_cluster_after_removal(clusters[0], {e.file.file_id for e in clusters[0].files[1:]}) is None
     assert K.choose_keeper(clusters[0].files) == clusters[0].keeper_id
+
+
+def test_batches_read_ahead_reach_the_decoders_in_their_own_order(tmp_path, monkeypatch):
+    """fastsig._Pipeline with a stage that reads files itself (the shape of _GpuStage: read_ahead / hash_ahead / hash_files):
+    the next batch is read while the current one is hashed, JPEG files first and PNG files after them in the buffer, each
+    kind handed its own slice; a batch whose read-ahead found no buffer goes through hash_files; every buffer comes back, also
+    when the run is given up half way.  No device: the 'hashes' are numbers taken from the file names."""
+    from kobato_eyes_amd import fastsig as fs
+
+    items = []
+    for k in range(23):
+        p = tmp_path / f"f{k:03d}.{'png' if k % 3 == 0 else 'jpg'}"
+        p.write_bytes(b"x")
+        items.append((1000 + k, str(p)))
+    log = {"ahead": 0, "direct": 0, "released": 0, "taken": 0}
+
+    class Held:
+        def __init__(self, paths):
+            self.paths = paths
+
+        def release(self):
+            log["released"] += 1
+
+    def numbers(paths, kind):
+        assert all(p.endswith("png" if kind == "png" else "jpg") for p in paths)
+        n = np.array([int(os.path.basename(p)[1:4]) for p in paths], np.uint64)
+        return n, n + np.uint64(500), np.where(n % 5 == 4, 1, 0).astype(np.int32)     # every fifth file is left to Pillow
+
+    class Stage:
+        def __init__(self, device, stage_bytes, max_images):
+            self.buf = np.zeros(1 << 16, np.uint8)
+
+        def acquire(self):
+            return 0, self.buf
+
+        def submit(self, slot, offsets, widths, heights, channels):
+            raise AssertionError("nothing decodes here: the files are not images")
+
+        def wait(self, slot):
+            pass
+
+        def hash_one(self, arr):
+            return None
+
+        def read_ahead(self, paths):
+            log["taken"] += 1
+            if log["taken"] == 2:                              # "both buffers taken": this batch is read inside the call
+                return None
+            log["ahead"] += 1
+            return Held(list(paths))
+
+        def hash_ahead(self, held, lo, hi, kind="jpeg"):
+            return numbers(held.paths[lo:hi], kind)
+
+        def hash_files(self, paths, kind="jpeg"):
+            log["direct"] += 1
+            return numbers(paths, kind)
+
+    monkeypatch.setattr(fs, "_make_stage", Stage)
+    monkeypatch.setenv("KE_GPU_BATCH", "8")
+    monkeypatch.setenv("KE_DECODE_PROCESSES", "0")
+    rows = fs.compute_signatures_mp(items, max_workers=2, chunksize=8)
+    want = [(1000 + k, k, k + 500) for k in range(23) if k % 5 != 4]          # the refused ones are not images: dropped
+    assert rows == want
+    assert log["ahead"] == 2 and log["released"] == 2 and log["direct"] == 2   # three batches: one of them jpeg + png direct
+    batches = fs._Pipeline(items, 2, 8, 0).run_batches()
+    next(batches)
+    batches.close()
+    assert log["released"] == log["ahead"]

@@ -482,12 +482,16 @@ class _Pipeline:
                 pass
 
 
+class _SignedRows(list):
+    """Rows whose hashes are Python ints in the signed 64-bit range (what the pipeline yields): nothing to convert on upsert."""
+
+
 def compute_signatures_mp(tasks: List[Task], *, max_workers: Optional[int] = None, chunksize: int = 64,
                           progress: Optional[Callable[[int, int], None]] = None,
                           cancel_fn: Optional[Callable[[], bool]] = None, device: int = 0) -> List[Row]:
     """[(file_id, path)] -> [(file_id, phash_s64, dhash_s64)], input order, failures omitted."""
     total = len(tasks)
-    rows: List[Row] = []
+    rows: List[Row] = _SignedRows()
     if total == 0:
         return rows
     workers = max_workers or max(1, _usable_cpus() - 1)
@@ -523,7 +527,10 @@ def compute_signatures_mp(tasks: List[Task], *, max_workers: Optional[int] = Non
 
 def bulk_upsert_signatures(conn: sqlite3.Connection, rows: Iterable[Row]) -> int:
     """One executemany upsert into signatures(file_id, phash_u64, dhash_u64); returns the row count."""
-    payload = [(int(fid), _to_signed64(ph), _to_signed64(dh)) for fid, ph, dh in rows]
+    if isinstance(rows, _SignedRows):               # compute_signatures_mp's own rows: ints in the signed range already
+        payload = rows
+    else:
+        payload = [(int(fid), _to_signed64(ph), _to_signed64(dh)) for fid, ph, dh in rows]
     if not payload:
         return 0
     with conn:

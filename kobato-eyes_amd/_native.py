@@ -175,6 +175,7 @@ class FilesAhead:
 
     def __init__(self, ctx, slot: int, flat, offsets, sizes) -> None:
         self._ctx, self._slot, self.flat, self.offsets, self.sizes = ctx, slot, flat, offsets, sizes
+        self.probed = {}                  # (kind, lo, hi) -> (widths, heights, channels, status) where the reader parsed headers too
 
     def __len__(self) -> int:
         return len(self.sizes)
@@ -431,11 +432,12 @@ class Context:
         flat = np.ctypeslib.as_array((C.c_uint8 * total).from_address(self._pack_ptr))
         return flat, offsets, sizes
 
-    def read_files_ahead(self, paths):
+    def read_files_ahead(self, paths, spans=()):
         """Read files into one of the context's two page-locked read-ahead buffers -- from any thread, while another call of the
         context is decoding the previous batch on the GPU (nothing here touches the stream or the context's lock).  Returns a
         FilesAhead to pass to ``jpeg_hash(..., ahead=(it, lo, hi))`` and to ``release()`` afterwards, or None when both buffers
-        are taken or the files exceed ``pack_limit`` (the caller then lets the decode call read them itself)."""
+        are taken or the files exceed ``pack_limit`` (the caller then lets the decode call read them itself).  ``spans`` =
+        [(kind, lo, hi)]: the headers of files lo..hi are parsed here as well (``ke_<kind>_probe``), off the decoding thread."""
         paths = list(paths)
         n = len(paths)
         if n == 0:
@@ -471,7 +473,14 @@ class Context:
             buf[2] = False
             raise
         flat = np.ctypeslib.as_array((C.c_uint8 * int(needed.value)).from_address(buf[0]))
-        return FilesAhead(self, slot, flat, offsets, sizes)
+        held = FilesAhead(self, slot, flat, offsets, sizes)
+        for kind, lo, hi in spans:
+            if hi > lo:
+                w, h, c, st = (np.zeros(hi - lo, np.int32) for _ in range(4))
+                o, z = np.ascontiguousarray(offsets[lo:hi]), np.ascontiguousarray(sizes[lo:hi])
+                if getattr(self._lib, f"ke_{kind}_probe")(_addr(flat), _addr(o), _addr(z), hi - lo, _addr(w), _addr(h), _addr(c), _addr(st)) == KE_OK:
+                    held.probed[(kind, lo, hi)] = (w, h, c, st)
+        return held
 
     def _pack_blobs_pinned(self, blobs):
         """The files back to back in the context's page-locked buffer (grown on demand, reused from call to call): the copy
@@ -525,9 +534,13 @@ class Context:
                 flat, offsets, sizes = held.flat, np.ascontiguousarray(held.offsets[lo:hi]), np.ascontiguousarray(held.sizes[lo:hi])
             else:
                 flat, offsets, sizes = self._pack_blobs_pinned(blobs) if paths is None else self._read_files_pinned(paths)
-            rc = getattr(self._lib, f"ke_{kind}_probe")(_addr(flat), _addr(offsets), _addr(sizes), n, _addr(w), _addr(h), _addr(c), _addr(st))
-            if rc != KE_OK:
-                raise ValueError(f"ke_{kind}_probe: bad arguments")
+            known = ahead[0].probed.get((kind, ahead[1], ahead[2])) if ahead is not None else None
+            if known is not None:
+                w, h, c, st = (a.copy() for a in known)
+            else:
+                rc = getattr(self._lib, f"ke_{kind}_probe")(_addr(flat), _addr(offsets), _addr(sizes), n, _addr(w), _addr(h), _addr(c), _addr(st))
+                if rc != KE_OK:
+                    raise ValueError(f"ke_{kind}_probe: bad arguments")
             nbytes = np.where(st == 0, w.astype(np.int64) * h * c, 0)
             padded = (nbytes + 15) & ~np.int64(15)
             out_off = np.zeros(n, np.uint64)

@@ -229,9 +229,9 @@ class _GpuStage:
         """jpeg_hash for files on disk: the library reads them (host threads, page-locked memory), no bytes objects."""
         return self.ctx.hash_files(paths, want_dhash=True, kind=kind)
 
-    def read_ahead(self, paths):
-        """The files read into one of the context's read-ahead buffers (any thread; None if none is free)."""
-        return self.ctx.read_files_ahead(paths)
+    def read_ahead(self, paths, spans=()):
+        """The files read into one of the context's read-ahead buffers, headers parsed (any thread; None if none is free)."""
+        return self.ctx.read_files_ahead(paths, spans)
 
     def hash_ahead(self, held, lo: int, hi: int, kind: str = "jpeg"):
         """hash_files for files lo..hi of what read_ahead returned."""
@@ -309,7 +309,9 @@ class _Pipeline:
         order = [k for k, v in files.items() if v[0] == "jpeg"] + [k for k, v in files.items() if v[0] == "png"]
         ahead = None
         if by_path and order and hasattr(self.stage, "read_ahead") and os.environ.get("KE_READ_AHEAD", "1") != "0":
-            ahead = self.pool.submit(self.stage.read_ahead, [str(self.tasks[k][1]) for k in order])
+            jpegs = sum(1 for v in files.values() if v[0] == "jpeg")
+            ahead = self.pool.submit(self.stage.read_ahead, [str(self.tasks[k][1]) for k in order],
+                                     (("jpeg", 0, jpegs), ("png", jpegs, len(order))))
         return {"files": files, "ahead": ahead, "order": order}
 
     def _decode_on_gpu(self, reads: dict, out: dict) -> list:

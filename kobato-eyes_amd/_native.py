@@ -169,6 +169,22 @@ def _addr(buf) -> Optional[int]:
     raise TypeError(f"unsupported buffer type {type(buf)!r}")
 
 
+def _leave_bombs_to_pillow(w, h, st, sizes) -> None:
+    """Every decode here stands in for an ``Image.open``, which raises DecompressionBombError on an image of more than twice
+    ``Image.MAX_IMAGE_PIXELS`` pixels: such files are marked unsupported (1) and hidden from the decoder (size 0: it reports
+    them as not decodable and writes nothing), so that the caller's Pillow route raises as the reference's does.  The live
+    value counts (safe_load_image changes it while it runs); None = no cap."""
+    try:
+        from PIL import Image
+    except ModuleNotFoundError:  # pragma: no cover
+        return
+    cap = Image.MAX_IMAGE_PIXELS
+    if cap is not None:
+        bombs = (st == 0) & (w.astype(np.int64) * h > 2 * int(cap))
+        st[bombs] = 1
+        sizes[bombs] = 0
+
+
 class FilesAhead:
     """The files of a batch in one of a context's read-ahead buffers (Context.read_files_ahead): file i is
     ``flat[offsets[i]:offsets[i] + sizes[i]]`` (size 0 = unreadable).  ``release()`` hands the buffer back."""
@@ -541,6 +557,7 @@ class Context:
                 rc = getattr(self._lib, f"ke_{kind}_probe")(_addr(flat), _addr(offsets), _addr(sizes), n, _addr(w), _addr(h), _addr(c), _addr(st))
                 if rc != KE_OK:
                     raise ValueError(f"ke_{kind}_probe: bad arguments")
+            _leave_bombs_to_pillow(w, h, st, sizes)
             nbytes = np.where(st == 0, w.astype(np.int64) * h * c, 0)
             padded = (nbytes + 15) & ~np.int64(15)
             out_off = np.zeros(n, np.uint64)
@@ -580,6 +597,7 @@ class Context:
                 raise ValueError(f"ke_{kind}_probe: bad arguments")
             if getattr(self._lib, f"ke_{kind}_caveats")(_addr(flat), _addr(offsets), _addr(sizes), n, _addr(flags)) != KE_OK:
                 raise ValueError(f"ke_{kind}_caveats: bad arguments")
+            _leave_bombs_to_pillow(w, h, st, sizes)
             nbytes = np.where(st == 0, w.astype(np.int64) * h * c, 0)
             if by_shape:
                 order = np.lexsort((w, h, c, st != 0))              # decodable files first, grouped by shape

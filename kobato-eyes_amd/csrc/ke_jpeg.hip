@@ -249,7 +249,7 @@ __global__ __launch_bounds__(64) void ke_jpeg_entropy(const KeJpegDev *__restric
             --restart_left;
         }
     }
-    if (rc == KE_JPEG_OK && bits.overrun > 8) rc = KE_JPEG_CORRUPT;     // ran past the data: truncated file (Pillow raises)
+    if (rc == KE_JPEG_OK && ke_bits_ran_dry(bits)) rc = KE_JPEG_CORRUPT;    // used bits beyond the data: truncated or damaged
     status[i] = rc;
 }
 
@@ -438,7 +438,7 @@ __global__ __launch_bounds__(64) void ke_jpeg_entropy_prog(const KeJpegDev *__re
                     --restart_left;
                 }
         }
-        if (rc == KE_JPEG_OK && bits.overrun > 8) rc = KE_JPEG_CORRUPT;   // ran past the scan's data: truncated file (Pillow raises)
+        if (rc == KE_JPEG_OK && ke_bits_ran_dry(bits)) rc = KE_JPEG_CORRUPT;  // used bits beyond the scan's data: truncated or damaged
     }
     status[i] = rc;
 }

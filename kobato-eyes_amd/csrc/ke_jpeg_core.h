@@ -74,12 +74,13 @@ struct KeBits {
     uint32_t pos, end;
     uint64_t acc;       // bits left-aligned
     int32_t n;          // valid bits in acc
-    int32_t overrun;
+    int32_t overrun;    // zero bytes fed behind the data
     int32_t marker;     // pending marker byte (0 = none)
+    int32_t next_rst;   // number the next restart marker must carry (jdmarker.c next_restart_num)
 };
 
 KE_HD void ke_bits_init(KeBits &b, const uint8_t *p, uint32_t pos, uint32_t end) {
-    b.p = p; b.pos = pos; b.end = end; b.acc = 0; b.n = 0; b.overrun = 0; b.marker = 0;
+    b.p = p; b.pos = pos; b.end = end; b.acc = 0; b.n = 0; b.overrun = 0; b.marker = 0; b.next_rst = 0;
 }
 
 KE_HD void ke_bits_fill(KeBits &b) {
@@ -110,8 +111,17 @@ KE_HD void ke_bits_fill(KeBits &b) {
 KE_HD uint32_t ke_bits_peek(const KeBits &b, int k) { return (uint32_t)(b.acc >> (64 - k)); }
 KE_HD void ke_bits_skip(KeBits &b, int k) { b.acc <<= k; b.n -= k; }
 
-// Restart: drop the partial byte, expect the RSTn marker that the filler stopped at (or find it), continue behind it.
+// Whether bits that are not in the file have been consumed: the zero bytes the filler feeds behind the data sit at the tail of
+// the buffer, so as long as it still holds 8 * overrun bits none of them was used (a valid stream only ever looks at them).
+// libjpeg marks such a segment (insufficient_data: the rest of it decodes to zero blocks, with a warning Pillow drops); the
+// decoders here refuse the file instead.
+KE_HD bool ke_bits_ran_dry(const KeBits &b) { return b.overrun * 8 > b.n; }
+
+// Restart: drop the partial byte, expect the RSTn marker that the filler stopped at (or that comes next) -- with the number
+// that is due: anything else and libjpeg resynchronises by a heuristic of its own (jpeg_resync_to_restart), so the file is
+// refused -- and continue behind it.
 KE_HD int ke_bits_restart(KeBits &b) {
+    if (ke_bits_ran_dry(b)) return KE_JPEG_CORRUPT;
     if (b.marker == 0) {                             // the filler has not reached the marker yet: it must come next
         // bytes buffered in acc beyond the current byte boundary belong to the next interval only if no marker was seen;
         // rewind to the byte boundary of what was consumed
@@ -124,7 +134,8 @@ KE_HD int ke_bits_restart(KeBits &b) {
         if (b.pos + 1 < b.end && b.p[b.pos] == 0xFF && b.p[b.pos + 1] >= 0xD0 && b.p[b.pos + 1] <= 0xD7) b.marker = b.p[b.pos + 1];
         else return KE_JPEG_CORRUPT;
     }
-    if (b.marker < 0xD0 || b.marker > 0xD7) return KE_JPEG_CORRUPT;
+    if (b.marker != 0xD0 + b.next_rst) return KE_JPEG_CORRUPT;
+    b.next_rst = (b.next_rst + 1) & 7;
     b.pos += 2;
     b.acc = 0; b.n = 0; b.marker = 0; b.overrun = 0;
     return KE_JPEG_OK;

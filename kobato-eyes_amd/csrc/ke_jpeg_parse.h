@@ -26,7 +26,7 @@ static inline bool ke_build_huff(const uint8_t *counts, const uint8_t *symbols, 
             t.maxcode[l] = -1;
         } else {
             t.valoffset[l] = k - code;
-            if (code + cnt > (1 << l)) return false;
+            if (code + cnt >= (1 << l)) return false;        // jdhuff.c: no code may be all ones
             for (int i = 0; i < cnt; ++i, ++k, ++code) {
                 if (l <= 9) {
                     const int first = code << (9 - l), span = 1 << (9 - l);
@@ -38,6 +38,22 @@ static inline bool ke_build_huff(const uint8_t *counts, const uint8_t *symbols, 
         code <<= 1;
     }
     t.maxcode[17] = 0x7fffffff;
+    return true;
+}
+
+// jpeg_make_d_derived_tbl's checks on a table a scan is about to use (JERR_BAD_HUFF_TABLE: Pillow raises): the codes of every
+// length leave the all-ones code free, and a DC table holds categories 0..15 only.  `dht` = 16 counts, then the symbols.
+static inline bool ke_dht_usable(const uint8_t *dht, bool dc) {
+    int code = 0, k = 0;
+    for (int l = 1; l <= 16; ++l) {
+        const int cnt = dht[l - 1];
+        if (cnt && code + cnt >= (1 << l)) return false;
+        code = (code + cnt) << 1;
+        k += cnt;
+    }
+    if (dc)
+        for (int i = 0; i < k; ++i)
+            if (dht[16 + i] > 15) return false;
     return true;
 }
 
@@ -104,7 +120,13 @@ static inline void ke_parse_jpeg(const uint8_t *p, size_t size, KeJpegTables &ta
         while (pos < size && p[pos] == 0xFF) ++pos;          // fill bytes
         if (pos >= size) break;
         const int m = p[pos++];
-        if (m == 0xD8 || (m >= 0xD0 && m <= 0xD7) || m == 0x01) continue;
+        if ((m >= 0xD0 && m <= 0xD7) || m == 0x01) continue; // RSTn / TEM between segments: jdmarker.c reads on
+        // what read_markers knows: SOFn, DHT, SOS, EOI, DQT, DNL, DRI, APPn, COM (DAC belongs to arithmetic coding: not taken
+        // here).  A second SOI, JPGn and the reserved codes
+        // are fatal there (JERR_SOI_DUPLICATE / JERR_UNKNOWN_MARKER), and Pillow's own scan stops at codes below 0xC0
+        if (!((m >= 0xC0 && m <= 0xCF && m != 0xC8 && m != 0xCC) || m == 0xD9 || m == 0xDA || m == 0xDB || m == 0xDC || m == 0xDD || (m >= 0xE0 && m <= 0xEF) ||
+              m == 0xFE))
+            return give_up(KE_JPEG_UNSUPPORTED);
         if (m == 0xD9) {
             if (progressive && have_geometry && scans && scans->size() > scan0) {
                 // libjpeg smooths blocks whose first AC coefficients have not been refined to the last bit (jdcoefct.c
@@ -156,6 +178,7 @@ static inline void ke_parse_jpeg(const uint8_t *p, size_t size, KeJpegTables &ta
                 (tc ? ac_dht : dc_dht)[th] = (uint32_t)(seg + o + 1 - p);
                 o += 17 + (size_t)total;
             }
+            if (o != n) { info.status = KE_JPEG_CORRUPT; return; }     // get_dht: JERR_BAD_LENGTH
         } else if (m == 0xC0 || m == 0xC1 || (m == 0xC2 && (scans || !find_end))) {   // SOF0 / SOF1 (sequential), SOF2 (progressive)
             if (n < 6 || have_sof) return;
             progressive = m == 0xC2;
@@ -163,27 +186,28 @@ static inline void ke_parse_jpeg(const uint8_t *p, size_t size, KeJpegTables &ta
             info.height = (seg[1] << 8) | seg[2];
             info.width = (seg[3] << 8) | seg[4];
             info.ncomp = seg[5];
-            if ((info.ncomp != 1 && info.ncomp != 3) || n < 6 + 3 * (size_t)info.ncomp) return;
-            if (info.width < 1 || info.height < 1) return;
+            if ((info.ncomp != 1 && info.ncomp != 3) || n != 6 + 3 * (size_t)info.ncomp) return;     // get_sof: JERR_BAD_LENGTH
+            if (info.width < 1 || info.height < 1 || info.width > 65500 || info.height > 65500) return;   // JPEG_MAX_DIMENSION
             for (int c = 0; c < info.ncomp; ++c) {
                 comp_id[c] = seg[6 + 3 * c];
                 info.hs[c] = seg[7 + 3 * c] >> 4;
                 info.vs[c] = seg[7 + 3 * c] & 15;
                 info.tq[c] = seg[8 + 3 * c];
                 if (info.tq[c] > 3) return;
+                if (info.hs[c] < 1 || info.hs[c] > 4 || info.vs[c] < 1 || info.vs[c] > 4) return;     // jdinput.c: JERR_BAD_SAMPLING
             }
             have_sof = true;
         } else if (m >= 0xC2 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) {
             return;                                          // progressive, lossless, arithmetic, hierarchical
         } else if (m == 0xDD) {                              // DRI
-            if (n < 2) { info.status = KE_JPEG_CORRUPT; return; }
+            if (n != 2) { info.status = KE_JPEG_CORRUPT; return; }     // get_dri: JERR_BAD_LENGTH
             info.restart_interval = (seg[0] << 8) | seg[1];
         } else if (m == 0xEE) {                              // Adobe
             if (n >= 12 && std::memcmp(seg, "Adobe", 5) == 0) adobe_transform = seg[11];
         } else if (m == 0xDA) {                              // SOS
             if (!have_sof || n < 1) return give_up(KE_JPEG_UNSUPPORTED);
             const int ns = seg[0];
-            if (ns < 1 || ns > info.ncomp || n < 1 + 2 * (size_t)ns + 3) return give_up(KE_JPEG_UNSUPPORTED);
+            if (ns < 1 || ns > info.ncomp || n != 1 + 2 * (size_t)ns + 3) return give_up(KE_JPEG_UNSUPPORTED);   // get_sos: JERR_BAD_LENGTH
             if (!progressive && ns != info.ncomp) return give_up(KE_JPEG_UNSUPPORTED);       // sequential: one interleaved scan only
             KeJpegScan sc;
             std::memset(&sc, 0, sizeof sc);
@@ -201,6 +225,8 @@ static inline void ke_parse_jpeg(const uint8_t *p, size_t size, KeJpegTables &ta
                 if (td > 3 || ta > 3) return give_up(KE_JPEG_CORRUPT);
                 const bool need_dc = !progressive || (sc.ss == 0 && sc.ah == 0), need_ac = !progressive || sc.ss > 0;
                 if ((need_dc && dc_tab[td] < 0) || (need_ac && ac_tab[ta] < 0) || !have_q[info.tq[c]]) return give_up(KE_JPEG_CORRUPT);
+                if ((need_dc && !ke_dht_usable(p + dc_dht[td], true)) || (need_ac && !ke_dht_usable(p + ac_dht[ta], false)))
+                    return give_up(KE_JPEG_CORRUPT);
                 sc.dc_tab[k] = need_dc ? dc_tab[td] : 0;
                 sc.ac_tab[k] = need_ac ? ac_tab[ta] : 0;
                 sc.dc_dht[k] = need_dc ? dc_dht[td] : 0;

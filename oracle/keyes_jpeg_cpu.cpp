@@ -78,7 +78,7 @@ int decode_progressive(const uint8_t *file, const KeJpegTables &tables, const Ke
                     --restart_left;
                 }
         }
-        if (bits.overrun > 8) return KE_JPEG_CORRUPT;
+        if (ke_bits_ran_dry(bits)) return KE_JPEG_CORRUPT;
     }
     return KE_JPEG_OK;
 }
@@ -144,7 +144,7 @@ int ko_jpeg_decode(const uint8_t *file, uint64_t size, uint8_t *out) {
                     }
             --restart_left;
         }
-    if (!info.progressive && bits.overrun > 8) return KE_JPEG_CORRUPT;          // ran past the data (a few zero bytes of look-ahead are normal)
+    if (!info.progressive && ke_bits_ran_dry(bits)) return KE_JPEG_CORRUPT;     // used bits that are not in the file
     if (!narrow) return KE_JPEG_UNSUPPORTED;
     for (int y = 0; y < info.height; ++y)
         for (int x = 0; x < info.width; ++x) {

@@ -1,0 +1,112 @@
+#!/usr/bin/env python3
+"""Randomised damage to JPEG files (test infrastructure): whatever the decoder still TAKES must carry the pixels Pillow
+(libjpeg-turbo) makes of the same bytes -- never other pixels.  Two kinds of damage:
+  header : one byte anywhere from the first marker to just behind the first scan header (marker codes, segment lengths,
+           sampling factors, table ids, Huffman / quantisation tables ...)
+  body   : in the entropy-coded data and the later scans: flipped bits, overwritten runs, deleted and inserted bytes,
+           truncation (restart markers lost or renumbered, scans cut short ...)
+The statuses may differ from Pillow's verdict in one direction only: refusing (-> the caller lets Pillow decide) is always right.
+    python tests/fuzz_jpeg_damage.py [variants per file] [seed] [--gpu]
+Without --gpu the CPU build of the decoder's headers (oracle/libkeyes_jpeg_cpu.so) is exercised; with it the kernels, one batch
+per kind.  Exits non-zero on the first mismatch."""
+import io
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+from PIL import Image, ImageFile
+
+import _jpeg_cases as J
+
+
+def damaged(rng, files, variants, kind):
+    """Yields (name, what was done, damaged bytes)."""
+    for name, data, _ in files:
+        sos = data.index(b"\xff\xda")
+        for v in range(variants):
+            d = bytearray(data)
+            if kind == "header":
+                pos = int(rng.integers(2, sos + 14))
+                d[pos] = (d[pos] + int(rng.integers(1, 256))) & 255
+                what = f"byte {pos}"
+            else:
+                how = v % 5
+                pos = int(rng.integers(sos, len(d)))
+                if how == 0:
+                    d[pos] ^= 1 << int(rng.integers(0, 8))
+                elif how == 1:
+                    k = int(rng.integers(1, 24))
+                    d[pos:pos + k] = rng.integers(0, 256, len(d[pos:pos + k]), dtype=np.uint8).tobytes()
+                elif how == 2:
+                    del d[pos:pos + int(rng.integers(1, 6))]
+                elif how == 3:
+                    d[pos:pos] = rng.integers(0, 256, int(rng.integers(1, 6)), dtype=np.uint8).tobytes()
+                else:
+                    d = d[:pos]
+                what = f"{('flip', 'overwrite', 'delete', 'insert', 'cut')[how]} at {pos} of {len(data)}"
+            yield name, what, bytes(d)
+
+
+def pillow_pixels(blob):
+    """Pillow's strict decode (LOAD_TRUNCATED_IMAGES off, as in the batch hasher's worker processes) or None."""
+    saved, ImageFile.LOAD_TRUNCATED_IMAGES = ImageFile.LOAD_TRUNCATED_IMAGES, False
+    try:
+        im = Image.open(io.BytesIO(blob))
+        im.load()
+        return np.asarray(im)
+    except Exception:
+        return None
+    finally:
+        ImageFile.LOAD_TRUNCATED_IMAGES = saved
+
+
+def check(decode_batch, variants, seed, files=40):
+    """decode_batch([bytes]) -> ([pixels | None], [status]).  Returns (cases, taken, mismatches as text)."""
+    rng = np.random.default_rng(seed)
+    pool = [c for c in J.supported() if c[2].shape[0] >= 16 and c[2].shape[1] >= 16]
+    pool = [pool[i] for i in rng.choice(len(pool), min(files, len(pool)), replace=False)]
+    cases = taken = 0
+    wrong = []
+    for kind in ("header", "body"):
+        batch = list(damaged(rng, pool, variants, kind))
+        out, status = decode_batch([b for _, _, b in batch])
+        for (name, what, blob), px, st in zip(batch, out, status):
+            cases += 1
+            if st != 0:
+                continue
+            taken += 1
+            ref = pillow_pixels(blob)
+            if ref is None or ref.shape != px.shape or not np.array_equal(ref, px):
+                wrong.append(f"{kind}: {name}, {what}: " + ("Pillow refuses the file" if ref is None else "other pixels than Pillow's"))
+    return cases, taken, wrong
+
+
+def cpu_decoder():
+    import test_jpeg_cpu as T
+
+    lib = T._lib()
+
+    def decode_batch(blobs):
+        res = [T._decode(lib, b) for b in blobs]
+        return [r[1] for r in res], [r[0] for r in res]
+    return decode_batch
+
+
+if __name__ == "__main__":
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    variants = int(args[0]) if args else 100
+    seed = int(args[1]) if len(args) > 1 else 1
+    if "--gpu" in sys.argv:
+        from kobato_eyes_amd import _native
+
+        decode = _native.get_context(0).jpeg_decode
+    else:
+        decode = cpu_decoder()
+    cases, taken, wrong = check(decode, variants, seed)
+    print(f"{cases} damaged files, {taken} taken, {len(wrong)} mismatches")
+    for line in wrong[:20]:
+        print("  " + line)
+    sys.exit(1 if wrong else 0)

@@ -317,3 +317,61 @@ def test_files_with_blocks_beyond_the_16_bit_bound_are_handed_back(ctx):
     assert taken[255] == 0 and taken[64] == 0 and taken[1] == len(good) and 0 < taken[16] < len(good)
     clean, st = ctx.jpeg_decode([g[1] for g in good])                    # the status is per file and per call
     assert (st == 0).all() and all(np.array_equal(a, g[2]) for a, g in zip(clean, good))
+
+
+def test_damaged_files_the_kernels_take_are_decoded_as_pillow_does(ctx):
+    """tests/fuzz_jpeg_damage.py through the kernels: two batches of 1 600 damaged files (headers / entropy data); every file the
+    decoder takes has Pillow's pixels, and the statuses are those of the CPU build of the same headers."""
+    import fuzz_jpeg_damage as F
+
+    seen = {}
+
+    def decode(blobs):
+        out, status = ctx.jpeg_decode(blobs)
+        _, cpu_status = F.cpu_decoder()(blobs)
+        seen[len(seen)] = (np.asarray(status).tolist(), list(cpu_status))
+        return out, status
+
+    cases, taken, wrong = F.check(decode, 40, 11)
+    assert not wrong, wrong[:5]
+    assert cases == 3200 and taken > 800
+    assert all(gpu == cpu for gpu, cpu in seen.values())
+
+
+def test_decompression_bombs_are_left_to_pillow(ctx, tmp_path, monkeypatch):
+    """`Image.open` raises DecompressionBombError beyond twice Image.MAX_IMAGE_PIXELS, so the batch hasher drops such a file;
+    the GPU decoders hand them back (status 1, nothing written) and the seam's rows are the Pillow route's.  The cap is
+    lowered to 2 000 pixels here: 64 x 64 files are 'bombs', 17 x 33 ones are not."""
+    from PIL import Image
+
+    import kobato_eyes_amd as K
+
+    monkeypatch.setattr(Image, "MAX_IMAGE_PIXELS", 2000)
+    for cases, decode, suffix in ((list(J.supported()), ctx.jpeg_decode, "jpg"), (list(P.supported()), ctx.png_decode, "png")):
+        small = [c for c in cases if c[2].shape[0] * c[2].shape[1] <= 4000][:12]
+        large = [c for c in cases if c[2].shape[0] * c[2].shape[1] > 4000][:12]
+        assert len(small) >= 4 and len(large) >= 4
+        mixed = [c for pair in zip(small, large) for c in pair]
+        out, status = decode([c[1] for c in mixed])
+        for k, (name, _, ref) in enumerate(mixed):
+            if k % 2 == 0:
+                assert status[k] == 0 and np.array_equal(out[k], ref), name
+            else:
+                assert status[k] != 0 and out[k] is None, name
+        items = []
+        for k, (name, data, _) in enumerate(mixed):
+            path = tmp_path / f"{suffix}{k:02d}.{suffix}"
+            path.write_bytes(data)
+            items.append((k + 1, str(path)))
+        import warnings
+
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", Image.DecompressionBombWarning)
+            rows = K.compute_signatures_mp(items, max_workers=2, chunksize=8)
+            monkeypatch.setenv("KE_GPU_JPEG", "0")
+            monkeypatch.setenv("KE_GPU_PNG", "0")
+            monkeypatch.setenv("KE_DECODE_PROCESSES", "0")         # the cap is this process's: decode on threads
+            assert K.compute_signatures_mp(items, max_workers=2, chunksize=8) == rows
+            monkeypatch.delenv("KE_GPU_JPEG")
+            monkeypatch.delenv("KE_GPU_PNG")
+        assert [r[0] for r in rows] == [k + 1 for k in range(len(mixed)) if k % 2 == 0]

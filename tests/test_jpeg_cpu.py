@@ -62,6 +62,18 @@ def test_blocks_beyond_the_idct_bound_hand_the_file_back():
     assert taken[255] == 0 and taken[1] == len(good) and 0 < taken[16] < len(good)
 
 
+def test_damaged_files_the_decoder_takes_are_decoded_as_pillow_does():
+    """tests/fuzz_jpeg_damage.py, a bounded sample: one header byte changed / the entropy data flipped, overwritten, cut, with
+    bytes deleted or inserted.  A file the decoder still takes has Pillow's pixels (reserved markers, bad segment lengths, bad
+    sampling factors, unusable Huffman tables, renumbered or missing restart markers, data that runs dry are all refused: libjpeg
+    stops on the former and patches the latter up by heuristics of its own)."""
+    import fuzz_jpeg_damage as F
+
+    cases, taken, wrong = F.check(F.cpu_decoder(), 12, 7, files=30)
+    assert not wrong, wrong[:5]
+    assert cases == 720 and taken > 150
+
+
 def test_files_outside_the_decoder_are_refused():
     L = _lib()
     for name, data, expected in J.refused():

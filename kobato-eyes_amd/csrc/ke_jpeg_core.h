@@ -122,17 +122,28 @@ KE_HD bool ke_bits_ran_dry(const KeBits &b) { return b.overrun * 8 > b.n; }
 // refused -- and continue behind it.
 KE_HD int ke_bits_restart(KeBits &b) {
     if (ke_bits_ran_dry(b)) return KE_JPEG_CORRUPT;
-    if (b.marker == 0) {                             // the filler has not reached the marker yet: it must come next
-        // bytes buffered in acc beyond the current byte boundary belong to the next interval only if no marker was seen;
-        // rewind to the byte boundary of what was consumed
+    if (b.marker == 0) {                             // the filler has not reached a marker yet
+        // bytes buffered in acc beyond the current byte boundary were not used: rewind to the byte boundary of what was
+        // consumed, stepping over stuffed zeros
         const int whole = b.n / 8;                   // whole unread bytes in the buffer
-        // walk back `whole` bytes in the stream, stepping over stuffed zeros
         for (int k = 0; k < whole; ++k) {
             if (b.pos >= 2 && b.p[b.pos - 1] == 0 && b.p[b.pos - 2] == 0xFF) b.pos -= 2;
             else b.pos -= 1;
         }
-        if (b.pos + 1 < b.end && b.p[b.pos] == 0xFF && b.p[b.pos + 1] >= 0xD0 && b.p[b.pos + 1] <= 0xD7) b.marker = b.p[b.pos + 1];
-        else return KE_JPEG_CORRUPT;
+        // ... and find the marker as jdmarker.c next_marker does: data left over in front of it is skipped (libjpeg warns of
+        // extraneous bytes; the pixels do not depend on them).  How far the filler had read ahead must not matter: with the
+        // marker already seen the same bytes are dropped with the buffer below.
+        uint32_t q = b.pos;
+        int found = 0;
+        while (q + 1 < b.end) {
+            if (b.p[q] != 0xFF) { ++q; continue; }
+            if (b.p[q + 1] == 0) { q += 2; continue; }           // a stuffed zero: data
+            found = b.p[q + 1];                                     // (0xFF fill bytes in front of a marker: not taken, as in the filler)
+            break;
+        }
+        if (!found) return KE_JPEG_CORRUPT;
+        b.pos = q;
+        b.marker = found;
     }
     if (b.marker != 0xD0 + b.next_rst) return KE_JPEG_CORRUPT;
     b.next_rst = (b.next_rst + 1) & 7;

@@ -346,8 +346,9 @@ def test_decompression_bombs_are_left_to_pillow(ctx, tmp_path, monkeypatch):
 
     import kobato_eyes_amd as K
 
+    jpegs, pngs = list(J.supported()), list(P.supported())            # (made with Pillow: before the cap is lowered)
     monkeypatch.setattr(Image, "MAX_IMAGE_PIXELS", 2000)
-    for cases, decode, suffix in ((list(J.supported()), ctx.jpeg_decode, "jpg"), (list(P.supported()), ctx.png_decode, "png")):
+    for cases, decode, suffix in ((jpegs, ctx.jpeg_decode, "jpg"), (pngs, ctx.png_decode, "png")):
         small = [c for c in cases if c[2].shape[0] * c[2].shape[1] <= 4000][:12]
         large = [c for c in cases if c[2].shape[0] * c[2].shape[1] > 4000][:12]
         assert len(small) >= 4 and len(large) >= 4
@@ -367,10 +368,10 @@ def test_decompression_bombs_are_left_to_pillow(ctx, tmp_path, monkeypatch):
 
         with warnings.catch_warnings():
             warnings.simplefilter("ignore", Image.DecompressionBombWarning)
+            monkeypatch.setenv("KE_DECODE_PROCESSES", "0")         # the lowered cap is this process's: Pillow on threads
             rows = K.compute_signatures_mp(items, max_workers=2, chunksize=8)
             monkeypatch.setenv("KE_GPU_JPEG", "0")
             monkeypatch.setenv("KE_GPU_PNG", "0")
-            monkeypatch.setenv("KE_DECODE_PROCESSES", "0")         # the cap is this process's: decode on threads
             assert K.compute_signatures_mp(items, max_workers=2, chunksize=8) == rows
             monkeypatch.delenv("KE_GPU_JPEG")
             monkeypatch.delenv("KE_GPU_PNG")

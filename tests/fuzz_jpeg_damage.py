@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
-"""Randomised damage to JPEG files (test infrastructure): whatever the decoder still TAKES must carry the pixels Pillow
-(libjpeg-turbo) makes of the same bytes -- never other pixels.  Two kinds of damage:
+"""Randomised damage to JPEG (and, with --png, PNG) files (test infrastructure): whatever the decoder still TAKES must carry
+the pixels Pillow makes of the same bytes -- never other pixels, and never a file Pillow gives up on.  Two kinds of damage:
   header : one byte anywhere from the first marker to just behind the first scan header (marker codes, segment lengths,
            sampling factors, table ids, Huffman / quantisation tables ...)
   body   : in the entropy-coded data and the later scans: flipped bits, overwritten runs, deleted and inserted bytes,
            truncation (restart markers lost or renumbered, scans cut short ...)
 The statuses may differ from Pillow's verdict in one direction only: refusing (-> the caller lets Pillow decide) is always right.
-    python tests/fuzz_jpeg_damage.py [variants per file] [seed] [--gpu]
+(PNG files: `header` = one byte anywhere in the file changed, `body` = the same edits anywhere behind the signature.)
+    python tests/fuzz_jpeg_damage.py [variants per file] [seed] [--gpu] [--png]
 Without --gpu the CPU build of the decoder's headers (oracle/libkeyes_jpeg_cpu.so) is exercised; with it the kernels, one batch
 per kind.  Exits non-zero on the first mismatch."""
 import io
@@ -20,16 +21,17 @@ import numpy as np
 from PIL import Image, ImageFile
 
 import _jpeg_cases as J
+import _png_cases as P
 
 
-def damaged(rng, files, variants, kind):
+def damaged(rng, files, variants, kind, fmt="jpeg"):
     """Yields (name, what was done, damaged bytes)."""
     for name, data, _ in files:
-        sos = data.index(b"\xff\xda")
+        sos = data.index(b"\xff\xda") if fmt == "jpeg" else 8
         for v in range(variants):
             d = bytearray(data)
             if kind == "header":
-                pos = int(rng.integers(2, sos + 14))
+                pos = int(rng.integers(2, sos + 14)) if fmt == "jpeg" else int(rng.integers(8, len(d)))
                 d[pos] = (d[pos] + int(rng.integers(1, 256))) & 255
                 what = f"byte {pos}"
             else:
@@ -51,11 +53,14 @@ def damaged(rng, files, variants, kind):
 
 
 def pillow_pixels(blob):
-    """Pillow's strict decode (LOAD_TRUNCATED_IMAGES off, as in the batch hasher's worker processes) or None."""
+    """Pillow's strict decode (LOAD_TRUNCATED_IMAGES off, as in the batch hasher's worker processes) or None.  Palette, bilevel
+    and sub-byte gray PNGs as the hashes see them: convert("L") (what ke_png_decode yields for those)."""
     saved, ImageFile.LOAD_TRUNCATED_IMAGES = ImageFile.LOAD_TRUNCATED_IMAGES, False
     try:
         im = Image.open(io.BytesIO(blob))
         im.load()
+        if im.format == "PNG" and (im.mode in ("P", "1") or (im.mode == "L" and blob[24] < 8)):
+            return np.asarray(im.convert("L"))
         return np.asarray(im)
     except Exception:
         return None
@@ -63,15 +68,18 @@ def pillow_pixels(blob):
         ImageFile.LOAD_TRUNCATED_IMAGES = saved
 
 
-def check(decode_batch, variants, seed, files=40):
+def check(decode_batch, variants, seed, files=40, fmt="jpeg"):
     """decode_batch([bytes]) -> ([pixels | None], [status]).  Returns (cases, taken, mismatches as text)."""
     rng = np.random.default_rng(seed)
-    pool = [c for c in J.supported() if c[2].shape[0] >= 16 and c[2].shape[1] >= 16]
+    if fmt == "jpeg":
+        pool = [c for c in J.supported() if c[2].shape[0] >= 16 and c[2].shape[1] >= 16]
+    else:
+        pool = [c for c in list(P.supported()) + list(P.handmade()) + list(P.mapped()) if c[2].shape[0] >= 8]
     pool = [pool[i] for i in rng.choice(len(pool), min(files, len(pool)), replace=False)]
     cases = taken = 0
     wrong = []
     for kind in ("header", "body"):
-        batch = list(damaged(rng, pool, variants, kind))
+        batch = list(damaged(rng, pool, variants, kind, fmt))
         out, status = decode_batch([b for _, _, b in batch])
         for (name, what, blob), px, st in zip(batch, out, status):
             cases += 1
@@ -84,9 +92,11 @@ def check(decode_batch, variants, seed, files=40):
     return cases, taken, wrong
 
 
-def cpu_decoder():
-    import test_jpeg_cpu as T
-
+def cpu_decoder(fmt="jpeg"):
+    if fmt == "jpeg":
+        import test_jpeg_cpu as T
+    else:
+        import test_png_cpu as T
     lib = T._lib()
 
     def decode_batch(blobs):
@@ -99,13 +109,14 @@ if __name__ == "__main__":
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     variants = int(args[0]) if args else 100
     seed = int(args[1]) if len(args) > 1 else 1
+    fmt = "png" if "--png" in sys.argv else "jpeg"
     if "--gpu" in sys.argv:
         from kobato_eyes_amd import _native
 
-        decode = _native.get_context(0).jpeg_decode
+        decode = getattr(_native.get_context(0), f"{fmt}_decode")
     else:
-        decode = cpu_decoder()
-    cases, taken, wrong = check(decode, variants, seed)
+        decode = cpu_decoder(fmt)
+    cases, taken, wrong = check(decode, variants, seed, fmt=fmt)
     print(f"{cases} damaged files, {taken} taken, {len(wrong)} mismatches")
     for line in wrong[:20]:
         print("  " + line)

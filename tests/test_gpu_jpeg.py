@@ -336,6 +336,10 @@ def test_damaged_files_the_kernels_take_are_decoded_as_pillow_does(ctx):
     assert not wrong, wrong[:5]
     assert cases == 3200 and taken > 800
     assert all(gpu == cpu for gpu, cpu in seen.values())
+    # PNG files the same way (chunk and zlib checksums refuse nearly all of them)
+    cases, taken, wrong = F.check(ctx.png_decode, 40, 12, fmt="png")
+    assert not wrong, wrong[:5]
+    assert cases == 3200 and taken >= 1
 
 
 def test_decompression_bombs_are_left_to_pillow(ctx, tmp_path, monkeypatch):

@@ -43,6 +43,17 @@ def test_decoder_arithmetic_matches_pillow():
     assert n > 100
 
 
+def test_damaged_files_the_decoder_takes_are_decoded_as_pillow_does():
+    """tests/fuzz_jpeg_damage.py --png, a bounded sample: bytes changed, flipped, deleted, inserted anywhere behind the
+    signature, truncation.  Nearly everything is refused (chunk checksums, the zlib checksum); what is taken has Pillow's
+    pixels, and Pillow takes it too."""
+    import fuzz_jpeg_damage as F
+
+    cases, taken, wrong = F.check(F.cpu_decoder("png"), 25, 3, files=40, fmt="png")
+    assert not wrong, wrong[:5]
+    assert cases == 2000 and taken >= 1
+
+
 def test_files_outside_the_decoder_are_refused():
     L = _lib()
     for name, data, expected in P.refused():

@@ -114,6 +114,7 @@ struct RecSink {
     uint32_t n, w;
     uint2 *rec;
     uint32_t nrec;
+    int hold;           // streams that must wait with a match before the wave turns to the matches (matches_now)
     __device__ __forceinline__ uint32_t size() const { return n; }
     __device__ __forceinline__ void put(uint8_t b) {
         w |= (uint32_t)b << (8 * (n & 3));
@@ -125,6 +126,12 @@ struct RecSink {
         w = 0;
     }
     __device__ __forceinline__ void finish() { settle(); }
+    // ke_inflate_zlib's question once per turn: finish the held matches now?  Yes when `hold` streams wait with one, or all
+    // that are still inside the symbol loop (the others would only watch).
+    __device__ __forceinline__ bool matches_now(bool waiting) const {
+        const int waiters = __popcll(__ballot(waiting)), inside = __popcll(__ballot(true));
+        return waiters >= min(hold, inside);
+    }
     __device__ __forceinline__ void copy(uint32_t dist, uint32_t len) {
         settle();
         rec[nrec++] = make_uint2(n, (dist << 9) | (len - 3));
@@ -183,7 +190,7 @@ struct LaneTab {           // limits and bases in registers, the symbols in this
 __global__ __launch_bounds__(64) void ke_png_inflate(const KePngDev *__restrict__ imgs, int64_t n, const uint8_t *__restrict__ streams,
                                                      uint8_t *__restrict__ raw, uint8_t *__restrict__ work, uint2 *__restrict__ records,
                                                      int32_t *__restrict__ status, uint32_t *__restrict__ adler, uint32_t *__restrict__ nrec,
-                                                     int lanes) {
+                                                     int lanes, int hold) {
     __shared__ uint8_t s_lsym[288 * 64], s_dsym[32 * 64];
     __shared__ uint32_t s_lhigh[9 * 64], s_win[16 * 64];
     // `lanes` streams per wave (the rest of the wave idles): every path any lane takes is paid for by the whole wave, so while
@@ -197,7 +204,7 @@ __global__ __launch_bounds__(64) void ke_png_inflate(const KePngDev *__restrict_
     src.nchunk = (d.info.zlen + 15u) >> 4;
     src.avail = src.req = src.t = 0;
     KeBitsLsb<LdsStream> bits{&src, 0, 0, 0};
-    RecSink sink{raw + d.raw_off, 0, 0, records + d.rec_off, 0};
+    RecSink sink{raw + d.raw_off, 0, 0, records + d.rec_off, 0, hold};
     LaneTab tab;
     tab.lsym_ = s_lsym + threadIdx.x;
     tab.lhigh_ = s_lhigh + threadIdx.x;
@@ -689,9 +696,10 @@ KE_API int ke_png_decode(ke_ctx *ctx, const uint8_t *files, const uint64_t *offs
         // of one.  Not the instruction cache (SQC_ICACHE_MISSES stay at 1e-6 of the requests either way); the narrower waves
         // execute 0.84x the instructions of a full one each, 3.3x as many in total.
         const int lanes = 64;
+        static const int hold = [] { const char *e = std::getenv("KE_PNG_HOLD"); const int v = e ? std::atoi(e) : 6; return v < 1 ? 1 : (v > 64 ? 64 : v); }();
         hipLaunchKernelGGL(ke_png_inflate, dim3((unsigned)((m + lanes - 1) / lanes)), dim3(64), 0, ctx->stream, (const KePngDev *)d_imgs, m,
                            (const uint8_t *)d_streams, (uint8_t *)d_raw, (uint8_t *)d_work, (uint2 *)d_rec, (int32_t *)d_status,
-                           (uint32_t *)d_adler, (uint32_t *)d_nrec, lanes);
+                           (uint32_t *)d_adler, (uint32_t *)d_nrec, lanes, hold);
         hipLaunchKernelGGL(ke_png_matches, dim3((unsigned)m), dim3(64), 0, ctx->stream, (const KePngDev *)d_imgs, (uint8_t *)d_raw,
                            (const uint2 *)d_rec, (const int32_t *)d_status, (const uint32_t *)d_nrec);
         const size_t row_lds = (size_t)max_groups * 16;

@@ -341,18 +341,29 @@ KE_PNG_HD int ke_inflate_zlib(KeBitsLsb<Src> &b, Sink &out, uint32_t zlen, uint3
         KE_OCT_LOAD(m, KE_LIM1);
         KE_OCT_LOAD(h, KE_BASE1);
         uint32_t bad = 0;
+        int held = 0;                                 // a length symbol whose distance and copy wait for their turn (0 = none)
         for (;;) {
             b.src->tick(b.wpos);
-            ke_lsb_refill(b);                         // >= 33 bits: a code (<= 15) and its extra bits (<= 13)
-            int cl;
-            int sym = ke_inflate_canon(t, 0, (uint32_t)b.acc, &cl, KE_OCT_ARGS(l), KE_OCT_ARGS(g), KE_OCT_ARGS(m), KE_OCT_ARGS(h));
-            ke_lsb_take(b, cl);
-            bad |= (uint32_t)(cl == 0);               // no such code (sym is -1 then)
-            if ((uint32_t)sym < 256u) {
-                if (out.size() < limit) out.put((uint8_t)sym); else bad = 1;
-            } else if (sym > 256) {
+            int sym = 0;
+            if (!held) {
+                ke_lsb_refill(b);                     // >= 33 bits: a code (<= 15) and its extra bits (<= 13)
+                int cl;
+                sym = ke_inflate_canon(t, 0, (uint32_t)b.acc, &cl, KE_OCT_ARGS(l), KE_OCT_ARGS(g), KE_OCT_ARGS(m), KE_OCT_ARGS(h));
+                ke_lsb_take(b, cl);
+                bad |= (uint32_t)(cl == 0);           // no such code (sym is -1 then)
+                if ((uint32_t)sym < 256u) {
+                    if (out.size() < limit) out.put((uint8_t)sym); else bad = 1;
+                } else if (sym > 256) {
+                    held = sym;
+                }
+            }
+            // The second half of a match costs as much as a literal; on the GPU the whole wave pays for it in every turn in
+            // which one of its 64 streams has a match.  So a stream holds its length symbol back (and sits idle) until the
+            // sink says that enough streams are waiting: the turns in between are literals only.  Per stream nothing changes.
+            if (out.matches_now(held != 0) && held) {
                 // length 3..258 (3.2.5): eight codes of one length each, then groups of four per extra bit, then 258 itself
-                const int ls = sym - 257;
+                const int ls = held - 257;
+                held = 0;
                 const int lx = (ls < 8 || ls >= 28) ? 0 : (ls - 4) >> 2;
                 const uint32_t len = (ls < 8 ? 3u + (uint32_t)ls : ls >= 28 ? 258u : 3u + ((4u + ((uint32_t)ls & 3u)) << lx)) + ke_lsb_take(b, lx);
                 ke_lsb_refill(b);

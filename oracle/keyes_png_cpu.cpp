@@ -24,6 +24,7 @@ struct VecSink {
         for (uint32_t k = 0; k < len; ++k) v.push_back(v[v.size() - dist]);
     }
     uint32_t size() const { return (uint32_t)v.size(); }
+    bool matches_now(bool) const { return true; }     // one stream: a match is finished where it starts
     void finish() {}
 };
 }  // namespace
@@ -90,6 +91,7 @@ int ko_png_stats(const uint8_t *file, uint64_t size, uint64_t *literals, uint64_
         void put(uint8_t) { ++lit; }
         void copy(uint32_t, uint32_t len) { ++cp; cpb += len; }
         uint32_t size() const { return (uint32_t)(lit + cpb); }
+        bool matches_now(bool) const { return true; }
         void finish() {}
     } sink;
     MemSrc src{stream.data(), info.zlen};

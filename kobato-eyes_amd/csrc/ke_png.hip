@@ -28,6 +28,8 @@ struct KePngDev {
     uint64_t raw_off;      // filtered scanlines (height * (1 + width * channels) bytes) inside the scratch
     uint64_t rec_off;      // this image's LZ77 copy records (8 bytes each; at most one per 3 output bytes)
     uint64_t out_off;      // bytes into the caller's pixel buffer
+    uint64_t z_off;        // the image's zlib stream inside the staged stream bytes (64 bits: a batch of textured files holds
+                           // more than 4 GB of them, and a batch cut short there is a launch with half the chip idle)
 };
 
 struct KePngPiece {        // part of one IDAT payload: bytes [src, src + len) of the uploaded files -> [dst, dst + len) of the streams
@@ -199,7 +201,7 @@ __global__ __launch_bounds__(64) void ke_png_inflate(const KePngDev *__restrict_
     if ((int)threadIdx.x >= lanes || i >= n) return;
     const KePngDev &d = imgs[i];
     LdsStream src;
-    src.z = reinterpret_cast<const u32x4 *>(streams + d.info.zoff);
+    src.z = reinterpret_cast<const u32x4 *>(streams + d.z_off);
     src.win = s_win + threadIdx.x;
     src.nchunk = (d.info.zlen + 15u) >> 4;
     src.avail = src.req = src.t = 0;
@@ -636,7 +638,7 @@ KE_API int ke_png_decode(ke_ctx *ctx, const uint8_t *files, const uint64_t *offs
     void *d_files;
     KE_TRY(ke_reserve(ctx, KE_BUF_PIXELS, (size_t)(hi - lo) + 256, &d_files));
     KE_HIP(ctx, hipMemcpyAsync(d_files, files + lo, (size_t)(hi - lo), hipMemcpyHostToDevice, ctx->stream));
-    // sub-batches bounded by scratch (streams + filtered scanlines) and by 32-bit stream offsets
+    // sub-batches bounded by scratch (streams + filtered scanlines + copy records)
     size_t free_b = 0, total_b = 0;
     KE_HIP(ctx, hipMemGetInfo(&free_b, &total_b));
     const uint64_t held = (uint64_t)ctx->buf[KE_BUF_SSIM_IN].bytes + ctx->buf[KE_BUF_TMP].bytes + ctx->buf[KE_BUF_SSIM_AUX].bytes;
@@ -657,9 +659,9 @@ KE_API int ke_png_decode(ke_ctx *ctx, const uint8_t *files, const uint64_t *offs
             const uint64_t zl = ((uint64_t)it.d.info.zlen + 15) & ~15ull;
             const uint64_t want = ((uint64_t)it.d.info.row_bytes + 1) * it.d.info.height;
             const uint64_t rw = (want + 32 + 15) & ~15ull, rc = want / 3 + 2;      // a copy covers at least 3 bytes
-            if (last > first && (zbytes + zl > 0xE0000000ull || zbytes + zl + raw_bytes + rw + (nrecs + rc) * 8 > budget)) break;
-            if (zbytes + zl > 0xF0000000ull) return ke_fail(ctx, KE_EUNSUPPORTED, "a PNG with more than 3.7 GB of compressed data");
-            it.d.info.zoff = (uint32_t)zbytes;
+            if (last > first && zbytes + zl + raw_bytes + rw + (nrecs + rc) * 8 > budget) break;
+            it.d.info.zoff = 0;
+            it.d.z_off = zbytes;
             it.d.raw_off = raw_bytes;
             it.d.rec_off = nrecs;
             nrecs += rc;

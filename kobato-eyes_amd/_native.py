@@ -217,6 +217,7 @@ class Context:
         self._decoded_ptr, self._decoded_cap = 0, 0
         self._ahead = [[0, 0, False], [0, 0, False]]         # read-ahead buffers: [page-locked ptr, capacity, taken]
         self._ahead_lock = threading.Lock()
+        self.decode_kernel_ms = 0.0        # kernel time of every ke_jpeg_decode / ke_png_decode call so far (a batch beyond the limits is several)
         # a decode call beyond these is split in halves: compressed bytes in page-locked memory, decoded pixels on the device
         self.pack_limit = int(os.environ.get("KE_PACK_LIMIT_BYTES", str(8 << 30)))
         self.decode_limit = int(os.environ.get("KE_DECODE_LIMIT_BYTES", str(48 << 30)))
@@ -576,6 +577,7 @@ class Context:
             dev = self._decoded_ptr
             self._check(getattr(self._lib, f"ke_{kind}_decode")(self._h, _addr(flat), _addr(offsets), _addr(sizes), n, dev,
                                                                 _addr(out_off), _addr(st)), f"ke_{kind}_decode")
+            self.decode_kernel_ms += self.last_kernel_ms(4)
         return dev, out_off, w, h, c, st
 
     def decode_files_owned(self, paths, kind: str = "jpeg", *, by_shape: bool = False):

@@ -30,12 +30,12 @@ if [ -x "$root/benchmarks/micro/hbm_read.bin" ]; then run "$root/benchmarks/micr
 # 5. the decode step in front of the path: JPEG and PNG rates per batch size, kernel statistics of one batch of each
 D="$root/benchmarks/bench_jpeg.py"
 : > "$out/${tag}_decode.jsonl"
-for spec in "jpeg corpus 4096" "jpeg corpus 16384" "jpeg corpus 65536" "png corpus 4096" "png corpus 16384" "png drawing 4096" "png drawing 16384" "png drawing 65536"; do
+for spec in "jpeg corpus 4096" "jpeg corpus 16384" "jpeg corpus 65536" "png corpus 4096" "png corpus 16384" "png corpus 32768" "png drawing 4096" "png drawing 16384" "png drawing 65536"; do
     set -- $spec
     run python3 "$D" --format "$1" --content "$2" --images "$3" >> "$out/${tag}_decode.jsonl" 2>> "$out/${tag}_decode.err"
 done
 : > "$out/${tag}_fastsig.jsonl"
-for spec in "jpeg corpus 16384" "jpeg corpus 65536" "jpeg corpus 131072" "mixed drawing 16384" "png drawing 65536" "png corpus 4096"; do
+for spec in "jpeg corpus 16384" "jpeg corpus 65536" "jpeg corpus 131072" "mixed drawing 16384" "png drawing 65536" "png corpus 4096" "png corpus 16384"; do
     set -- $spec
     run python3 "$root/benchmarks/bench_fastsig.py" --format "$1" --content "$2" --images "$3" >> "$out/${tag}_fastsig.jsonl" 2>> "$out/${tag}_decode.err"
 done

@@ -219,7 +219,7 @@ class Context:
         self._ahead_lock = threading.Lock()
         self.decode_kernel_ms = 0.0        # kernel time of every ke_jpeg_decode / ke_png_decode call so far (a batch beyond the limits is several)
         # a decode call beyond these is split in halves: compressed bytes in page-locked memory, decoded pixels on the device
-        self.pack_limit = int(os.environ.get("KE_PACK_LIMIT_BYTES", str(8 << 30)))
+        self.pack_limit = int(os.environ.get("KE_PACK_LIMIT_BYTES", str(16 << 30)))
         self.decode_limit = int(os.environ.get("KE_DECODE_LIMIT_BYTES", str(48 << 30)))
 
     # -- lifetime ---------------------------------------------------------------------------

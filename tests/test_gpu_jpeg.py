@@ -380,3 +380,24 @@ def test_decompression_bombs_are_left_to_pillow(ctx, tmp_path, monkeypatch):
             monkeypatch.delenv("KE_GPU_JPEG")
             monkeypatch.delenv("KE_GPU_PNG")
         assert [r[0] for r in rows] == [k + 1 for k in range(len(mixed)) if k % 2 == 0]
+
+
+def test_png_batch_with_more_than_4_gb_of_compressed_data(ctx):
+    """One launch over 12 288 copies of a 384 KB PNG (4.7 GB of zlib streams: their offsets are 64-bit): every file decodes --
+    each stream's Adler-32 is checked on the device -- and hashes like Pillow's pixels of the file."""
+    import io
+
+    from PIL import Image
+
+    rng = np.random.default_rng(77)
+    arr = rng.integers(0, 256, (512, 512, 3), dtype=np.uint8)
+    arr[:, 100:400] = arr[:, 99:100]                                  # some long copies among the literals
+    b = io.BytesIO()
+    Image.fromarray(arr).save(b, "PNG", compress_level=1)
+    blob = b.getvalue()
+    n = (4_700_000_000 + len(blob) - 1) // len(blob)
+    ph, dh, st = ctx.jpeg_hash([blob] * n, kind="png")
+    assert (st == 0).all()
+    want = O.hash_image(np.asarray(Image.open(io.BytesIO(blob))))
+    assert (ph == np.uint64(want[0])).all() and (dh == np.uint64(want[1])).all()
+    ctx.release_decode_buffers()

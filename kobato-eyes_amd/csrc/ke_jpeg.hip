@@ -236,7 +236,7 @@ __global__ __launch_bounds__(64) void ke_jpeg_entropy(const KeJpegDev *__restric
                             }
                             k += r;
                             if (k > 63) { rc = KE_JPEG_CORRUPT; break; }
-                            lblk[s_zz[k]] = (int16_t)receive_extend(bits, st, s);
+                            lblk[k] = (int16_t)receive_extend(bits, st, s);         // zigzag order in memory (ke_jpeg_idct undoes it)
                             ++k;
                         }
                         if (rc != KE_JPEG_OK) break;
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(64) void ke_jpeg_entropy_prog(const KeJpegDev *__re
     __shared__ __attribute__((aligned(16))) uint8_t s_win[64 * kWinPitch];
     __shared__ __attribute__((aligned(16))) uint8_t s_blk[64 * kBlkPitch];
     const int lane = threadIdx.x;
-    s_zz[lane] = c_zigzag[lane];
+    s_zz[lane] = (uint8_t)lane;            // the blocks are kept in zigzag order (ke_jpeg_idct undoes it): position k is element k
     __syncthreads();
     const int64_t slot_i = (int64_t)blockIdx.x * lanes + lane;
     if (lane >= lanes || slot_i >= n) return;
@@ -460,14 +460,18 @@ __global__ __launch_bounds__(256) void ke_jpeg_idct(const KeJpegDev *__restrict_
     const int brow = local / bpr, bcol = local - brow * bpr;
     const int16_t *src = coefs + d.coef_off + (size_t)b * 64;
     int blk[64];
+    // The entropy kernels leave the 64 coefficients in ZIGZAG order (position k of the scan is element k: no table look-up per
+    // coefficient there, and the bands of a progressive scan are runs of elements); here every element has a compile-time
+    // index, so putting it where the IDCT wants it costs nothing.
+    constexpr uint8_t nat[64] = KE_ZZ;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {                                        // 128 bytes per block: eight 16-byte loads
         const int4 v = reinterpret_cast<const int4 *>(src)[k];
         const int w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {                                    // dequantise here: the entropy threads store raw values
-            blk[8 * k + 2 * j] = (int)(int16_t)(w[j] & 0xFFFF) * (int)in.quant[c][8 * k + 2 * j];
-            blk[8 * k + 2 * j + 1] = (w[j] >> 16) * (int)in.quant[c][8 * k + 2 * j + 1];
+            blk[nat[8 * k + 2 * j]] = (int)(int16_t)(w[j] & 0xFFFF) * (int)in.quant[c][nat[8 * k + 2 * j]];
+            blk[nat[8 * k + 2 * j + 1]] = (w[j] >> 16) * (int)in.quant[c][nat[8 * k + 2 * j + 1]];
         }
     }
     uint8_t rows[64];

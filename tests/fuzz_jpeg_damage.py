@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Randomised damage to JPEG (and, with --png, PNG) files (test infrastructure): whatever the decoder still TAKES must carry
-the pixels Pillow makes of the same bytes -- never other pixels, and never a file Pillow gives up on.  Two kinds of damage:
+the pixels Pillow makes of the same bytes -- never other pixels, and never a file Pillow gives up on.  The kinds of damage:
   header : one byte anywhere from the first marker to just behind the first scan header (marker codes, segment lengths,
            sampling factors, table ids, Huffman / quantisation tables ...)
+  fields : (JPEG) a sampling factor or a table number of the frame header set to another plausible value
   body   : in the entropy-coded data and the later scans: flipped bits, overwritten runs, deleted and inserted bytes,
            truncation (restart markers lost or renumbered, scans cut short ...)
 The statuses may differ from Pillow's verdict in one direction only: refusing (-> the caller lets Pillow decide) is always right.
@@ -30,7 +31,12 @@ def damaged(rng, files, variants, kind, fmt="jpeg"):
         sos = data.index(b"\xff\xda") if fmt == "jpeg" else 8
         for v in range(variants):
             d = bytearray(data)
-            if kind == "header":
+            if kind == "fields":                            # the frame header's sampling factors and table numbers, plausible values
+                sof = max(data.find(b"\xff\xc0"), data.find(b"\xff\xc2"))
+                pos = sof + 11 + 3 * int(rng.integers(0, data[sof + 9])) + int(rng.integers(0, 2))
+                d[pos] = int(rng.choice([0x11, 0x12, 0x21, 0x22, 0x14, 0x41, 0x44, 0x13, 0x31, 0x24, 0x42, 0, 1, 2, 3]))
+                what = f"frame byte {pos - sof} = {d[pos]:#x}"
+            elif kind == "header":
                 pos = int(rng.integers(2, sos + 14)) if fmt == "jpeg" else int(rng.integers(8, len(d)))
                 d[pos] = (d[pos] + int(rng.integers(1, 256))) & 255
                 what = f"byte {pos}"
@@ -78,7 +84,7 @@ def check(decode_batch, variants, seed, files=40, fmt="jpeg"):
     pool = [pool[i] for i in rng.choice(len(pool), min(files, len(pool)), replace=False)]
     cases = taken = 0
     wrong = []
-    for kind in ("header", "body"):
+    for kind in ("header", "body") + (("fields",) if fmt == "jpeg" else ()):
         batch = list(damaged(rng, pool, variants, kind, fmt))
         out, status = decode_batch([b for _, _, b in batch])
         for (name, what, blob), px, st in zip(batch, out, status):

@@ -71,7 +71,7 @@ def test_damaged_files_the_decoder_takes_are_decoded_as_pillow_does():
 
     cases, taken, wrong = F.check(F.cpu_decoder(), 12, 7, files=30)
     assert not wrong, wrong[:5]
-    assert cases == 720 and taken > 150
+    assert cases == 1080 and taken > 150
 
 
 def test_files_outside_the_decoder_are_refused():

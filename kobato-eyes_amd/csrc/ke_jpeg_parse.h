@@ -98,6 +98,7 @@ static inline void ke_parse_jpeg(const uint8_t *p, size_t size, KeJpegTables &ta
     if (size < 4 || p[0] != 0xFF || p[1] != 0xD8) { info.status = KE_JPEG_CORRUPT; return; }
     uint16_t qt[4][64];
     bool have_q[4] = {false, false, false, false};
+    bool latched[3] = {false, false, false};
     int dc_tab[4] = {-1, -1, -1, -1}, ac_tab[4] = {-1, -1, -1, -1};
     uint32_t dc_dht[4] = {0, 0, 0, 0}, ac_dht[4] = {0, 0, 0, 0};
     int comp_id[3] = {0, 0, 0};
@@ -236,7 +237,10 @@ static inline void ke_parse_jpeg(const uint8_t *p, size_t size, KeJpegTables &ta
                     info.huff_dc[c] = dc_tab[td];
                     info.huff_ac[c] = ac_tab[ta];
                 }
-                std::memcpy(info.quant[c], qt[info.tq[c]], sizeof qt[0]);
+                if (!latched[c]) {                            // jdinput.c latch_quant_tables: the table in effect at the component's
+                    std::memcpy(info.quant[c], qt[info.tq[c]], sizeof qt[0]);   // FIRST scan stays, a DQT between scans notwithstanding
+                    latched[c] = true;
+                }
             }
             if (!progressive) {
                 if (sc.ss != 0 || sc.se != 63 || sc.ah != 0 || sc.al != 0) return give_up(KE_JPEG_UNSUPPORTED);

@@ -57,7 +57,7 @@ static inline void ke_parse_png(const uint8_t *p, size_t size, std::vector<KePng
     if (size < 8 + 25 || std::memcmp(p, sig, 8) != 0) return;
     auto be32 = [&](size_t o) { return ((uint32_t)p[o] << 24) | ((uint32_t)p[o + 1] << 16) | ((uint32_t)p[o + 2] << 8) | p[o + 3]; };
     size_t pos = 8;
-    bool have_ihdr = false, ended = false, palette = false, have_plte = false;
+    bool have_ihdr = false, ended = false, palette = false, have_plte = false, idat_closed = false;
     const size_t s0 = segs ? segs->size() : 0;
     uint64_t zlen = 0;
     while (pos + 12 <= size) {
@@ -100,6 +100,8 @@ static inline void ke_parse_png(const uint8_t *p, size_t size, std::vector<KePng
             }
         } else if (idat) {
             if (palette && !have_plte) break;
+            if (idat_closed) break;                    // IDAT, another chunk, IDAT: Pillow's load_read ends the stream at the first
+                                                       // non-IDAT chunk ("image file is truncated"), libpng rejects the file too
             if (len) segs->push_back(KePngSeg{(uint64_t)(pos + 8), len});
             zlen += len;
         } else if (std::memcmp(type, "IEND", 4) == 0) {
@@ -110,6 +112,7 @@ static inline void ke_parse_png(const uint8_t *p, size_t size, std::vector<KePng
             segs->resize(s0);
             return;
         }
+        if (!idat && zlen != 0) idat_closed = true;
         pos += 12 + (size_t)len;
     }
     if (!have_ihdr || zlen == 0 || zlen > 0xF0000000ull || !ended) {   // no IEND: truncated (Pillow raises unless LOAD_TRUNCATED_IMAGES)

@@ -192,3 +192,64 @@ def degenerate_tiles():
         ("checker32", two(0, 255, ((yy // 32 + xx // 32) % 2) == 1), 0xFFBBFFEEFFBBFFEE, 0x5A5A185A24002424, 27.564197540283203),
     ]
     return table
+
+
+# ---- the seams end to end (reference-run fixtures: make_golden.py --only-seams)
+def config0_golden():
+    """BASELINE configs[0] through the reference: {"rows": iter_files_for_dup-shaped dicts without hashes, "phash_s64",
+    "dhash_s64", "edges", "counters", "clusters"}."""
+    with open(os.path.join(GOLDEN, "config0_golden.json")) as fh:
+        g = json.load(fh)
+    n, side = g["n"], g["side"]
+    g["rows"] = [{"file_id": i + 1, "path": f"img_{i:07d}.png", "size": 1000 + (i % 7), "width": side, "height": side}
+                 for i in range(n)]
+    g["phash_s64"] = [int(v) for v in g["phash_s64"]]
+    g["dhash_s64"] = [int(v) for v in g["dhash_s64"]]
+    return g
+
+
+def scan100k_golden():
+    with open(os.path.join(GOLDEN, "scan100k_golden.json")) as fh:
+        return json.load(fh)
+
+
+def scan_listing_digests(edges, clusters):
+    """sha256 of the canonical listings, as make_golden.make_scan100k writes them: edges = sorted (a, b, h) with a < b;
+    clusters = [[keeper_id, [[file_id, best_hamming], ...]], ...] in the scanner's order."""
+    import hashlib
+
+    e = hashlib.sha256(json.dumps(sorted([min(a, b), max(a, b), h] for a, b, h in edges), separators=(",", ":")).encode()).hexdigest()
+    c = hashlib.sha256(json.dumps(clusters, separators=(",", ":")).encode()).hexdigest()
+    return e, c
+
+
+def worker_golden():
+    """[(name, file bytes | None, file_id, expected row (file_id, phash_s64, dhash_s64) | None, opened_as)] in task order: the
+    corpus of make_golden.worker_corpus with what the reference's _compute_worker returned for each file; bytes None = a
+    path that is a directory / does not exist."""
+    with open(os.path.join(GOLDEN, "worker_golden.json")) as fh:
+        rows = json.load(fh)["rows"]
+    z = np.load(os.path.join(GOLDEN, "worker_corpus.npz"))
+    blobs = {str(n): z[f"f{k}"].tobytes() for k, n in enumerate(z["names"])}
+    out = []
+    for name, rec in rows.items():
+        row = rec["row"]
+        out.append((name, blobs.get(name), rec["file_id"], None if row is None else (row[0], int(row[1]), int(row[2])), rec["opened_as"]))
+    out.sort(key=lambda t: t[2])
+    return out
+
+
+def write_worker_corpus(td):
+    """The corpus as files under td -> [(file_id, path)], expected rows in that order (dropped files left out)."""
+    tasks, expected = [], []
+    for name, data, fid, row, _ in worker_golden():
+        p = os.path.join(str(td), name)
+        if data is not None:
+            with open(p, "wb") as fh:
+                fh.write(data)
+        elif name.startswith("a_directory"):
+            os.mkdir(p)
+        tasks.append((fid, p))
+        if row is not None:
+            expected.append(row)
+    return tasks, expected

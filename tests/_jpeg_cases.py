@@ -59,6 +59,21 @@ def supported(full: bool = False):
                 except TypeError:                      # a Pillow without the restart options
                     continue
                 yield f"restart_{list(kw)[0]}_{list(kw.values())[0]}_s{sub}_p{int(prog)}", data, np.asarray(Image.open(io.BytesIO(data)))
+    # a DQT between the scans of a progressive file is legal; libjpeg keeps the table that was in effect at a component's first
+    # scan (jdinput.c latch_quant_tables), so the redefinition changes nothing for components already seen
+    for sub in (0, 2):
+        data = with_dqt_between_scans(_save(a, quality=85, subsampling=sub, progressive=True), 1)
+        yield f"progressive_dqt_between_scans_s{sub}", data, np.asarray(Image.open(io.BytesIO(data)))
+
+
+def with_dqt_between_scans(data: bytes, value: int) -> bytes:
+    """A progressive file with a DQT segment (tables 0 and 1, every step = `value`) put in front of its second scan."""
+    first = data.index(b"\xff\xda")
+    pos = first + 2 + int.from_bytes(data[first + 2:first + 4], "big")
+    while not (data[pos] == 0xFF and data[pos + 1] not in (0x00, 0xFF) and not 0xD0 <= data[pos + 1] <= 0xD7):
+        pos += 1                                          # end of the first scan's entropy data
+    dqt = b"\xff\xdb" + (2 + 2 * 65).to_bytes(2, "big") + b"\x00" + bytes([value]) * 64 + b"\x01" + bytes([value]) * 64
+    return data[:pos] + dqt + data[pos:]
 
 
 def with_quantisation_tables(data: bytes, value: int) -> bytes:

@@ -144,6 +144,18 @@ def refused():
     yield "truncated", good[: len(good) // 2], 2
     yield "bit_flip_in_idat", good[:100] + bytes([good[100] ^ 1]) + good[101:], 2
     yield "not_a_png", b"GIF89a" + bytes(64), 2
+    # IDAT, another chunk, IDAT: Pillow ends the stream at the first non-IDAT chunk ("image file is truncated"), the
+    # reference's worker drops the file (src/core/fastsig.py:36-37)
+    rows = np.concatenate([np.zeros((40, 1), np.uint8), rng.integers(0, 256, (40, 150), dtype=np.uint8)], 1).tobytes()
+    whole = _container(rows, 50, 40, 2, 6, 0, 1 << 30)
+    z_at = whole.index(b"IDAT") - 4
+    zlen = struct.unpack(">I", whole[z_at:z_at + 4])[0]
+    z = whole[z_at + 8:z_at + 8 + zlen]
+
+    def ch(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d))
+
+    yield "idat_text_idat", whole[:z_at] + ch(b"IDAT", z[: zlen // 2]) + ch(b"tEXt", b"k\x00v") + ch(b"IDAT", z[zlen // 2:]) + ch(b"IEND", b""), 2
 
 
 def random_cases(n: int, seed: int = 0):

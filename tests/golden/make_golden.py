@@ -482,8 +482,303 @@ def make_image_io():
     print("image_io:", {k: (v and (v.get("size") or v.get("raises"))) for k, v in out.items()})
 
 
+# ------------------------------------------------------------------ the seams, end to end
+def config0_rows(n=1000, side=256):
+    """Row dicts in the shape of db.repository.iter_files_for_dup for BASELINE configs[0] (file_id = i + 1,
+    size = 1000 + (i mod 7), path = img_{i:07d}.png); shared with tests/_golden.py through the fixture itself."""
+    return [{"file_id": i + 1, "path": f"img_{i:07d}.png", "size": 1000 + (i % 7), "width": side, "height": side} for i in range(n)]
+
+
+def make_config0():
+    """BASELINE configs[0] whole: 1 000 synthetic 256 x 256 RGB images -> the reference's phash / dhash (src/sig/phash.py:33-57,
+    SciPy DCT stand-in) -> DuplicateFile.from_row -> DuplicateScanner(hamming_threshold=8).build_clusters
+    (src/dup/scanner.py:211-356) -> hashes, edges, funnel counters, clusters, keepers."""
+    from core.fastsig import _to_signed64
+
+    n, side = 1000, 256
+    rows = config0_rows(n, side)
+    ph, dh = [], []
+    for i in range(n):
+        img = Image.fromarray(O.synth_rgb(i, side, side))
+        ph.append(_to_signed64(ref_sig.phash(img)))
+        dh.append(_to_signed64(ref_sig.dhash(img)))
+    for r, p in zip(rows, ph):
+        r["phash_u64"] = p                       # what the signatures table holds: the signed wrap
+    files = [DuplicateFile.from_row(r) for r in rows]
+    cap_obj = _Capture()
+    sys.setprofile(cap_obj)
+    try:
+        clusters = DuplicateScanner(DuplicateScanConfig(hamming_threshold=8)).build_clusters(files)
+    finally:
+        sys.setprofile(None)
+    out = {
+        "n": n, "side": side, "config": {"hamming_threshold": 8}, "dct_backend": "scipy.fft.dctn(type=2,norm=ortho) float32",
+        "phash_s64": [str(v) for v in ph], "dhash_s64": [str(v) for v in dh],
+        "edges": sorted([min(a, b), max(a, b), h] for a, b, h in cap_obj.edges),
+        "counters": cap_obj.counters,
+        "clusters": [{"keeper_id": c.keeper_id, "entries": [[e.file.file_id, e.best_hamming] for e in c.files]} for c in clusters],
+    }
+    with open(os.path.join(HERE, "config0_golden.json"), "w") as fh:
+        json.dump(out, fh, separators=(",", ":"))
+    print(f"config0: {n} images, {len(out['edges'])} edges, {len(clusters)} clusters, counters {out['counters']}")
+
+
+def make_scan100k():
+    """The reference's scanner on a BASELINE-size table (100 000 synthetic hashes, T = 8; the probe of BASELINE.md section 2):
+    too many edges to store, so digests of the canonical listings + the counts."""
+    n = 100_000
+    hashes = O.synth_hashes(n)
+    files = [DuplicateFile(file_id=i + 1, path=Path(f"img_{i:07d}.png"), size=1000 + (i % 7), width=512, height=512,
+                           phash=int(hashes[i]), embedding=None) for i in range(n)]
+    out = {"n": n, "hash_generator": "oracle.synth_hashes", "runs": []}
+    for kwargs in ({"hamming_threshold": 8}, {"hamming_threshold": 8, "size_ratio": 0.9985}):
+        cap_obj = _Capture()
+        sys.setprofile(cap_obj)
+        try:
+            clusters = DuplicateScanner(DuplicateScanConfig(**kwargs)).build_clusters(files)
+        finally:
+            sys.setprofile(None)
+        edges = sorted((min(a, b), max(a, b), h) for a, b, h in cap_obj.edges)
+        listing = [[c.keeper_id, [[e.file.file_id, e.best_hamming] for e in c.files]] for c in clusters]
+        out["runs"].append({
+            "config": kwargs, "n_edges": len(edges), "n_clusters": len(clusters), "counters": cap_obj.counters,
+            "edges_sha256": hashlib.sha256(json.dumps(edges, separators=(",", ":")).encode()).hexdigest(),
+            "clusters_sha256": hashlib.sha256(json.dumps(listing, separators=(",", ":")).encode()).hexdigest(),
+            "first_clusters": listing[:5]})
+        print(f"scan100k {kwargs}: {len(edges)} edges, {len(clusters)} clusters, counters {cap_obj.counters}")
+    with open(os.path.join(HERE, "scan100k_golden.json"), "w") as fh:
+        json.dump(out, fh, separators=(",", ":"))
+
+
+def _png_chunks(w, h, depth, ctype, interlace, payload_rows: bytes, *, idat_split=None, between=None) -> bytes:
+    """A PNG container around already filtered scanlines (filter byte + packed samples per row / per Adam7 pass row)."""
+    import struct
+    import zlib
+
+    def ch(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d))
+
+    z = zlib.compress(payload_rows, 6)
+    out = b"\x89PNG\r\n\x1a\n" + ch(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, interlace))
+    if idat_split:
+        cut = max(1, len(z) // idat_split)
+        parts = [z[o:o + cut] for o in range(0, len(z), cut)]
+    else:
+        parts = [z]
+    for k, part in enumerate(parts):
+        out += ch(b"IDAT", part)
+        if between is not None and k == 0 and len(parts) > 1:
+            out += ch(*between)
+    return out + ch(b"IEND", b"")
+
+
+def _adam7_rows(arr: np.ndarray) -> bytes:
+    """8- or 16-bit samples (H x W x C, big-endian bytes already) -> the seven passes' rows, filter 0."""
+    h, w = arr.shape[:2]
+    out = b""
+    for (x0, y0, dx, dy) in ((0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)):
+        sub = arr[y0::dy, x0::dx]
+        if sub.shape[0] == 0 or sub.shape[1] == 0:
+            continue
+        for row in sub:
+            out += b"\x00" + np.ascontiguousarray(row).tobytes()
+    return out
+
+
+def worker_corpus():
+    """[(file name, bytes)] -- the files the batch-hasher seam meets: every format family the reference ranks as a keeper
+    (src/dup/scanner.py:16-28) in the modes Pillow opens them in, damaged and mis-named files included.  Written ONCE here and
+    stored as bytes in the fixture, so the test does not depend on any encoder."""
+    import io
+
+    rng = np.random.default_rng(41)
+    files = []
+
+    def photo(w, h, i=3):
+        return O.synth_rgb(i, w, h)
+
+    def save(name, img, fmt, **kw):
+        b = io.BytesIO()
+        img.save(b, fmt, **kw)
+        files.append((name, b.getvalue()))
+        return b.getvalue()
+
+    rgb = Image.fromarray(photo(96, 80))
+    rgb2 = Image.fromarray(photo(200, 120, 19))
+    odd = Image.fromarray(photo(97, 61, 7))
+    gray = rgb.convert("L")
+    # ---- JPEG family (suffix routes them to the GPU decoder in the build)
+    save("base_420.jpg", rgb, "JPEG", quality=85)
+    save("base_444_q95.jpeg", rgb2, "JPEG", quality=95, subsampling=0)
+    save("base_422.JPG", odd, "JPEG", quality=75, subsampling=1)
+    save("base_gray.jpg", gray, "JPEG", quality=80)
+    save("base_optimized.jpe", rgb2, "JPEG", quality=60, optimize=True)
+    save("progressive.jpg", rgb2, "JPEG", quality=85, progressive=True)
+    save("progressive_gray.jpg", gray, "JPEG", quality=85, progressive=True)
+    save("progressive_444.jfif", odd, "JPEG", quality=92, progressive=True, subsampling=0)
+    save("cmyk.jpg", rgb.convert("CMYK"), "JPEG", quality=90)
+    exif = Image.Exif()
+    exif[0x0112] = 6
+    save("exif_rot6.jpg", rgb2, "JPEG", quality=90, exif=exif.tobytes())       # the worker does NOT transpose (fastsig.py:31-34)
+    exif[0x0112] = 3
+    save("exif_rot3_progressive.jpg", odd, "JPEG", quality=88, exif=exif.tobytes(), progressive=True)
+    try:
+        save("restart_rows.jpg", rgb2, "JPEG", quality=85, restart_marker_rows=1)
+        save("restart_blocks.jpg", rgb2, "JPEG", quality=85, subsampling=0, restart_marker_blocks=3)
+    except TypeError:
+        pass
+    save("tiny_8x8.jpg", Image.fromarray(photo(8, 8)), "JPEG", quality=90)
+    save("tiny_1x1.jpg", Image.fromarray(photo(1, 1)), "JPEG", quality=90)
+    save("thin_3x300.jpg", Image.fromarray(photo(3, 300)), "JPEG", quality=90)
+    save("vga.jpg", Image.fromarray(photo(640, 480, 29)), "JPEG", quality=85)
+    save("q100_noise.jpg", Image.fromarray(rng.integers(0, 256, (70, 90, 3), dtype=np.uint8)), "JPEG", quality=100, subsampling=0)
+    save("rgb_coded.jpg", rgb, "JPEG", quality=90, keep_rgb=True)            # RGB-coded: no colour transform (Adobe marker)
+    # ---- PNG family
+    save("rgb.png", rgb, "PNG")
+    save("rgb_level0.png", rgb2, "PNG", compress_level=0)
+    save("rgb_level9_opt.PNG", odd, "PNG", optimize=True)
+    save("rgba.png", Image.fromarray(rng.integers(0, 256, (70, 90, 4), dtype=np.uint8)), "PNG")
+    save("rgba_photo_halfalpha.png", Image.fromarray(np.dstack([photo(96, 80), np.tile(np.arange(96, dtype=np.uint8) * 2, (80, 1))])), "PNG")
+    save("la.png", Image.fromarray(np.dstack([np.asarray(gray), np.tile(np.arange(96, dtype=np.uint8) * 2, (80, 1))]), "LA"), "PNG")
+    save("l.png", gray, "PNG")
+    pal = rgb.convert("P", palette=Image.Palette.ADAPTIVE, colors=256)
+    save("p256.png", pal, "PNG")
+    save("p256_trns.png", pal, "PNG", transparency=3)
+    save("p16.png", rgb.convert("P", palette=Image.Palette.ADAPTIVE, colors=16), "PNG")
+    save("p4.png", rgb.convert("P", palette=Image.Palette.ADAPTIVE, colors=4), "PNG")
+    save("p2.png", rgb.convert("P", palette=Image.Palette.ADAPTIVE, colors=2), "PNG")
+    save("p16_trns_bytes.png", rgb.convert("P", palette=Image.Palette.ADAPTIVE, colors=16), "PNG", transparency=bytes([0, 128, 255, 7]))
+    save("bilevel.png", gray.convert("1"), "PNG")
+    save("i16.png", Image.fromarray((np.asarray(gray).astype(np.uint16) * 257) ^ 0x55), "PNG")
+    save("apng_2frames.png", rgb, "PNG", save_all=True, append_images=[rgb2.resize(rgb.size)])
+    # hand-made: what Pillow's writer never produces
+    g8 = np.asarray(gray)
+    for depth in (2, 4):
+        per = 8 // depth
+        vals = (g8 >> (8 - depth)).astype(np.uint8)
+        pad = np.zeros((vals.shape[0], (vals.shape[1] + per - 1) // per * per), np.uint8)
+        pad[:, :vals.shape[1]] = vals
+        packed = np.zeros((vals.shape[0], pad.shape[1] // per), np.uint8)
+        for q in range(per):
+            packed |= pad[:, q::per] << (8 - depth * (q + 1))
+        rows = b"".join(b"\x00" + r.tobytes() for r in packed)
+        files.append((f"gray{depth}bit.png", _png_chunks(vals.shape[1], vals.shape[0], depth, 0, 0, rows)))
+    a3 = photo(75, 53, 9)
+    files.append(("adam7_rgb.png", _png_chunks(75, 53, 8, 2, 1, _adam7_rows(a3))))
+    files.append(("adam7_gray.png", _png_chunks(96, 80, 8, 0, 1, _adam7_rows(g8[:, :, None]))))
+    a4 = np.dstack([photo(75, 53, 9), np.full((53, 75), 200, np.uint8)])
+    files.append(("adam7_rgba.png", _png_chunks(75, 53, 8, 6, 1, _adam7_rows(a4))))
+    r16 = (photo(64, 48, 11).astype(np.uint16) * 257 + 13).astype(">u2")
+    rows16 = b"".join(b"\x00" + np.ascontiguousarray(r).tobytes() for r in r16)
+    files.append(("rgb16.png", _png_chunks(64, 48, 16, 2, 0, rows16)))
+    la16 = np.dstack([np.asarray(gray)[:48, :64].astype(np.uint16) * 257, np.full((48, 64), 40000, np.uint16)]).astype(">u2")
+    files.append(("la16.png", _png_chunks(64, 48, 16, 4, 0, b"".join(b"\x00" + np.ascontiguousarray(r).tobytes() for r in la16))))
+    rows8 = b"".join(b"\x00" + np.ascontiguousarray(r).tobytes() for r in photo(64, 48, 11))
+    files.append(("idat_split5.png", _png_chunks(64, 48, 8, 2, 0, rows8, idat_split=5)))
+    files.append(("idat_text_idat.png", _png_chunks(64, 48, 8, 2, 0, rows8, idat_split=2, between=(b"tEXt", b"k\x00v"))))
+    # ---- the other keeper formats (src/dup/scanner.py:16-28): Pillow decodes them in the build as in the reference
+    save("rgb24.bmp", rgb2, "BMP")
+    save("pal8.bmp", pal, "BMP")
+    save("gray8.bmp", gray, "BMP")
+    save("rgba32.bmp", Image.fromarray(a4), "BMP")
+    save("still.gif", pal, "GIF")
+    save("anim.gif", pal, "GIF", save_all=True, append_images=[rgb2.resize(rgb.size).convert("P")], duration=50)
+    save("gif_transparent.gif", pal, "GIF", transparency=5)
+    save("rgb.tif", rgb2, "TIFF")
+    save("rgb_lzw.tiff", odd, "TIFF", compression="tiff_lzw")
+    save("gray16.tif", Image.fromarray((np.asarray(gray).astype(np.uint16) * 200)), "TIFF")
+    save("float32.tif", Image.fromarray((np.asarray(gray).astype(np.float32) * 1.5 - 20)), "TIFF")
+    save("int32.tif", Image.fromarray((np.asarray(gray).astype(np.int32) * 3 - 100)), "TIFF")
+    save("cmyk.tif", rgb.convert("CMYK"), "TIFF")
+    save("bilevel.tif", gray.convert("1"), "TIFF")
+    save("lossy.webp", rgb2, "WEBP", quality=80)
+    save("lossless.webp", odd, "WEBP", lossless=True)
+    save("alpha.webp", Image.fromarray(a4), "WEBP", quality=90)
+    save("raw.ppm", rgb, "PPM")
+    save("raw.pgm", gray, "PPM")
+    save("rgb.tga", rgb, "TGA")
+    save("icon.ico", rgb.resize((64, 64)), "ICO")
+    save("wavelet.jp2", rgb2, "JPEG2000")
+    save("ycbcr.tif", rgb.convert("YCbCr"), "TIFF")
+    # ---- mis-named, damaged, not there
+    png_bytes = dict(files)["rgb.png"]
+    jpg_bytes = dict(files)["base_420.jpg"]
+    prog_bytes = dict(files)["progressive.jpg"]
+    files.append(("png_named.jpg", png_bytes))
+    files.append(("jpeg_named.png", jpg_bytes))
+    files.append(("webp_named.png", dict(files)["lossy.webp"]))
+    files.append(("truncated_60.jpg", jpg_bytes[: len(jpg_bytes) * 6 // 10]))
+    files.append(("truncated_last2.jpg", jpg_bytes[:-2]))
+    files.append(("truncated_prog.jpg", prog_bytes[: len(prog_bytes) // 2]))
+    files.append(("truncated.png", png_bytes[: len(png_bytes) * 2 // 3]))
+    files.append(("truncated_iend.png", png_bytes[:-12]))
+    files.append(("trailing_garbage.jpg", jpg_bytes + b"\x00garbage after EOI" * 7))
+    files.append(("trailing_garbage.png", png_bytes + b"tail"))
+    files.append(("empty.jpg", b""))
+    files.append(("empty.png", b""))
+    files.append(("garbage.jpg", bytes(rng.integers(0, 256, 600, dtype=np.uint8))))
+    files.append(("text.png", b"not an image at all\n"))
+    bad_crc = bytearray(png_bytes)
+    bad_crc[29] ^= 0xFF                                    # the IHDR chunk's CRC
+    files.append(("bad_ihdr_crc.png", bytes(bad_crc)))
+    flipped = bytearray(jpg_bytes)
+    flipped[len(flipped) // 2] ^= 0x5A
+    files.append(("bitflip_mid.jpg", bytes(flipped)))
+    return [(n, b) for n, b in files if b is not None]
+
+
+def make_worker():
+    """The corpus above through the reference's worker, core.fastsig._compute_worker (src/core/fastsig.py:24-37): per file
+    (file_id, phash_s64, dhash_s64) or None (dropped).  A missing path and a directory are part of the task list."""
+    import tempfile
+    import warnings
+
+    from core.fastsig import _compute_worker
+
+    corpus = worker_corpus()
+    names = [n for n, _ in corpus]
+    assert len(set(names)) == len(names)
+    store = {"names": np.array(names)}
+    for k, (_, data) in enumerate(corpus):
+        store[f"f{k}"] = np.frombuffer(data, np.uint8)
+    rows = {}
+    with tempfile.TemporaryDirectory() as td:
+        tasks = []
+        for k, (name, data) in enumerate(corpus):
+            p = os.path.join(td, name)
+            with open(p, "wb") as fh:
+                fh.write(data)
+            tasks.append((k + 1, p, name))
+        os.mkdir(os.path.join(td, "a_directory.jpg"))
+        tasks.append((len(corpus) + 1, os.path.join(td, "a_directory.jpg"), "a_directory.jpg"))
+        tasks.append((len(corpus) + 2, os.path.join(td, "does_not_exist.png"), "does_not_exist.png"))
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            for fid, p, name in tasks:
+                out = _compute_worker((fid, p))
+                info = None
+                try:
+                    with Image.open(p) as im:
+                        info = [im.format, im.mode, list(im.size)]
+                except Exception:
+                    pass
+                rows[name] = {"file_id": fid, "row": None if out is None else [out[0], str(out[1]), str(out[2])], "opened_as": info}
+    np.savez_compressed(os.path.join(HERE, "worker_corpus.npz"), **store)
+    with open(os.path.join(HERE, "worker_golden.json"), "w") as fh:
+        json.dump({"source": "core.fastsig._compute_worker run on /root/reference with the SciPy cv2.dct stand-in",
+                   "pillow_version": Image.__version__, "rows": rows}, fh, indent=1)
+    kept = sum(1 for v in rows.values() if v["row"] is not None)
+    print(f"worker: {len(rows)} tasks, {kept} hashed, dropped:", [n for n, v in rows.items() if v["row"] is None])
+    print("  total bytes", sum(len(b) for _, b in corpus))
+
+
 if __name__ == "__main__":
     logging.basicConfig(level=logging.WARNING)
+    if "--only-seams" in sys.argv:
+        make_config0()
+        make_worker()
+        make_scan100k()
+        raise SystemExit(0)
     if "--only-cluster-update" in sys.argv:
         make_cluster_update()
         raise SystemExit(0)
@@ -504,3 +799,6 @@ if __name__ == "__main__":
     make_refine_parallel()
     make_image_io()
     make_cluster_update()
+    make_config0()
+    make_worker()
+    make_scan100k()

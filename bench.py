@@ -52,7 +52,54 @@ def parse_args():
                     help="exchange through torch.distributed (kobato_eyes_amd.distributed) instead of the library's own RCCL entry points")
     ap.add_argument("--phase-timing", action="store_true", help="after the timed run, time each phase of a step with syncs in between (stderr)")
     ap.add_argument("--cpu-sample", type=int, default=16000, help="images hashed by the CPU oracle for the baseline")
+    ap.add_argument("--weak", action="store_true",
+                    help="weak scaling: --images is the corpus PER RANK (the job hashes images x N; --images 125000 --gpus 8 is BASELINE "
+                         "configs[3]'s 1 000 000-image table)")
+    ap.add_argument("--self-launch", action="store_true",
+                    help="start the ranks as child processes under torch.distributed.run even at --gpus 1 (the RCCL path on one GPU)")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="launch check without a GPU: the ranks meet over gloo, count each other and rank 0 prints the line")
+    ap.add_argument("--phase-steps", type=int, default=3, help="steps of the per-phase timing pass behind the timed region (0: none)")
     return ap.parse_args()
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` typed without a launcher: start the N ranks as FRESH child processes under
+    torch.distributed.run -- before this process has imported torch or touched a GPU (a process that has initialised the GPU
+    must never be replaced or forked) -- let rank 0 write its one JSON line to the inherited stdout, and hand back the
+    children's exit code."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sock:                       # a free port for the rendezvous
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    argv = [a for a in sys.argv[1:] if a != "--self-launch"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), KE_BENCH_SELF_LAUNCHED="1")
+    print(f"[bench] starting {args.gpus} rank(s): {' '.join(cmd)}", file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def rendezvous_only(args) -> None:
+    """The launch path without a GPU (CPU suite): gloo process group, every rank counts the others."""
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)                                       # gloo announces its connections on stdout
+    import torch
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo")
+    one = torch.ones(1, dtype=torch.int64)
+    dist.all_reduce(one)
+    if dist.get_rank() == 0:
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        print(json.dumps({"rendezvous_only": True, "n_gpus": args.gpus, "n_ranks_seen": int(one.item()),
+                          "world_size": dist.get_world_size(), "self_launched": os.environ.get("KE_BENCH_SELF_LAUNCHED") == "1"}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 def cpu_baseline(ctx, args, table_host):
@@ -124,6 +171,10 @@ def cpu_baseline(ctx, args, table_host):
 
 def main():
     args = parse_args()
+    if "RANK" not in os.environ and (args.gpus > 1 or args.self_launch):
+        raise SystemExit(self_launch(args))              # nothing below has run: no torch import, no GPU call in this process
+    if args.rendezvous_only:
+        return rendezvous_only(args)
     # stdout carries ONE JSON line: whatever libraries print while the job runs (RCCL announces its version on stdout when a
     # communicator is made) goes to stderr instead -- file descriptor 1 is pointed at 2 until the line is written
     sys.stdout.flush()
@@ -185,7 +236,12 @@ def main():
         elif int(flag.item()) == 0:
             exchange = None
 
-    n_total, side = args.images, args.side
+    n_ranks_seen = 1
+    if distributed:
+        seen = torch.ones(1, dtype=torch.int32, device=dev)
+        dist.all_reduce(seen)                            # over RCCL: the record shows how many ranks really met
+        n_ranks_seen = int(seen.item())
+    n_total, side = (args.images * world if args.weak else args.images), args.side
     img_bytes = side * side * 3
     # hash-partition of the corpus: image i lives on rank i mod world
     mine = np.arange(rank, n_total, world, dtype=np.int64)
@@ -291,16 +347,34 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
-    if args.phase_timing:
+    # what the batch-hasher seam launches per file is BOTH hashes (src/core/fastsig.py:31-34): the same kernel family with the
+    # dHash leg, timed behind the timed region on the same resident images
+    dual_ms = []
+    dual_hash = torch.zeros(per, dtype=torch.int64, device=dev)
+    dual_dhash = local_dhash if local_dhash is not None else torch.zeros(per, dtype=torch.int64, device=dev)
+    for k in range(2 + max(3, min(args.steps, 10))):
+        ctx.hash_uniform(pixels.data_ptr(), n_local, side, side, 3, phash_out=dual_hash.data_ptr(), dhash_out=dual_dhash.data_ptr(),
+                         want_dhash=True)
+        if k >= 2:
+            dual_ms.append(ctx.last_kernel_ms(0))
+    torch.cuda.synchronize()
+    assert torch.equal(dual_hash[:n_local], local_hash[:n_local]), "pHash of the dual-hash launch differs from the single-hash launch"
+
+    phase_ms = None
+    if args.phase_timing or args.phase_steps > 0:
+        # where a step's time goes: the same calls with a device sync (and, across ranks, the slowest rank) after each phase;
+        # behind the timed region, so `value` is untouched
         acc = {}
+        phase_steps = args.steps if args.phase_timing else args.phase_steps
 
         def lap(name, t0):
             torch.cuda.synchronize()
             acc[name] = acc.get(name, 0.0) + (time.perf_counter() - t0) * 1e3
 
-        for _ in range(args.steps):
+        for _ in range(phase_steps):
             t0 = time.perf_counter()
-            ctx.hash_uniform(pixels.data_ptr(), n_local, side, side, 3, phash_out=local_hash.data_ptr(), want_dhash=False)
+            ctx.hash_uniform(pixels.data_ptr(), n_local, side, side, 3, phash_out=local_hash.data_ptr(),
+                             dhash_out=local_dhash.data_ptr() if args.dhash else None, want_dhash=args.dhash)
             lap("hash", t0)
             t0 = time.perf_counter()
             if exchange:
@@ -322,10 +396,16 @@ def main():
                 all_edges = edges_dev[: edges * 24].cpu().numpy().view(_native.EDGE_DTYPE)
             lap("edge_merge", t0)
             t0 = time.perf_counter()
-            _native.cluster_labels(all_edges, n_total)
+            if rank == 0:
+                _native.cluster_labels(all_edges, n_total)
             lap("labels", t0)
-        if rank == 0:
-            print("phase ms/step:", {k: round(v / args.steps, 3) for k, v in acc.items()}, file=sys.stderr, flush=True)
+        names = list(acc)
+        per_phase = torch.tensor([acc[k] / phase_steps for k in names], dtype=torch.float64, device=dev)
+        if distributed:
+            dist.all_reduce(per_phase, op=dist.ReduceOp.MAX)
+        phase_ms = {k: round(float(v), 4) for k, v in zip(names, per_phase.tolist())}
+        if rank == 0 and args.phase_timing:
+            print("phase ms/step:", phase_ms, file=sys.stderr, flush=True)
 
     h2d = None
     if rank == 0 and world == 1 and not args.no_h2d:
@@ -419,12 +499,12 @@ def main():
             if len(state["edges"]) else 0
         out = {
             "metric": "images/s (pHash + all-pairs Hamming scan + cluster membership)",
-            "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "value": value, "unit": "images/s", "n_gpus": world, "n_ranks_seen": n_ranks_seen, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak" if args.weak else "strong", "vs_baseline": None,
             "dtype": "u8 luma, int32 taps (i8 matrix cores), f64 DCT, 1-bit Hamming products (fp4 matrix cores, exact)", "data": "synthetic",
             "config": {
                 "workload": f"{n_total} synthetic {side}x{side} RGB images resident in HBM, hamming_threshold={args.threshold}, "
-                            f"band 16x4 (BASELINE configs[{1 if world == 1 else 2}])",
+                            f"band 16x4 (BASELINE configs[{1 if world == 1 else 2}]" + (f"; weak: {args.images} images per rank" if args.weak else "") + ")",
                 "images": n_total, "side": side, "hamming_threshold": args.threshold, "dhash": bool(args.dhash),
                 "partition": f"image i on rank i mod {world}; scan tiles dealt round-robin",
                 "exchange": ("none (one GPU)" if not distributed else "torch.distributed all_gather_into_tensor" if not exchange
@@ -437,6 +517,8 @@ def main():
             "edges": int(len(state["edges"])), "clusters": n_clusters,
             "kernel_ms": {"hash": hash_avg, "scan": scan_avg, **({"ssim": state["ssim_ms"]} if "ssim_ms" in state else {})},
             "kernel_ms_median": {"hash": float(np.median(hash_ms)), "scan": float(np.median(scan_ms))},
+            **({"phase_ms": phase_ms, "phase_ms_note": "max over ranks, device sync after every phase (not the pipelined step)"} if phase_ms else {}),
+            "self_launched": os.environ.get("KE_BENCH_SELF_LAUNCHED") == "1",
             **({"ssim": {"threshold": args.ssim_threshold, "pairs": state["ssim_pairs"], "quartiles": state["ssim_quartiles"],
                          "kept": state["ssim_kept"], "within_1e-4_of_threshold": state["ssim_near_threshold"],
                          "pairs_per_s": state["ssim_pairs"] / (state["ssim_ms"] * 1e-3),
@@ -454,6 +536,11 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": "profiles/hash_kernel_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE pass of this kernel at this "
                                            "size, gfx950 corrections applied; counters cannot be read inside this process)" if traffic else None},
+            # pHash + dHash in one launch: what kobato_eyes_amd.fastsig runs per batch (algorithmic bytes: 3*W*H read + 16 written)
+            "roofline_dual": {"bound": "hbm", "kernel": "ke_phash_fused_mx (dHash leg on)", "ms": float(np.mean(dual_ms)),
+                              "achieved": n_local * (img_bytes + 16) / (float(np.mean(dual_ms)) * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                              "unit": "GB/s", "frac": n_local * (img_bytes + 16) / (float(np.mean(dual_ms)) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              "images_per_s": n_local * world / (float(np.mean(dual_ms)) * 1e-3)},
             # scan: one v_mfma_f32_16x16x128_f8f6f4 (fp4) = 256 pairs x 128 one-bit products -> 256 flop per pair
             # against the dense fp4 peak; the 16 B/pair HBM convention of SURVEY 8d is kept beside it (operands are
             # reused from registers/LDS, so that fraction exceeds 1)

@@ -97,3 +97,21 @@ def test_rccl_entry_points_one_rank_and_the_reorder_step():
             ctx.free(d)
     finally:
         ex.close()
+
+
+def test_bench_self_launch_one_rank_over_rccl():
+    """`python bench.py --gpus 1 --self-launch`: the parent starts one rank under torch.distributed.run before touching the GPU;
+    the rank runs the whole step with the library's RCCL exchange (one-rank communicator) and the parent relays ONE line."""
+    import json
+
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--self-launch", "--steps", "2", "--warmup", "1",
+                          "--images", "6000", "--side", "256", "--no-cpu-baseline", "--no-h2d", "--no-decode"],
+                         capture_output=True, text=True, timeout=600, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, res.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["self_launched"] is True and out["n_gpus"] == 1 and out["n_ranks_seen"] == 1
+    assert out["config"]["exchange"].startswith(("ke_allgather_hashes", "torch.distributed"))
+    assert set(out["phase_ms"]) == {"hash", "allgather_hashes", "scan+count", "edge_merge", "labels"}
+    assert out["edges"] > 0 and out["value"] > 0

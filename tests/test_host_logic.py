@@ -493,3 +493,22 @@ def test_batches_read_ahead_reach_the_decoders_in_their_own_order(tmp_path, monk
     next(batches)
     batches.close()
     assert log["released"] == log["ahead"]
+
+
+def test_bench_self_launches_its_ranks_world_size_2_gloo():
+    """`python bench.py --gpus 2` typed without a launcher (as the driver types it at N = 1) must start its ranks as fresh
+    child processes under torch.distributed.run, relay rank 0's one JSON line on stdout and return the children's exit
+    code.  Without a GPU the ranks only meet (gloo) and count each other."""
+    import json
+
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--rendezvous-only"], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, res.stdout
+    out = json.loads(lines[0])
+    assert out["n_ranks_seen"] == 2 and out["world_size"] == 2 and out["self_launched"] is True
+    # a failing rank is the launcher's failure too
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rendezvous-only", "--no-such-flag"],
+                         capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0

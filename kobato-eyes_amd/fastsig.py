@@ -149,22 +149,39 @@ class _SharedBuffers:
     """Two page-aligned buffers that other processes can map: files in /dev/shm, unlinked when the object goes."""
 
     def __init__(self, nbytes: int, count: int = 2) -> None:
-        self.paths, self.maps = [], []
-        for stale in os.listdir("/dev/shm"):                 # what a process that died left behind
-            parts = stale.split("_")
-            if stale.startswith("ke_stage_") and len(parts) >= 3 and parts[2].isdigit() and not os.path.exists(f"/proc/{parts[2]}"):
-                try:
-                    os.unlink(os.path.join("/dev/shm", stale))
-                except OSError:
-                    pass
+        import fcntl
+
+        self.paths, self.maps, self._fds = [], [], []
+        # what a process that died left behind.  A live owner holds an flock on its files for as long as it runs, so a file
+        # whose lock can be taken has no owner -- whatever PID namespace that owner lived in (containers that share /dev/shm
+        # do not share /proc, so "no such PID here" proves nothing).
+        for stale in os.listdir("/dev/shm"):
+            if not stale.startswith("ke_stage_"):
+                continue
+            full = os.path.join("/dev/shm", stale)
+            try:
+                fd = os.open(full, os.O_RDWR)
+            except OSError:
+                continue
+            try:
+                fcntl.flock(fd, fcntl.LOCK_EX | fcntl.LOCK_NB)
+                os.unlink(full)
+            except OSError:
+                pass
+            finally:
+                os.close(fd)
         for k in range(count):
             path = f"/dev/shm/ke_stage_{os.getpid()}_{id(self):x}_{k}"
             fd = os.open(path, os.O_CREAT | os.O_EXCL | os.O_RDWR, 0o600)
             try:
+                fcntl.flock(fd, fcntl.LOCK_EX | fcntl.LOCK_NB)
                 os.ftruncate(fd, nbytes)
                 self.maps.append(mmap.mmap(fd, nbytes))
-            finally:
+            except BaseException:
                 os.close(fd)
+                os.unlink(path)
+                raise
+            self._fds.append(fd)                             # stays open: the lock lives as long as this descriptor
             self.paths.append(path)
         self.addresses = [np.frombuffer(m, np.uint8).ctypes.data for m in self.maps]
 
@@ -175,6 +192,12 @@ class _SharedBuffers:
             except OSError:
                 pass
         self.paths = []
+        for fd in self._fds:
+            try:
+                os.close(fd)
+            except OSError:
+                pass
+        self._fds = []
 
     def __del__(self) -> None:  # pragma: no cover
         self.close()
@@ -266,14 +289,30 @@ class _Pipeline:
       own through ``ke_hash_images``.
     """
 
-    def __init__(self, tasks: Sequence[Task], workers: int, chunk: int, device: int) -> None:
+    def __init__(self, tasks: Sequence[Task], workers: int, chunk: int, device: int,
+                 cancel_fn: Optional[Callable[[], bool]] = None) -> None:
         self.tasks, self.chunk, self.device = tasks, max(1, int(chunk)), device
         self.batch = max(self.chunk, int(os.environ.get("KE_GPU_BATCH", "32768")))
+        self.cancel_fn = cancel_fn
+        self.stopped = False
+        if cancel_fn is not None:
+            # somebody may want to stop: the reference asks after every file (src/core/fastsig.py:86-90).  Here the question is
+            # put between the chunks / rounds of the Pillow route and before every GPU decode call, and a batch is small
+            # enough that even a batch of slow files is abandoned within a chunk's time
+            self.batch = max(self.chunk, min(self.batch, int(os.environ.get("KE_GPU_BATCH_CANCELLABLE", "4096"))))
         self.workers = max(1, workers)
         self.pool = ThreadPoolExecutor(max_workers=self.workers)
         self.stage = _make_stage(device, int(os.environ.get("KE_STAGE_BYTES", str(256 << 20))), max(self.chunk, 4096))
         self.process_min = int(os.environ.get("KE_DECODE_PROCESS_MIN", "256"))
         self.bytes_per_image = 1 << 20                     # running estimate of a decoded image, for sizing the workers' jobs
+
+    def cancelled(self) -> bool:
+        if not self.stopped and self.cancel_fn is not None:
+            try:
+                self.stopped = bool(self.cancel_fn())
+            except Exception:
+                self.stopped = False
+        return self.stopped
 
     def _decode_into(self, path_text: str, view, alloc: dict):
         """One file -> (offset, width, height, channels) inside the staging buffer, ("spill", array) when it does not
@@ -333,7 +372,7 @@ class _Pipeline:
         first = 0
         try:
             for kind, (positions, blobs) in coded.items():
-                if not blobs:
+                if not blobs or self.cancelled():
                     continue
                 try:
                     if held is not None:                   # this kind's files are first .. first + len(positions) of the buffer
@@ -390,14 +429,18 @@ class _Pipeline:
         shared staging buffer to write them into; the buffer of round k is copied and hashed while round k+1 decodes."""
         pool = _process_pool(self.workers)
         shared_paths = self.stage.shared_paths
-        region = (self.stage.stage_bytes // self.workers) & ~4095
         previous, pending, at = None, [], 0
+        spilled: list = []                                        # larger than their worker's region: the thread route takes them
         try:
-            while at < len(todo):
+            while at < len(todo) and not self.cancelled():
                 slot, _ = self.stage.acquire()
+                # a worker's region holds at least two images of the size seen so far: camera-sized files mean fewer workers
+                # per round with a larger share of the buffer each, not files that are decoded, dropped and decoded again
+                active = int(max(1, min(self.workers, self.stage.stage_bytes // max(2 * self.bytes_per_image, 1))))
+                region = (self.stage.stage_bytes // active) & ~4095
                 per_job = int(min(64, max(1, region // (2 * max(self.bytes_per_image, 1)))))
                 pending = []
-                for r in range(self.workers):
+                for r in range(active):
                     part = todo[at:at + per_job]
                     if not part:
                         break
@@ -407,14 +450,11 @@ class _Pipeline:
                 if previous is not None:
                     self._collect(previous[1], previous[0], previous[2], out)
                     previous = None
-                positions, placed, spills, nbytes = [], [], [], 0
+                positions, placed, nbytes = [], [], 0
                 for part, fut in pending:
                     for k, res in zip(part, fut.result()):
-                        if res == "spill":                        # did not fit its worker's region: decoded here, hashed on its own
-                            arr = _read_pixels(str(self.tasks[k][1]))
-                            if arr is not None and arr.size:
-                                spills.append((len(positions), arr))
-                                positions.append(k)
+                        if res == "spill":
+                            spilled.append(k)
                         elif res is not None:
                             placed.append((len(positions), res))
                             positions.append(k)
@@ -422,30 +462,40 @@ class _Pipeline:
                 pending = []
                 if placed:
                     self.bytes_per_image = max(1, nbytes // len(placed))
+                elif spilled:
+                    self.bytes_per_image = min(self.stage.stage_bytes, self.bytes_per_image * 2)     # nothing fitted: larger regions next round
                 handle = None
                 if placed:
                     handle = self.stage.submit(slot, [d[0] for _, d in placed], [d[1] for _, d in placed],
                                                [d[2] for _, d in placed], [d[3] for _, d in placed])
-                previous = (positions, slot, ([i for i, _ in placed], handle, spills))
+                previous = (positions, slot, ([i for i, _ in placed], handle, []))
             if previous is not None:
                 self._collect(previous[1], previous[0], previous[2], out)
+                previous = None
         finally:
             for _, fut in pending:                                # nobody may still be writing into a staging buffer
                 try:
                     fut.result()
                 except Exception:
                     pass
+        if spilled:
+            self._decode_with_threads(sorted(spilled), out)
 
     def _decode_with_pillow(self, todo: Sequence[int], out: dict) -> None:
         if self.workers > 1 and len(todo) >= self.process_min and getattr(self.stage, "shared_paths", None):
             try:
                 return self._decode_with_processes(todo, out)
-            except BrokenProcessPool:                             # e.g. a __main__ the children cannot import: threads after all
-                _pools.pop(self.workers, None)
+            except (BrokenProcessPool, OSError):                  # e.g. a __main__ the children cannot import, a staging file
+                _pools.pop(self.workers, None)                    # that went away under a worker: threads after all
                 self.process_min = 1 << 62
                 todo = [k for k in todo if k not in out]
+        self._decode_with_threads(todo, out)
+
+    def _decode_with_threads(self, todo: Sequence[int], out: dict) -> None:
         previous = None                                           # (positions, slot, submitted) of the chunk on the GPU
         for c0 in range(0, len(todo), self.chunk):
+            if self.cancelled():
+                break
             positions = todo[c0:c0 + self.chunk]
             slot, futures = self._start(positions)                # decode of this chunk runs on the pool from here on
             if previous is not None:                              # ... while the previous one is copied and hashed
@@ -459,6 +509,12 @@ class _Pipeline:
         for fids, sigs in self.run_batches():
             yield from zip(fids, sigs)
 
+    @staticmethod
+    def _drop_reads(reads) -> None:
+        ahead = reads["ahead"] if reads else None
+        if ahead is not None and ahead.done() and not ahead.cancelled() and ahead.exception() is None and ahead.result() is not None:
+            ahead.result().release()
+
     def run_batches(self) -> Iterator[Tuple[List[int], List[Optional[Tuple[int, int]]]]]:
         """Yields ([file_id], [hashes | None]) batch by batch, in task order."""
         reads_next = None
@@ -469,15 +525,18 @@ class _Pipeline:
                 reads = reads_next
                 reads_next = self._start_reads(stop) if stop < len(self.tasks) else None
                 out: dict = {}
+                if self.cancelled():
+                    self._drop_reads(reads)
+                    return
                 refused = self._decode_on_gpu(reads, out)
                 todo = sorted([k for k in range(start, stop) if k not in reads["files"]] + refused)
                 self._decode_with_pillow(todo, out)
+                if self.stopped:                                  # abandoned half way: the caller returns what earlier batches gave
+                    return
                 yield [int(t[0]) for t in self.tasks[start:stop]], [out.get(k) for k in range(start, stop)]
         finally:
             self.pool.shutdown(wait=True, cancel_futures=True)    # no thread may still be writing into a staging buffer
-            ahead = reads_next["ahead"] if reads_next else None   # abandoned half way: the batch read ahead gives its buffer back
-            if ahead is not None and ahead.done() and not ahead.cancelled() and ahead.exception() is None and ahead.result() is not None:
-                ahead.result().release()
+            self._drop_reads(reads_next)                          # abandoned half way: the batch read ahead gives its buffer back
             try:
                 self.stage.wait(-1)
             except Exception:
@@ -503,7 +562,7 @@ def compute_signatures_mp(tasks: List[Task], *, max_workers: Optional[int] = Non
         except Exception:
             pass
 
-    pipeline = _Pipeline(tasks, workers, chunksize, device)
+    pipeline = _Pipeline(tasks, workers, chunksize, device, cancel_fn)
     if cancel_fn is None:                           # nobody to ask between files: whole batches at a time
         seen = 0
         for fids, sigs in pipeline.run_batches():

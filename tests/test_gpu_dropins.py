@@ -102,6 +102,9 @@ def test_fast_fill_on_decoder_processes(K, tmp_path, monkeypatch):
     monkeypatch.setenv("KE_STAGE_BYTES", str(300 * 1024))       # 100 KB per worker: most files do not fit their region
     squeezed = K.compute_signatures_mp(items, max_workers=3, chunksize=6)
     assert by_processes == by_threads and squeezed == by_threads
+    monkeypatch.setenv("KE_STAGE_BYTES", str(20 * 1024))        # no image fits a staging buffer at all: the workers report a
+    tiny = K.compute_signatures_mp(items, max_workers=3, chunksize=6)    # spill, the thread route takes the files, each hashed alone
+    assert tiny == by_threads
     assert [fid for fid, _, _ in by_threads] == [fid for fid, _ in items if fid < 70]
     for fid, ph, dh in by_processes:
         ep, ed = O.hash_image(arrays[fid])

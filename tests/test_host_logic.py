@@ -287,14 +287,20 @@ def test_fastsig_drops_missing_files_and_reports_progress(K, monkeypatch, tmp_pa
     out = fs.compute_signatures_mp(paths, max_workers=2, chunksize=4, progress=lambda d, t: seen.append((d, t)))
     assert [r[0] for r in out] == [1, 2, 3, 4, 5] and seen == [(6, 6)]
     assert all(r[1] < 0 for r in out)                      # stored signed
+    full = out
     calls = {"n": 0}
 
     def cancel():
         calls["n"] += 1
-        return calls["n"] > 2
+        return calls["n"] > 6
 
+    # the callback is asked between the chunks of the Pillow route and before each GPU decode call (4 times for these six
+    # files) and then once per result, as the reference does (src/core/fastsig.py:86-90): a prefix comes back
     out = fs.compute_signatures_mp(paths, max_workers=2, chunksize=4, cancel_fn=cancel)
-    assert len(out) == 2                                   # partial result after cancel
+    assert 0 < len(out) < len(full) and out == full[:len(out)]
+    calls["n"] = 0
+    stopped_early = fs.compute_signatures_mp(paths, max_workers=2, chunksize=4, cancel_fn=lambda: True)
+    assert stopped_early == []                             # asked before any work: nothing decoded, nothing returned
 
 
 def test_fastsig_progress_cadence_over_whole_batches(K, monkeypatch):
@@ -303,7 +309,7 @@ def test_fastsig_progress_cadence_over_whole_batches(K, monkeypatch):
     import kobato_eyes_amd.fastsig as fs
 
     class FakePipeline:
-        def __init__(self, tasks, workers, chunk, device):
+        def __init__(self, tasks, workers, chunk, device, cancel_fn=None):
             self.tasks = tasks
 
         def run_batches(self):

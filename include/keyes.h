@@ -230,6 +230,14 @@ int ke_hamming_scan(ke_ctx *ctx, const uint64_t *hashes, const int64_t *ids, con
                     int32_t band_count, double size_ratio, int64_t bucket_pair_cap, ke_edge *edges_out,
                     int64_t capacity, int64_t *n_edges_out, uint64_t *counters_out);
 
+/* The reference's "size=" funnel counter (src/dup/scanner.py:268-270 with _passes_size_ratio, :358-370): over every band
+ * and band value whose bucket the reference walks (>= 2 members, under the pair cap), the member pairs that pass the size
+ * filter -- pairs of equal file id included (the host takes those out, as for counters_out[3] of ke_hamming_scan).  A log
+ * figure, not part of the candidate set: asked for separately so that a scan nobody watches does not pay for it.
+ * size_ratio must be > 0.  hashes / sizes: host or device.  Blocks. */
+int ke_band_pairs_after_size(ke_ctx *ctx, const uint64_t *hashes, const int64_t *sizes, int64_t n, int32_t band_bits,
+                             int32_t band_count, double size_ratio, int64_t bucket_pair_cap, uint64_t *count_out);
+
 /* Connected components of the candidate graph (DisjointSet, src/dup/scanner.py:176-200,
  * 304-318; ClusterBuilder union-find, src/dup/cluster.py:30-46).  HOST function, no device
  * work: label_out[v] = smallest node of v's component for v < n_nodes. */

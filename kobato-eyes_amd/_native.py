@@ -25,7 +25,8 @@ FILTER_LANCZOS, FILTER_BILINEAR, FILTER_BICUBIC = 0, 1, 2   # include/keyes.h KE
 EXPORTS = (
     "ke_abi_version", "ke_create", "ke_create_error", "ke_destroy", "ke_last_error", "ke_set_stream",
     "ke_get_stream", "ke_synchronize", "ke_device_info", "ke_malloc", "ke_free", "ke_memcpy",
-    "ke_hash_images", "ke_hash_uniform", "ke_hash_images_ex", "ke_hash_uniform_ex", "ke_luma_tiles_uniform", "ke_hamming_scan",
+    "ke_hash_images", "ke_hash_uniform", "ke_hash_images_ex", "ke_hash_uniform_ex", "ke_luma_tiles_uniform", "ke_hamming_scan", "ke_band_pairs_after_size",
+    "ke_band_pairs_after_size",
     "ke_stage_create", "ke_stage_create_shared", "ke_stage_destroy", "ke_stage_acquire", "ke_stage_submit_hash", "ke_stage_wait",
     "ke_comm_unique_id", "ke_comm_create", "ke_comm_destroy", "ke_allgather_u64", "ke_allgather_hashes", "ke_allgather_edges",
     "ke_interleave_shards", "ke_host_alloc", "ke_host_free", "ke_host_pack", "ke_host_read_files", "ke_jpeg_probe", "ke_jpeg_decode", "ke_png_probe", "ke_png_decode", "ke_jpeg_caveats", "ke_png_caveats", "ke_cluster_labels", "ke_ssim_pairs_uniform", "ke_ssim_pairs", "ke_ssim_set_mode", "ke_resize_luma_uniform", "ke_fit_luma_uniform", "ke_tile_ahash", "ke_sad_pairs", "ke_synth_rgb",
@@ -130,6 +131,7 @@ def load_library() -> C.CDLL:
         lib.ke_png_decode.argtypes = [vp, vp, vp, vp, i64, vp, vp, vp]
         lib.ke_jpeg_caveats.argtypes = [vp, vp, vp, i64, vp]
         lib.ke_png_caveats.argtypes = [vp, vp, vp, i64, vp]
+        lib.ke_band_pairs_after_size.argtypes = [vp, vp, vp, i64, i32, i32, dbl, i64, vp]
         lib.ke_hamming_scan.argtypes = [vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, dbl, i64, vp, i64,
                                         C.POINTER(i64), vp]
         lib.ke_cluster_labels.argtypes = [vp, i64, i64, vp]
@@ -146,7 +148,7 @@ def load_library() -> C.CDLL:
         lib.ke_last_kernel_ms.argtypes = [vp, i32]
         lib.ke_last_kernel_ms.restype = dbl
         for name in ("ke_set_stream", "ke_synchronize", "ke_device_info", "ke_malloc", "ke_free", "ke_memcpy",
-                     "ke_hash_images", "ke_hash_uniform", "ke_hash_images_ex", "ke_hash_uniform_ex", "ke_luma_tiles_uniform", "ke_hamming_scan",
+                     "ke_hash_images", "ke_hash_uniform", "ke_hash_images_ex", "ke_hash_uniform_ex", "ke_luma_tiles_uniform", "ke_hamming_scan", "ke_band_pairs_after_size",
                      "ke_stage_create", "ke_stage_create_shared", "ke_stage_destroy", "ke_stage_acquire", "ke_stage_submit_hash", "ke_stage_wait",
                      "ke_comm_unique_id", "ke_comm_create", "ke_comm_destroy", "ke_allgather_u64", "ke_allgather_hashes", "ke_allgather_edges",
                      "ke_interleave_shards", "ke_host_alloc", "ke_host_free", "ke_host_pack", "ke_host_read_files", "ke_jpeg_probe", "ke_jpeg_decode", "ke_png_probe", "ke_png_decode", "ke_jpeg_caveats", "ke_png_caveats", "ke_cluster_labels", "ke_ssim_pairs_uniform", "ke_ssim_pairs", "ke_ssim_set_mode", "ke_resize_luma_uniform", "ke_fit_luma_uniform", "ke_tile_ahash",
@@ -339,15 +341,18 @@ class Context:
 
     # -- pinned staging ---------------------------------------------------------------------
     def stage_create(self, bytes_per_buffer: int, max_images: int, n_buffers: int = 2) -> None:
+        self._stage_geom = None                              # whoever cached "my buffers are in place" (fastsig) must look again
         self._check(self._lib.ke_stage_create(self._h, int(bytes_per_buffer), int(max_images), int(n_buffers)), "ke_stage_create")
 
     def stage_create_shared(self, addresses, bytes_per_buffer: int, max_images: int) -> None:
         """Staging on the caller's page-aligned buffers (shared memory that decoder processes write into)."""
         ptrs = (C.c_void_p * len(addresses))(*[int(a) for a in addresses])
+        self._stage_geom = None
         self._check(self._lib.ke_stage_create_shared(self._h, ptrs, int(bytes_per_buffer), int(max_images), len(addresses)),
                     "ke_stage_create_shared")
 
     def stage_destroy(self) -> None:
+        self._stage_geom = None
         self._check(self._lib.ke_stage_destroy(self._h), "ke_stage_destroy")
 
     def stage_acquire(self):
@@ -731,6 +736,16 @@ class Context:
             if n_edges.value <= cap:
                 return edges[: n_edges.value], counters
             cap = int(n_edges.value)  # overflow protocol: retry with the reported size
+
+    def band_pairs_after_size(self, hashes, sizes, n: int, *, band_bits=16, band_count=4, size_ratio: float, bucket_pair_cap: int = 0) -> int:
+        """The reference's "size=" funnel counter before pairs of equal file id are taken out (ke_band_pairs_after_size)."""
+        hashes = np.ascontiguousarray(hashes, dtype=np.uint64) if isinstance(hashes, np.ndarray) else hashes
+        sizes = np.ascontiguousarray(sizes, dtype=np.int64) if isinstance(sizes, np.ndarray) else sizes
+        out = np.zeros(1, np.uint64)
+        with self._lock:
+            self._check(self._lib.ke_band_pairs_after_size(self._h, _addr(hashes), _addr(sizes), n, band_bits, band_count,
+                                                           float(size_ratio), int(bucket_pair_cap), _addr(out)), "ke_band_pairs_after_size")
+        return int(out[0])
 
     def cluster_labels(self, edges: np.ndarray, n_nodes: int) -> np.ndarray:
         edges = np.ascontiguousarray(edges, dtype=EDGE_DTYPE)

@@ -901,6 +901,43 @@ KE_API int ke_hamming_scan(ke_ctx *ctx, const uint64_t *hashes, const int64_t *i
     return KE_OK;
 }
 
+KE_API int ke_band_pairs_after_size(ke_ctx *ctx, const uint64_t *hashes, const int64_t *sizes, int64_t n, int32_t band_bits,
+                                    int32_t band_count, double size_ratio, int64_t bucket_pair_cap, uint64_t *count_out) {
+    if (!ctx) return KE_EINVAL;
+    if (!count_out) return ke_fail(ctx, KE_EINVAL, "count_out is NULL");
+    if (n < 0 || (n > 0 && (!hashes || !sizes))) return ke_fail(ctx, KE_EINVAL, "hashes / sizes is NULL");
+    if (band_bits <= 0 || band_count <= 0 || (int64_t)band_bits * band_count > 64) return ke_fail(ctx, KE_EINVAL, "bad band config");
+    if (!(size_ratio > 0.0)) return ke_fail(ctx, KE_EINVAL, "size_ratio must be positive (without a size filter the counter equals the bucket pairs)");
+    *count_out = 0;
+    if (n < 2) return KE_OK;
+    KE_HIP(ctx, hipSetDevice(ctx->device));
+    const void *d_h = hashes, *d_s = sizes;
+    if (!ke_is_device_ptr(hashes) || !ke_is_device_ptr(sizes)) {
+        void *base;
+        KE_TRY(ke_reserve(ctx, KE_BUF_SCAN_IN, (size_t)n * 24, &base));
+        if (!ke_is_device_ptr(hashes)) {
+            KE_HIP(ctx, hipMemcpyAsync(base, hashes, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+            d_h = base;
+        }
+        if (!ke_is_device_ptr(sizes)) {
+            void *d = (uint8_t *)base + (size_t)n * 16;
+            KE_HIP(ctx, hipMemcpyAsync(d, sizes, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+            d_s = d;
+        }
+    }
+    void *tmp;
+    KE_TRY(ke_reserve(ctx, KE_BUF_SCAN_CNT, 4 * sizeof(unsigned long long), &tmp));
+    unsigned long long *d_cnt = (unsigned long long *)tmp;
+    KE_HIP(ctx, hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), ctx->stream));
+    KE_TRY(ke_launch_band_pairs_after_size(ctx, (const uint64_t *)d_h, (const int64_t *)d_s, n, band_bits, band_count, size_ratio,
+                                           bucket_pair_cap, d_cnt));
+    unsigned long long h = 0;
+    KE_HIP(ctx, hipMemcpyAsync(&h, d_cnt, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    KE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *count_out = h;
+    return KE_OK;
+}
+
 // ---- ssim ------------------------------------------------------------------------------------
 KE_API int ke_ssim_set_mode(ke_ctx *ctx, int32_t mode) {
     if (!ctx) return KE_EINVAL;

@@ -197,6 +197,8 @@ int ke_launch_resize_group(ke_ctx *ctx, const KeHashGroup &g, int ow, int oh, in
 int ke_launch_tile_ahash(ke_ctx *ctx, const uint8_t *d_tiles, int64_t n, int grid, int tile, uint64_t *d_bits);
 int ke_launch_sad_pairs(ke_ctx *ctx, const uint8_t *d_thumbs, int64_t pixels, const int64_t *d_pa, const int64_t *d_pb,
                         int64_t n_pairs, uint64_t *d_out);
+int ke_launch_band_pairs_after_size(ke_ctx *ctx, const uint64_t *d_hashes, const int64_t *d_sizes, int64_t n, int band_bits,
+                                    int band_count, double ratio, int64_t bucket_pair_cap, unsigned long long *d_out);
 int ke_launch_scan(ke_ctx *ctx, const uint64_t *d_hashes, const int64_t *d_ids, const int64_t *d_sizes, int64_t n,
                    int part_index, int part_count, int threshold, int band_bits, int band_count, double size_ratio,
                    int64_t bucket_pair_cap, ke_edge *d_edges, int64_t capacity, unsigned long long *d_counters,

@@ -264,7 +264,111 @@ __global__ void ke_run_lengths(const uint64_t *__restrict__ keys, const uint32_t
     if (len >= 2 && (!cap || p <= cap)) atomicAdd(out, p);
 }
 
+// ---- the "size=" funnel counter (src/dup/scanner.py:268-270, 358-370): bucket pairs that pass the size filter ----------
+// Positions sorted by size once; per band a stable sort by band value then leaves every bucket contiguous with its sizes
+// ascending, and a member's partners are the earlier members whose size is large enough -- found by a binary search whose
+// test is the reference's own float division (smaller / larger >= ratio, monotone in the smaller size).
+__global__ void ke_size_keys(const int64_t *__restrict__ sizes, int64_t n, uint64_t *__restrict__ keys, uint32_t *__restrict__ pos) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t s = sizes[i];
+    keys[i] = s > 0 ? (uint64_t)s : 0ull;                     // a missing / non-positive size passes with everyone
+    pos[i] = (uint32_t)i;
+}
+
+__global__ void ke_band_keys_of(const uint64_t *__restrict__ hashes, const uint32_t *__restrict__ order, int64_t n, int shift,
+                                uint64_t mask, uint64_t *__restrict__ keys) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) keys[i] = (hashes[order[i]] >> shift) & mask;
+}
+
+__global__ void ke_run_flags(const uint64_t *__restrict__ keys, int64_t n, uint32_t *__restrict__ flags) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flags[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
+}
+
+// rank[i] = number of the run position i lies in (inclusive sum of the flags, minus one); starts[r] = first position of run r
+__global__ void ke_run_starts(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ rank1, int64_t n, uint32_t *__restrict__ starts) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (i == 0 || keys[i] != keys[i - 1]) starts[rank1[i] - 1] = (uint32_t)i;
+    if (i == n - 1) starts[rank1[i]] = (uint32_t)n;
+}
+
+__global__ void ke_size_pairs(const uint64_t *__restrict__ sz, const uint32_t *__restrict__ rank1, const uint32_t *__restrict__ starts,
+                              int64_t n, double ratio, unsigned long long cap, unsigned long long *out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long c = 0;
+    if (i < n) {
+        const uint32_t r = rank1[i] - 1;
+        const int64_t st = starts[r], en = starts[r + 1], m = en - st;
+        if (m >= 2 && (!cap || (unsigned long long)m * (unsigned long long)(m - 1) / 2 <= cap)) {
+            const uint64_t si = sz[i];
+            if (si == 0) {
+                c = (unsigned long long)(i - st);             // every earlier member is size-free as well
+            } else {
+                int64_t lo = st, hi = i;                      // first member with a positive size
+                while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (sz[mid] == 0) lo = mid + 1; else hi = mid; }
+                const int64_t free_n = lo - st;
+                hi = i;                                       // first positive member j < i with sz[j] / si >= ratio
+                const double larger = (double)si;
+                while (lo < hi) {
+                    const int64_t mid = (lo + hi) >> 1;
+                    if ((double)sz[mid] / larger >= ratio) hi = mid; else lo = mid + 1;
+                }
+                c = (unsigned long long)(i - lo) + (unsigned long long)free_n;
+            }
+        }
+    }
+    for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d);
+    __shared__ unsigned long long part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0 && (part[0] | part[1] | part[2] | part[3])) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
+}
+
 }  // namespace
+
+int ke_launch_band_pairs_after_size(ke_ctx *ctx, const uint64_t *d_hashes, const int64_t *d_sizes, int64_t n, int band_bits,
+                                    int band_count, double ratio, int64_t bucket_pair_cap, unsigned long long *d_out) {
+    if (n > 0x7fffffffLL) return ke_fail(ctx, KE_EUNSUPPORTED, "the size funnel counter needs n < 2^31");
+    const unsigned long long cap = bucket_pair_cap > 0 ? (unsigned long long)bucket_pair_cap : 0ull;
+    size_t t_size = 0, t_band = 0, t_scan = 0;
+    KE_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, t_size, (const uint64_t *)nullptr, (uint64_t *)nullptr,
+                                                   (const uint32_t *)nullptr, (uint32_t *)nullptr, (int)n, 0, 64, ctx->stream));
+    KE_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, t_band, (const uint64_t *)nullptr, (uint64_t *)nullptr,
+                                                   (const uint64_t *)nullptr, (uint64_t *)nullptr, (int)n, 0, band_bits, ctx->stream));
+    KE_HIP(ctx, hipcub::DeviceScan::InclusiveSum(nullptr, t_scan, (const uint32_t *)nullptr, (uint32_t *)nullptr, (int)n, ctx->stream));
+    const size_t temp_bytes = std::max(t_size, std::max(t_band, t_scan));
+    const size_t kb = ((size_t)n * 8 + 255) & ~(size_t)255, pb = ((size_t)(n + 1) * 4 + 255) & ~(size_t)255;
+    void *scratch;
+    KE_TRY(ke_reserve(ctx, KE_BUF_SCAN_AUX, 4 * kb + 4 * pb + temp_bytes + 256, &scratch));
+    uint8_t *sp = (uint8_t *)scratch;
+    uint64_t *k_a = (uint64_t *)sp, *k_b = (uint64_t *)(sp + kb), *sz_sorted = (uint64_t *)(sp + 2 * kb), *sz_band = (uint64_t *)(sp + 3 * kb);
+    uint32_t *p_a = (uint32_t *)(sp + 4 * kb), *order = (uint32_t *)(sp + 4 * kb + pb), *rank1 = (uint32_t *)(sp + 4 * kb + 2 * pb),
+             *starts = (uint32_t *)(sp + 4 * kb + 3 * pb);
+    void *temp = sp + 4 * kb + 4 * pb;
+    const dim3 grid((unsigned)((n + 255) / 256)), blk(256);
+    const uint64_t mask = band_bits >= 64 ? ~0ull : ((1ull << band_bits) - 1ull);
+    hipLaunchKernelGGL(ke_size_keys, grid, blk, 0, ctx->stream, d_sizes, n, k_a, p_a);
+    size_t tb = temp_bytes;
+    KE_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(temp, tb, (const uint64_t *)k_a, sz_sorted, (const uint32_t *)p_a, order, (int)n, 0, 64, ctx->stream));
+    for (int b = 0; b < band_count; ++b) {
+        hipLaunchKernelGGL(ke_band_keys_of, grid, blk, 0, ctx->stream, d_hashes, (const uint32_t *)order, n, b * band_bits, mask, k_a);
+        tb = temp_bytes;
+        KE_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(temp, tb, (const uint64_t *)k_a, k_b, (const uint64_t *)sz_sorted, sz_band, (int)n, 0,
+                                                       band_bits, ctx->stream));
+        uint32_t *flags = p_a;                                // the positions are not needed again
+        hipLaunchKernelGGL(ke_run_flags, grid, blk, 0, ctx->stream, (const uint64_t *)k_b, n, flags);
+        tb = temp_bytes;
+        KE_HIP(ctx, hipcub::DeviceScan::InclusiveSum(temp, tb, (const uint32_t *)flags, rank1, (int)n, ctx->stream));
+        hipLaunchKernelGGL(ke_run_starts, grid, blk, 0, ctx->stream, (const uint64_t *)k_b, (const uint32_t *)rank1, n, starts);
+        hipLaunchKernelGGL(ke_size_pairs, grid, blk, 0, ctx->stream, (const uint64_t *)sz_band, (const uint32_t *)rank1,
+                           (const uint32_t *)starts, n, ratio, cap, d_out);
+        KE_HIP(ctx, hipGetLastError());
+    }
+    return KE_OK;
+}
 
 int ke_launch_scan(ke_ctx *ctx, const uint64_t *d_hashes, const int64_t *d_ids, const int64_t *d_sizes, int64_t n,
                    int part_index, int part_count, int threshold, int band_bits, int band_count, double size_ratio,

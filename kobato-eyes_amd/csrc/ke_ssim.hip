@@ -297,7 +297,9 @@ __device__ __forceinline__ uint32_t luma_sum(uint32_t p, bool shifted) {
 }
 __device__ __forceinline__ float byte2_f32(uint32_t s) { return (float)((s >> 16) & 0xFFu); }   // v_cvt_f32_ubyte2
 
-// The C dwords of an aligned quad -> four luma values as floats (integers 0..255)
+// The C dwords of an aligned quad -> four luma values as floats (integers 0..255).  (A float32 form -- three byte->float
+// conversions, an exact multiply-add chain, floor -- costs the same issue cycles as these 2 v_dot4 + v_lshl_add + conversion:
+// its first fma with the 0.5 is a three-source instruction again, and it needs 10 more registers.)
 template <int C>
 __device__ __forceinline__ void quad_to_f32(const uint32_t *q, float *out) {
     if (C == 1) {
@@ -317,11 +319,37 @@ __device__ __forceinline__ void quad_to_f32(const uint32_t *q, float *out) {
 // keeps the compiler from folding (float)a + (float)b into an integer add + one more conversion (costs an instruction)
 __device__ __forceinline__ float opaque(float x) { asm("" : "+v"(x)); return x; }
 
+// Packed float32 operations with operand selection (VOP3P op_sel / neg): one instruction where the compiler's own choice for
+// "difference and sum of the two halves of a pair" is two or three.
+__device__ __forceinline__ ke_f2 pk_diff_sum(ke_f2 v) {          // {v.lo - v.hi, v.lo + v.hi}
+    ke_f2 r;
+    asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,0]" : "=v"(r) : "v"(v));
+    return r;
+}
+__device__ __forceinline__ ke_f2 pk_sum_diff(ke_f2 v) {          // {v.lo + v.hi, v.lo - v.hi}
+    ke_f2 r;
+    asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_lo:[0,0] neg_hi:[0,1]" : "=v"(r) : "v"(v));
+    return r;
+}
+__device__ __forceinline__ ke_f2 pk_mul_hh_lh(ke_f2 x, ke_f2 y) {  // {x.hi * y.hi, x.lo * y.hi}
+    ke_f2 r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,1]" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
+__device__ __forceinline__ ke_f2 pk_mul_ll_hl(ke_f2 x, ke_f2 y) {  // {x.lo * y.lo, x.hi * y.lo}
+    ke_f2 r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
+
 template <int C, int PX, bool AL>
 __global__ __launch_bounds__(256, 2) void ke_ssim_fast(const SsimArgs a) {
     constexpr int NW = PX / 4;
     const int lane = threadIdx.x & 63;
-    const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    // everything that names the work item is the same for the 64 lanes: kept in scalar registers, so that a row's loads are
+    // "scalar row pointer + this lane's constant byte offset" and the row loop spends no vector instruction on addresses
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t item = (int64_t)blockIdx.x * 4 + wave;
     if (item >= a.n_items) return;
     const int64_t pair = item / a.items_per_pair;
     const int sub = (int)(item % a.items_per_pair);
@@ -331,6 +359,7 @@ __global__ __launch_bounds__(256, 2) void ke_ssim_fast(const SsimArgs a) {
     const int y0 = band * a.band_rows;                      // first halo row; interior rows y0 + 3 ..
     const int y_last = min(a.h - 3, y0 + 3 + a.band_rows) + 3;   // one past the last halo row (>= y0 + 7)
     const size_t img_bytes = (size_t)a.w * a.h * C;
+    const uint32_t row_bytes = (uint32_t)a.w * C;
     const uint8_t *A = a.images + (size_t)a.pa[pair] * img_bytes;
     const uint8_t *B = a.images + (size_t)a.pb[pair] * img_bytes;
     const uint32_t dA = (uint32_t)((uintptr_t)A & 3), dB = (uint32_t)((uintptr_t)B & 3);
@@ -338,9 +367,9 @@ __global__ __launch_bounds__(256, 2) void ke_ssim_fast(const SsimArgs a) {
     const uint32_t lastA = (dA + (uint32_t)img_bytes - 1u) & ~3u, lastB = (dB + (uint32_t)img_bytes - 1u) & ~3u;
     int xc = x0 + PX * lane;
     xc = xc < a.w ? xc : a.w - 1;
-    int xq[NW];
+    uint32_t voff[NW];                                      // AL: byte offset of each 4-pixel group inside its row
 #pragma unroll
-    for (int n = 0; n < NW; ++n) xq[n] = min(x0 + PX * lane + 4 * n, a.w - 4);
+    for (int n = 0; n < NW; ++n) voff[n] = (uint32_t)min(x0 + PX * lane + 4 * n, a.w - 4) * C;
 
     // column k of this lane counts iff it is an interior column of the block and of the image
     bool ink[PX];                                           // loop-invariant lane masks (scalar register pairs)
@@ -366,41 +395,47 @@ __global__ __launch_bounds__(256, 2) void ke_ssim_fast(const SsimArgs a) {
     // not depend on how its rows are cut into bands or on the order of the partial sums: one launch or many give equal bits.
     long long local = 0;
 
-    // The luma of the NEXT row travels from iteration to iteration as floats: its loads are issued at the top of an
-    // iteration and converted at the bottom, behind the arithmetic of the current row.
-    float xa[PX], xb[PX];
+    // The luma of the NEXT row travels from iteration to iteration as floats -- (La, Lb) of a column in one register pair:
+    // its loads are issued at the top of an iteration and converted at the bottom, behind the arithmetic of the current row.
+    ke_f2 xab[PX];
     uint32_t qa[NW][C], qb[NW][C];
     auto issue = [&](int y) {                               // raw quads of row y (clamped to the band)
-        const int yc = min(y, y_last - 1);
+        const uint32_t yc = (uint32_t)min(y, y_last - 1);
+        const uint8_t *ra = A + (size_t)(yc * row_bytes), *rb = B + (size_t)(yc * row_bytes);
 #pragma unroll
         for (int n = 0; n < NW; ++n) {
             if (AL) {
-                const uint32_t o = ((uint32_t)yc * (uint32_t)a.w + (uint32_t)xq[n]) * C;
+                // the 32-bit offset is made opaque here so that its zero-extension stays next to the load: hoisted out of the
+                // loop it becomes a 64-bit register pair and every load pays a 64-bit vector add instead of using the
+                // "scalar base + 32-bit vector offset" addressing mode
+                uint32_t vo = voff[n];
+                asm volatile("" : "+v"(vo));
 #pragma unroll
                 for (int k = 0; k < C; ++k) {
-                    qa[n][k] = reinterpret_cast<const uint32_t *>(A + o)[k];
-                    qb[n][k] = reinterpret_cast<const uint32_t *>(B + o)[k];
+                    qa[n][k] = *reinterpret_cast<const uint32_t *>(ra + vo + 4 * k);
+                    qb[n][k] = *reinterpret_cast<const uint32_t *>(rb + vo + 4 * k);
                 }
             } else {
-                const uint32_t off = ((uint32_t)yc * (uint32_t)a.w + (uint32_t)xc) * C + (uint32_t)n * 4 * C;
+                const uint32_t off = (yc * (uint32_t)a.w + (uint32_t)xc) * C + (uint32_t)n * 4 * C;
                 qa[n][0] = load_luma4<C>(A0, dA + off, lastA);
                 qb[n][0] = load_luma4<C>(B0, dB + off, lastB);
             }
         }
     };
     auto convert = [&]() {
+        float fa[4], fb[4];
 #pragma unroll
         for (int n = 0; n < NW; ++n) {
             if (AL) {
-                quad_to_f32<C>(qa[n], xa + 4 * n);
-                quad_to_f32<C>(qb[n], xb + 4 * n);
+                quad_to_f32<C>(qa[n], fa);
+                quad_to_f32<C>(qb[n], fb);
             } else {
-                quad_to_f32<1>(qa[n], xa + 4 * n);
-                quad_to_f32<1>(qb[n], xb + 4 * n);
+                quad_to_f32<1>(qa[n], fa);
+                quad_to_f32<1>(qb[n], fb);
             }
-        }
 #pragma unroll
-        for (int k = 0; k < PX; ++k) { xa[k] = opaque(xa[k]); xb[k] = opaque(xb[k]); }
+            for (int k = 0; k < 4; ++k) xab[4 * n + k] = ke_f2{fa[k], fb[k]};
+        }
     };
     // slide the vertical windows: - the row that leaves (ring slot `slot` holds it; zeros at the band start), + the new row
     auto vertical = [&](auto slot_c) {
@@ -409,56 +444,64 @@ __global__ __launch_bounds__(256, 2) void ke_ssim_fast(const SsimArgs a) {
         for (int k = 0; k < PX; ++k) {
             vs[k] = vs[k] - ring[slot][k];
             vq[k] = pk_fma(-ring[slot][k], ring[slot][k], vq[k]);
-            ring[slot][k] = ke_f2{xa[k] + xb[k], xa[k] - xb[k]};
+            ring[slot][k] = pk_sum_diff(xab[k]);             // (La + Lb, La - Lb): one packed add
             vs[k] = vs[k] + ring[slot][k];
             vq[k] = pk_fma(ring[slot][k], ring[slot][k], vq[k]);
         }
     };
     auto outputs = [&](bool valid) {
-        ke_f2 ws[PX + 6], wq[PX + 6];                       // [left 3 | own PX | right 3]
-#pragma unroll
-        for (int k = 0; k < PX; ++k) { ws[3 + k] = vs[k]; wq[3 + k] = vq[k]; }
+        // the 7-wide horizontal windows of this lane's PX columns over w = [left 3 | own PX | right 3]: suffix sums of
+        // w[0..6] towards the left, prefix sums of w[7..] towards the right, window k = suffix[k] + prefix[k + 6]
+        // (2.25 packed adds per column and quantity pair instead of 2.5 for a sliding sum); the halo values, which arrive
+        // through the LDS crossbar, sit at the far ends of both chains
+        ke_f2 ls[3], lq[3], rs[3], rq[3];
 #pragma unroll
         for (int e = 0; e < 3; ++e) {
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-                ws[e][c] = __int_as_float(__builtin_amdgcn_ds_bpermute(addr_l, __float_as_int(vs[PX - 3 + e][c])));
-                wq[e][c] = __int_as_float(__builtin_amdgcn_ds_bpermute(addr_l, __float_as_int(vq[PX - 3 + e][c])));
-                ws[PX + 3 + e][c] = __int_as_float(__builtin_amdgcn_ds_bpermute(addr_r, __float_as_int(vs[e][c])));
-                wq[PX + 3 + e][c] = __int_as_float(__builtin_amdgcn_ds_bpermute(addr_r, __float_as_int(vq[e][c])));
+                ls[e][c] = __int_as_float(__builtin_amdgcn_ds_bpermute(addr_l, __float_as_int(vs[PX - 3 + e][c])));
+                lq[e][c] = __int_as_float(__builtin_amdgcn_ds_bpermute(addr_l, __float_as_int(vq[PX - 3 + e][c])));
+                rs[e][c] = __int_as_float(__builtin_amdgcn_ds_bpermute(addr_r, __float_as_int(vs[e][c])));
+                rq[e][c] = __int_as_float(__builtin_amdgcn_ds_bpermute(addr_r, __float_as_int(vq[e][c])));
             }
         }
-        // own columns first (the halo values are still in flight), then the halos
-        ke_f2 hs = (ws[3] + ws[4]) + (ws[5] + ws[6]), hq = (wq[3] + wq[4]) + (wq[5] + wq[6]);
-        hs = hs + ((ws[0] + ws[1]) + ws[2]);
-        hq = hq + ((wq[0] + wq[1]) + wq[2]);
-        float num[PX], den[PX];
+        auto w_s = [&](int j) -> ke_f2 { return j < 3 ? ls[j] : j < PX + 3 ? vs[j - 3] : rs[j - PX - 3]; };
+        auto w_q = [&](int j) -> ke_f2 { return j < 3 ? lq[j] : j < PX + 3 ? vq[j - 3] : rq[j - PX - 3]; };
+        ke_f2 Ls[7], Lq[7], Rs[PX - 1], Rq[PX - 1];
+        Ls[6] = w_s(6); Lq[6] = w_q(6);
+#pragma unroll
+        for (int j = 5; j >= 0; --j) { Ls[j] = w_s(j) + Ls[j + 1]; Lq[j] = w_q(j) + Lq[j + 1]; }
+        Rs[0] = w_s(7); Rq[0] = w_q(7);
+#pragma unroll
+        for (int i = 1; i < PX - 1; ++i) { Rs[i] = Rs[i - 1] + w_s(7 + i); Rq[i] = Rq[i - 1] + w_q(7 + i); }
+        ke_f2 nd[PX];                                       // (numerator, denominator) of the column's SSIM value
 #pragma unroll
         for (int k = 0; k < PX; ++k) {
-            if (k > 0) { hs = hs + (ws[k + 6] - ws[k - 1]); hq = hq + (wq[k + 6] - wq[k - 1]); }
+            const ke_f2 hs = k == 0 ? Ls[0] : k <= 6 ? Ls[k] + Rs[k - 1] : Rs[k - 1];
+            const ke_f2 hq = k == 0 ? Lq[0] : k <= 6 ? Lq[k] + Rq[k - 1] : Rq[k - 1];
             const ke_f2 P = hs * hs;
             const ke_f2 e2 = pk_fma(hs, hs, -P);
             const ke_f2 e1 = pk_fma(ke_f2{49.f, 49.f}, hq, -P);
             const ke_f2 N = e1 - e2;                        // (Np, Nm)
-            // difference and sum of the two halves: two plain VALU operations each (the packed form with operand swizzles
-            // the compiler would pick costs three)
-            const ke_f2 d1 = {opaque(P[0] - P[1]), opaque(P[0] + P[1])};
-            const ke_f2 d2 = {opaque(N[0] - N[1]), opaque(N[0] + N[1])};
+            const ke_f2 d1 = pk_diff_sum(P);                // (SP^2 - SM^2, SP^2 + SM^2)
+            const ke_f2 d2 = pk_diff_sum(N);                // (Np - Nm, Np + Nm)
             const ke_f2 ab1 = pk_fma(d1, ke_f2{c1, c1}, ke_f2{C1, C1});   // (A1, B1)
             const ke_f2 ab2 = pk_fma(d2, ke_f2{c2, c2}, ke_f2{C2, C2});   // (A2, B2)
-            const ke_f2 nd = ab1 * ab2;
-            num[k] = ink[k] ? nd[0] : 0.f;
-            den[k] = nd[1];
+            nd[k] = ab1 * ab2;
+            nd[k][0] = ink[k] ? nd[k][0] : 0.f;
         }
-        // four quotients per reciprocal: n0/d0 + .. + n3/d3 = (N01 D23 + N23 D01) / (D01 D23); every d >= C1*C2 = 9e-8
+        // four quotients per reciprocal: n0/d0 + .. + n3/d3 = (N01 D23 + N23 D01) / (D01 D23); every d >= C1*C2 = 9e-8.
+        // (D01, n0 d1) and then (D01 D23, N01 D23) come out of one packed multiply each
         float rowsum = 0.f;
 #pragma unroll
         for (int g = 0; g < PX; g += 4) {
-            const float D01 = den[g] * den[g + 1], D23 = den[g + 2] * den[g + 3];
-            const float N01 = __builtin_fmaf(num[g], den[g + 1], num[g + 1] * den[g]);
-            const float N23 = __builtin_fmaf(num[g + 2], den[g + 3], num[g + 3] * den[g + 2]);
-            const float Nn = __builtin_fmaf(N01, D23, N23 * D01);
-            rowsum = __builtin_fmaf(Nn, __builtin_amdgcn_rcpf(D01 * D23), rowsum);
+            ke_f2 u = pk_mul_hh_lh(nd[g], nd[g + 1]);                  // (d0 d1, n0 d1)
+            u[1] = __builtin_fmaf(nd[g + 1][0], nd[g][1], u[1]);       // (D01, N01)
+            ke_f2 v = pk_mul_hh_lh(nd[g + 2], nd[g + 3]);
+            v[1] = __builtin_fmaf(nd[g + 3][0], nd[g + 2][1], v[1]);   // (D23, N23)
+            const ke_f2 t = pk_mul_ll_hl(u, v);                        // (D01 D23, N01 D23)
+            const float Nn = __builtin_fmaf(v[1], u[0], t[1]);
+            rowsum = __builtin_fmaf(Nn, __builtin_amdgcn_rcpf(t[0]), rowsum);
         }
         const int q = __float2int_rn(rowsum * 67108864.0f);   // |rowsum| <= PX + eps
         local += valid ? (long long)q : 0ll;

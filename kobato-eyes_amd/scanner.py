@@ -11,6 +11,7 @@ key follow src/dup/scanner.py:320-356, 402-415.
 """
 from __future__ import annotations
 
+import gc
 import logging
 import math
 import os
@@ -188,7 +189,8 @@ class DuplicateScanner:
         self._config = config
         self._device = device
         self._part = (part_index, part_count)
-        self.last_counters: Optional[dict] = None
+        self._counters: Optional[dict] = None
+        self._funnel: Optional[tuple] = None
 
     # -- candidate edges ---------------------------------------------------------------------
     def candidate_edges(self, candidates: Sequence[DuplicateFile]) -> dict:
@@ -242,36 +244,6 @@ class DuplicateScanner:
                         sized += _size_ok(int(sizes[i]), int(sizes[j]), ratio)
         return total, sized
 
-    def _pairs_after_size(self, hashes, sizes, ratio, cap) -> int:
-        """Bucket pairs passing the size filter (:358-370), equal ids included: per bucket the sizes are sorted and the
-        partners of each member counted with a binary search whose boundary is settled by the reference's own float
-        division (smaller / larger >= ratio)."""
-        cfg = self._config
-        total = 0
-        for band in range(cfg.band_count):
-            vals = self._band_values(hashes, band)
-            order = np.argsort(vals, kind="stable")
-            sv = vals[order]
-            starts = np.nonzero(np.concatenate(([True], sv[1:] != sv[:-1])))[0]
-            ends = np.concatenate((starts[1:], [len(sv)]))
-            for s0, e0 in zip(starts.tolist(), ends.tolist()):
-                m = e0 - s0
-                if m < 2 or (cap is not None and m * (m - 1) // 2 > cap):
-                    continue
-                sz = np.sort(sizes[order[s0:e0]])
-                free = int((sz <= 0).sum())                   # a missing / non-positive size passes with everyone
-                pos = sz[free:].astype(np.float64)
-                k = len(pos)
-                total += free * (free - 1) // 2 + free * k
-                if k >= 2:
-                    lo = np.searchsorted(pos, ratio * pos, side="left")
-                    for _ in range(2):                        # settle the boundary by the exact predicate
-                        lo = np.where((lo > 0) & (pos[np.maximum(lo - 1, 0)] / pos >= ratio), lo - 1, lo)
-                    for _ in range(2):
-                        lo = np.where((lo < k) & ~(pos[np.minimum(lo, k - 1)] / pos >= ratio), lo + 1, lo)
-                    total += int(np.maximum(np.arange(k) - lo, 0).sum())
-        return total
-
     def _edges_from_raw(self, candidates, hashes, ids, raw, counters, *, sizes=None, ratio=0.0, cap=None) -> dict:
         cfg = self._config
         order = np.lexsort((raw["b"], raw["a"]))
@@ -310,21 +282,41 @@ class DuplicateScanner:
                 hits.sort(key=lambda t: (bucket_rank(t[0], t[3]), t[0], t[1]))
             a, b, h, _ = hits[0]
             edges[key] = DuplicateEdge(int(ids[a]), int(ids[b]), int(h))
-        # "pairs total" = the device's bucket-pair count (band histograms) minus bucket pairs of equal file id; "size" =
-        # the same with the size filter.  A shard reports the whole table's figures for these two (they do not depend on
-        # the tiles it was dealt), its own share for the rest.
-        same_total, same_sized = self._same_id_bucket_pairs(hashes, ids, sizes if sizes is not None else np.zeros(len(ids), np.int64),
-                                                            ratio, cap)
-        pair_total = int(counters[3]) - same_total
-        if ratio > 0 and sizes is not None:
-            after_size = self._pairs_after_size(hashes, sizes, ratio, cap) - same_sized
-        else:
-            after_size = pair_total
-        self.last_counters = {"pairs_evaluated": int(counters[0]), "pair_total": pair_total, "after_size": after_size,
-                              "after_ham": int(counters[1]), "after_cosine": after_cos, "edges": len(edges)}
-        logger.info("dup: pairs total=%d -> size=%d -> ham=%d -> cosine=%d -> edges=%d", pair_total, after_size,
-                    int(counters[1]), after_cos, len(edges))
+        # The reference's funnel figures (src/dup/scanner.py:292-299) are a log line, not part of the result: they are worked
+        # out when somebody looks -- the logger at INFO, or a reader of ``last_counters`` -- and cost nothing otherwise.
+        self._counters = None
+        self._funnel = (hashes, ids, sizes, ratio, cap, [int(c) for c in counters], after_cos, len(edges))
+        if logger.isEnabledFor(logging.INFO):
+            c = self.last_counters
+            logger.info("dup: pairs total=%d -> size=%d -> ham=%d -> cosine=%d -> edges=%d", c["pair_total"], c["after_size"],
+                        c["after_ham"], c["after_cosine"], c["edges"])
         return edges
+
+    @property
+    def last_counters(self) -> Optional[dict]:
+        """The funnel of the last scan: "pairs total" = the device's bucket-pair count (band histograms) minus bucket pairs of
+        equal file id; "size" = the same with the size filter (``ke_band_pairs_after_size``).  A shard reports the whole
+        table's figures for these two (they do not depend on the tiles it was dealt), its own share for the rest."""
+        if self._counters is None and self._funnel is not None:
+            hashes, ids, sizes, ratio, cap, counters, after_cos, n_edges = self._funnel
+            same_total, same_sized = self._same_id_bucket_pairs(hashes, ids, sizes if sizes is not None else np.zeros(len(ids), np.int64),
+                                                                ratio, cap)
+            pair_total = counters[3] - same_total
+            if ratio > 0 and sizes is not None:
+                cfg = self._config
+                after_size = _native.get_context(self._device).band_pairs_after_size(
+                    hashes, sizes, len(hashes), band_bits=cfg.band_bits, band_count=cfg.band_count, size_ratio=ratio,
+                    bucket_pair_cap=cap or 0) - same_sized
+            else:
+                after_size = pair_total
+            self._counters = {"pairs_evaluated": counters[0], "pair_total": pair_total, "after_size": after_size,
+                              "after_ham": counters[1], "after_cosine": after_cos, "edges": n_edges}
+            self._funnel = None
+        return self._counters
+
+    @last_counters.setter
+    def last_counters(self, value: Optional[dict]) -> None:
+        self._counters, self._funnel = value, None
 
     def _log_bucket_stats(self, hashes: np.ndarray, cap: Optional[int]) -> None:
         if not logger.isEnabledFor(logging.INFO) and cap is None:
@@ -352,10 +344,19 @@ class DuplicateScanner:
                     cfg.band_bits, cfg.band_count, cfg.hamming_threshold, cfg.size_ratio, cfg.cosine_threshold)
         if len(candidates) < 2:
             return []
-        edges = self.candidate_edges(candidates)
-        if not edges:
-            return []
-        return assemble_clusters(candidates, edges.values())
+        # The host part allocates a few objects per edge and per cluster and none of them is part of a reference cycle; with a
+        # million DuplicateFile objects alive every full pass of the cycle collector it sets off walks all of them (1.3 of the
+        # 1.7 s of a million-file call went there).  The collector is paused for the duration of the call.
+        paused = gc.isenabled()
+        gc.disable()
+        try:
+            edges = self.candidate_edges(candidates)
+            if not edges:
+                return []
+            return assemble_clusters(candidates, edges.values())
+        finally:
+            if paused:
+                gc.enable()
 
     @staticmethod
     def _choose_keeper(entries: Sequence[DuplicateClusterEntry]) -> int:
@@ -367,40 +368,64 @@ def _keeper_key(entry: DuplicateClusterEntry) -> tuple:
     return (-(f.size or 0), -f.resolution, -f.extension_priority, f.path.suffix.lower(), f.path.name.lower(), f.file_id)
 
 
+def _file_keys(f: DuplicateFile) -> tuple:
+    """(keeper key, entry sort key without the keeper flag) of src/dup/scanner.py:402-415 and :338-347."""
+    suffix = f.path.suffix.lower()
+    name = f.path.name.lower()
+    head = (-(f.size or 0), -f.resolution, -_EXT_RANK.get(suffix.lstrip("."), 0))
+    return head + (suffix, name, f.file_id), head + (name, f.file_id)
+
+
 def assemble_clusters(candidates: Sequence[DuplicateFile], edges: Iterable[DuplicateEdge]) -> list:
-    """Edges -> ordered clusters (src/dup/scanner.py:304-356).  Components come from the
-    library's host union-find over compacted file ids."""
+    """Edges -> ordered clusters (src/dup/scanner.py:304-356).  Components come from the library's host union-find over
+    compacted file ids; best_hamming and the grouping are array work, Python only touches the members of each cluster once
+    (a million-file table leaves some 60 000 clusters: their keys, not the union-find, are the time)."""
     edges = list(edges)
+    if not edges:
+        return []
+    m = len(edges)
     by_id = {f.file_id: f for f in candidates}          # later duplicates of an id win, as in the reference
-    node_ids = sorted({fid for e in edges for fid in (e.file_id_a, e.file_id_b)})
-    node_of = {fid: k for k, fid in enumerate(node_ids)}
-    raw = np.zeros(len(edges), _native.EDGE_DTYPE)
-    raw["a"] = [node_of[e.file_id_a] for e in edges]
-    raw["b"] = [node_of[e.file_id_b] for e in edges]
+    ends = np.empty(2 * m, np.int64)
+    ends[:m] = np.fromiter((e.file_id_a for e in edges), np.int64, m)
+    ends[m:] = np.fromiter((e.file_id_b for e in edges), np.int64, m)
+    ham = np.fromiter((-1 if e.hamming is None else e.hamming for e in edges), np.int64, m)
+    node_ids, inverse = np.unique(ends, return_inverse=True)         # ascending ids -> members ascending
+    raw = np.zeros(m, _native.EDGE_DTYPE)
+    raw["a"], raw["b"] = inverse[:m], inverse[m:]
     labels = _native.cluster_labels(raw, len(node_ids))
-    best: dict[int, int] = {}
-    for e in edges:
-        if e.hamming is None:
+    none = np.iinfo(np.int64).max
+    best = np.full(len(node_ids), none, np.int64)
+    known = ham >= 0
+    np.minimum.at(best, inverse[:m][known], ham[known])
+    np.minimum.at(best, inverse[m:][known], ham[known])
+    order = np.argsort(labels, kind="stable")
+    sorted_labels = labels[order]
+    cuts = np.nonzero(np.concatenate(([True], sorted_labels[1:] != sorted_labels[:-1], [True])))[0].tolist()
+    member_ids = node_ids[order].tolist()
+    member_best = best[order].tolist()
+    ranked = []                                          # (cluster sort key, cluster)
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        if hi - lo < 2:
             continue
-        for fid in (e.file_id_a, e.file_id_b):
-            if fid not in best or e.hamming < best[fid]:
-                best[fid] = e.hamming
-    groups: dict[int, list[int]] = {}
-    for fid, lab in zip(node_ids, labels.tolist()):
-        groups.setdefault(lab, []).append(fid)           # node_ids ascending -> members ascending
-    clusters = []
-    for members in groups.values():
+        members = [(by_id.get(member_ids[k]), member_best[k]) for k in range(lo, hi)]
+        members = [(f, None if b == none else b) for f, b in members if f is not None]
         if len(members) < 2:
             continue
-        entries = [DuplicateClusterEntry(by_id[m], best.get(m)) for m in members if m in by_id]
-        if len(entries) < 2:
-            continue
-        keeper = min(entries, key=_keeper_key).file.file_id
-        entries.sort(key=lambda en: (0 if en.file.file_id == keeper else 1, -(en.file.size or 0), -en.file.resolution,
-                                     -en.file.extension_priority, en.file.path.name.lower(), en.file.file_id))
-        clusters.append(DuplicateCluster(files=entries, keeper_id=keeper))
-    clusters.sort(key=lambda c: (-max((en.file.size or 0) for en in c.files), c.files[0].file.path.as_posix().lower()))
-    return clusters
+        if len(members) == 2 and (members[0][0].size or 0) != (members[1][0].size or 0):
+            # the common case needs no key at all: two files of different size, the larger is the keeper and comes first
+            if (members[0][0].size or 0) < (members[1][0].size or 0):
+                members.reverse()
+            keeper = members[0][0].file_id
+        else:
+            keyed = [(_file_keys(f), f, b) for f, b in members]
+            keeper = min(keyed, key=lambda t: t[0][0])[1].file_id
+            keyed.sort(key=lambda t: (0 if t[1].file_id == keeper else 1,) + t[0][1])
+            members = [(f, b) for _, f, b in keyed]
+        entries = [DuplicateClusterEntry(f, b) for f, b in members]
+        top = max((f.size or 0) for f, _ in members)
+        ranked.append(((-top, members[0][0].path.as_posix().lower()), DuplicateCluster(files=entries, keeper_id=keeper)))
+    ranked.sort(key=lambda t: t[0])
+    return [c for _, c in ranked]
 
 
 __all__ = ["DuplicateFile", "DuplicateCluster", "DuplicateClusterEntry", "DuplicateScanConfig", "DuplicateScanner"]

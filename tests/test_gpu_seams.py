@@ -92,6 +92,8 @@ def test_scan_100k_equals_the_reference_digests(K):
         edges = [(e.file_id_a, e.file_id_b, e.hamming) for e in scanner.candidate_edges(files).values()]
         clusters = [[c.keeper_id, [[e.file.file_id, e.best_hamming] for e in c.files]] for c in scanner.build_clusters(files)]
         assert len(edges) == run["n_edges"] and len(clusters) == run["n_clusters"]
+        c = scanner.last_counters                           # the reference's own funnel line (src/dup/scanner.py:292-299)
+        assert [c["pair_total"], c["after_size"], c["after_ham"], c["after_cosine"]] == run["counters"]
         assert G.scan_listing_digests(edges, clusters) == (run["edges_sha256"], run["clusters_sha256"])
 
 

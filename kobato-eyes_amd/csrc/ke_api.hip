@@ -232,6 +232,7 @@ KE_API void ke_destroy(ke_ctx *ctx) {
     }
     if (ctx->side_fork) (void)hipEventDestroy(ctx->side_fork);
     if (ctx->h_comm) (void)hipHostFree(ctx->h_comm);
+    if (ctx->h_meta) (void)hipHostFree(ctx->h_meta);
     for (auto &b : ctx->buf)
         if (b.ptr) (void)hipFree(b.ptr);
     free_coeff_cache(ctx);

@@ -141,6 +141,8 @@ struct ke_ctx {
     int64_t edge_slots = 1024;       // edges carried by one record of ke_allgather_edges (follows the largest list seen)
     void *h_comm = nullptr;          // pinned landing zone of the gathered edge records
     size_t h_comm_bytes = 0;
+    void *h_meta = nullptr;          // page-locked per-image records of a decode batch on their way to the device, and the statuses back
+    size_t h_meta_bytes = 0;
     bool ssim_exact = false;         // ke_ssim_set_mode: false = integer-sum kernel (default), true = fp64-carry kernel
     float *margin_cur = nullptr;     // device array the hash kernels of the CURRENT call write tie margins to (slot = hash slot)
     bool dct_tables_ready = false;   // __constant__ tables are per device: uploaded once per context

@@ -16,6 +16,10 @@
 #include <algorithm>
 #include <numeric>
 
+#include <chrono>
+#include <memory>
+#include <cstdio>
+
 #include "ke_internal.h"
 #include "ke_jpeg_parse.h"
 
@@ -29,6 +33,8 @@ struct KeJpegDev {                 // per image, device side
     uint64_t out_off;              // bytes into the caller's pixel buffer
     int32_t block_base[3];         // first block of each component inside the image's coefficient range
     int32_t blocks_total;
+    uint32_t file_size;            // bytes of the file
+    int32_t end_on_device;         // the entropy-coded segment's end is still to be found (ke_jpeg_find_end)
 };
 
 __constant__ uint8_t c_zigzag[64] = KE_ZZ;
@@ -141,6 +147,59 @@ constexpr int kLdsTables = 4;      // distinct Huffman tables a workgroup keeps 
 
 // One thread per image.  Coefficients are stored as decoded (int16, natural order, every block written whole); the IDCT kernel
 // dequantises.
+// ---- the end of a sequential file's entropy-coded segment, found where the bytes are.  ke_jpeg_segment_end's rule: the first
+// position e >= scan_offset, e <= size - 2, with p[e] == 0xFF and p[e + 1] neither 0x00 nor RSTn; none = truncated (Pillow
+// raises: KE_JPEG_CORRUPT); the marker there must be EOI (anything else = another scan or table: KE_JPEG_UNSUPPORTED).  One wave
+// per file, 16 bytes per lane and step; also sets every image's status to the verdict (0 for files the host has walked).
+__global__ __launch_bounds__(64) void ke_jpeg_find_end(KeJpegDev *__restrict__ imgs, int64_t n, const uint8_t *__restrict__ files,
+                                                       int32_t *__restrict__ status) {
+    const int64_t i = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (i >= n) return;
+    KeJpegDev &d = imgs[i];
+    if (!d.end_on_device) {
+        if (lane == 0) status[i] = KE_JPEG_OK;
+        return;
+    }
+    const uint8_t *p = files + d.file_off;
+    const uint32_t size = d.file_size, from = d.info.scan_offset;
+    // dword-aligned reads: the buffer starts on 256 bytes and ends with 256 bytes of slack
+    const uintptr_t a0 = (uintptr_t)(p + from) & ~(uintptr_t)3;
+    const int64_t pos0 = (int64_t)(a0 - (uintptr_t)p);            // file position of the first byte read (from - 3 .. from)
+    uint32_t found = 0xFFFFFFFFu;
+    for (int64_t base = pos0; base + 1 < (int64_t)size; base += 64 * 16) {
+        const int64_t q = base + (int64_t)lane * 16;               // this lane's 16 positions q .. q + 15
+        uint32_t hit = 0xFFFFFFFFu;
+        if (q + 1 < (int64_t)size) {
+            const uint32_t *w = reinterpret_cast<const uint32_t *>(p + q);
+            uint32_t v[5];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) v[k] = w[k];
+#pragma unroll
+            for (int k = 15; k >= 0; --k) {
+                const uint32_t b0 = (v[k >> 2] >> (8 * (k & 3))) & 0xFFu, b1 = (v[(k + 1) >> 2] >> (8 * ((k + 1) & 3))) & 0xFFu;
+                const int64_t e = q + k;
+                if (b0 == 0xFFu && b1 != 0u && !(b1 >= 0xD0u && b1 <= 0xD7u) && e >= (int64_t)from && e + 1 < (int64_t)size) hit = (uint32_t)e;
+            }
+        }
+        const uint64_t any = __ballot(hit != 0xFFFFFFFFu);
+        if (any) {
+            found = __shfl(hit, __ffsll((long long)any) - 1);       // lanes hold ascending positions: the first lane's is the first
+            break;
+        }
+    }
+    if (lane == 0) {
+        if (found == 0xFFFFFFFFu) {
+            status[i] = KE_JPEG_CORRUPT;
+        } else if (p[found + 1] != 0xD9) {
+            status[i] = KE_JPEG_UNSUPPORTED;
+        } else {
+            d.info.scan_end = found;
+            status[i] = KE_JPEG_OK;
+        }
+    }
+}
+
 __global__ __launch_bounds__(64) void ke_jpeg_entropy(const KeJpegDev *__restrict__ imgs, int64_t n, const uint8_t *__restrict__ files,
                                                       const KeHuffTable *__restrict__ tables, int16_t *__restrict__ coefs,
                                                       int32_t *__restrict__ status, int lanes) {
@@ -156,7 +215,8 @@ __global__ __launch_bounds__(64) void ke_jpeg_entropy(const KeJpegDev *__restric
     const int64_t i = (int64_t)blockIdx.x * lanes + lane;
     const KeJpegDev &d = imgs[i < n ? i : n - 1];
     const KeJpegInfo &in = d.info;
-    const bool live = lane < lanes && i < n && !in.progressive;          // progressive files are ke_jpeg_entropy_prog's
+    // progressive files are ke_jpeg_entropy_prog's; a file ke_jpeg_find_end has turned down keeps that status
+    const bool live = lane < lanes && i < n && !in.progressive && status[i] == KE_JPEG_OK;
     // the workgroup's distinct tables (files of one encoder share them): up to four go to LDS
     if (lane == 0) { s_count = 0; s_all = 1; }
     s_zz[lane] = c_zigzag[lane];
@@ -510,9 +570,11 @@ struct IdctMul24 {                  // see ke_idct_islow: multiplicands below 2^
     static __device__ __forceinline__ int mul(int a, int k) { return __mul24(a, k); }
 };
 
-__global__ __launch_bounds__(256) void ke_jpeg_idct(const KeJpegDev *__restrict__ imgs, const int16_t *__restrict__ coefs,
+__global__ __launch_bounds__(256) void ke_jpeg_idct(const KeJpegDev *__restrict__ imgs, int64_t n_imgs, const int16_t *__restrict__ coefs,
                                                     uint8_t *__restrict__ planes, int32_t *status) {
-    const KeJpegDev &d = imgs[blockIdx.y];
+    const int64_t img = (int64_t)blockIdx.z * 65535 + blockIdx.y;       // a grid dimension ends at 65535: the image index takes two
+    if (img >= n_imgs) return;
+    const KeJpegDev &d = imgs[img];
     const int b = blockIdx.x * 256 + threadIdx.x;
     if (b >= d.blocks_total) return;
     const KeJpegInfo &in = d.info;
@@ -540,7 +602,7 @@ __global__ __launch_bounds__(256) void ke_jpeg_idct(const KeJpegDev *__restrict_
     uint8_t rows[64];
     // a block outside the bound of ke_idct_islow: the file goes back to the caller (unless the entropy decoder already said
     // worse of it; every thread that finds one stores the same value)
-    if (!ke_idct_islow<int[64], IdctMul24>(blk, rows, 8) && status[blockIdx.y] == KE_JPEG_OK) status[blockIdx.y] = KE_JPEG_UNSUPPORTED;
+    if (!ke_idct_islow<int[64], IdctMul24>(blk, rows, 8) && status[img] == KE_JPEG_OK) status[img] = KE_JPEG_UNSUPPORTED;
     uint8_t *dst = planes + d.plane_off[c] + (size_t)(brow * 8) * in.plane_w[c] + bcol * 8;
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
@@ -613,22 +675,25 @@ __device__ __forceinline__ uint32_t ycc_to_rgb24(int y, int cb, int cr) {
     return (uint32_t)min(max(r, 0), 255) | ((uint32_t)min(max(g, 0), 255) << 8) | ((uint32_t)min(max(b, 0), 255) << 16);
 }
 
-__global__ __launch_bounds__(256) void ke_jpeg_colour(const KeJpegDev *__restrict__ imgs, const uint8_t *__restrict__ planes,
-                                                      uint8_t *__restrict__ out) {
+__global__ __launch_bounds__(256) void ke_jpeg_colour(const KeJpegDev *__restrict__ imgs, int64_t n_imgs, int xblocks,
+                                                      const uint8_t *__restrict__ planes, uint8_t *__restrict__ out) {
     // A workgroup takes 256 columns of kColourRows rows, four rows at a time (65 536 images of 512 x 512 are 16.7 M groups of
     // four rows: one workgroup each was bound by the rate workgroups can be started at); the turns are independent, so their
     // loads overlap.
-    const KeJpegDev &d = imgs[blockIdx.z];
+    const int64_t img = (int64_t)blockIdx.z * 65535 + blockIdx.y;       // image over two grid dimensions, (column, row) blocks in x
+    if (img >= n_imgs) return;
+    const KeJpegDev &d = imgs[img];
     const KeJpegInfo &in = d.info;
     const int r = threadIdx.x >> 6, q = threadIdx.x & 63;
-    const int x0 = blockIdx.x * 256 + q * 4;
+    const int block_x = (int)(blockIdx.x % (unsigned)xblocks), block_y = (int)(blockIdx.x / (unsigned)xblocks);
+    const int x0 = block_x * 256 + q * 4;
     if (x0 >= in.width) return;
     const uint8_t *Y = planes + d.plane_off[0], *Cb = planes + d.plane_off[1], *Cr = planes + d.plane_off[2];
     uint8_t *dst = out + d.out_off;
     const int npx = min(4, in.width - x0);
 #pragma unroll 4
     for (int turn = 0; turn < kColourRows / 4; ++turn) {
-        const int y = blockIdx.y * kColourRows + turn * 4 + r;
+        const int y = block_y * kColourRows + turn * 4 + r;
         if (y >= in.height) break;
         // four luma samples in one load (plane rows are multiples of 8 bytes, x0 of 4)
         const uint32_t y4 = *reinterpret_cast<const uint32_t *>(Y + (__umul24(y, in.plane_w[0]) + (uint32_t)x0));
@@ -733,79 +798,123 @@ KE_API int ke_jpeg_decode(ke_ctx *ctx, const uint8_t *files, const uint64_t *off
     for (const void *p : {(const void *)offsets, (const void *)sizes, (const void *)out_offsets, (const void *)status_out})
         if (ke_is_device_ptr(p)) return ke_fail(ctx, KE_EINVAL, "offsets/sizes/status are host arrays");
     KE_HIP(ctx, hipSetDevice(ctx->device));
-    // ---- host: headers, Huffman tables, geometry
-    // (on the host's threads: a header costs a few microseconds -- marker walk, Huffman tables, the search for the end of the
-    // scan -- which at 65 536 files is more than the kernels take)
+    const bool trace = std::getenv("KE_TRACE") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!trace) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[ke_jpeg_decode] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
+    // ---- host: headers, Huffman tables, geometry -- on the host's threads (a header costs a few microseconds; 65 536 of them on
+    // one thread are more than the kernels take).  A record is 700 bytes (three quantisation tables), so records are written
+    // once, where they are parsed, and move once more: in device order into the page-locked block they are uploaded from.
+    // (Before: per-thread vectors merged into one, copied again by the sort, uploaded from pageable memory -- 50 ms of a
+    // 65 536-file call, as long as the entropy kernel.)
     struct Part {
         KeJpegTables tables;
-        std::vector<KeJpegDev> devs;
-        std::vector<int64_t> which;
         std::vector<KeJpegScan> scans;
-        uint64_t lo = ~0ull, hi = 0;
+        int64_t first = 0, last = 0;
     };
+    // the compressed bytes set off for the device before anything is parsed: one contiguous range of the caller's buffer (the
+    // files the decoder will turn down travel along -- they are the few), 17 ms for the 970 MB of 65 536 files, hidden behind
+    // the parsing below
+    uint64_t lo = ~0ull, hi = 0;
+    for (int64_t i = 0; i < n; ++i)
+        if (sizes[i]) { lo = std::min(lo, offsets[i]); hi = std::max(hi, offsets[i] + sizes[i]); }
+    if (hi <= lo) {
+        for (int64_t i = 0; i < n; ++i) status_out[i] = KE_JPEG_CORRUPT;
+        return KE_OK;
+    }
+    void *d_files;
+    KE_TRY(ke_reserve(ctx, KE_BUF_PIXELS, (size_t)(hi - lo) + 256, &d_files));   // the stream windows read up to 64 bytes past a file
+    KE_HIP(ctx, hipMemcpyAsync(d_files, files + lo, (size_t)(hi - lo), hipMemcpyHostToDevice, ctx->stream));
+    std::unique_ptr<KeJpegDev[]> all(new KeJpegDev[(size_t)n]);           // record i <-> file i; status != OK = not decodable
     std::vector<Part> parts(16);
+    const bool on_device_end = !std::getenv("KE_JPEG_HOST_END");      // 1: walk every file's entropy data on the host, as before
     const int nparts = ke_parallel_ranges(n, [&](int64_t first, int64_t last, int t) {
         Part &p = parts[(size_t)t];
+        p.first = first; p.last = last;
         p.tables.sequential_only = true;
         for (int64_t i = first; i < last; ++i) {
-            KeJpegDev d;
-            ke_parse_jpeg(files + offsets[i], (size_t)sizes[i], p.tables, d.info, true, &p.scans);
+            KeJpegDev &d = all[(size_t)i];
+            bool defer = false;
+            ke_parse_jpeg(files + offsets[i], (size_t)sizes[i], p.tables, d.info, true, &p.scans, on_device_end ? &defer : nullptr);
             status_out[i] = d.info.status;
             if (d.info.status != KE_JPEG_OK) continue;
+            d.end_on_device = defer ? 1 : 0;
+            d.file_size = (uint32_t)sizes[i];
             d.file_off = offsets[i];
             d.out_off = out_offsets[i];
-            p.lo = std::min(p.lo, offsets[i]);
-            p.hi = std::max(p.hi, offsets[i] + sizes[i]);
-            p.devs.push_back(d);
-            p.which.push_back(i);
         }
     });
+    lap("parse (threads)");
     KeJpegTables tables;                              // one pool for the batch: every part's tables interned again
-    std::vector<KeJpegDev> devs;
-    std::vector<int64_t> which;                       // batch position of every decodable image
     std::vector<KeJpegScan> scans;                    // of the progressive files, image after image
-    uint64_t lo = ~0ull, hi = 0;
+    std::vector<std::vector<int>> remaps((size_t)nparts);
+    std::vector<uint32_t> scan_base((size_t)nparts);
     for (int t = 0; t < nparts; ++t) {
         Part &p = parts[(size_t)t];
-        for (KeJpegDev &d : p.devs)
-            if (d.info.progressive) d.info.first_scan += (uint32_t)scans.size();
+        scan_base[(size_t)t] = (uint32_t)scans.size();
         scans.insert(scans.end(), p.scans.begin(), p.scans.end());
-        std::vector<int> remap(p.tables.keys.size());
+        std::vector<int> &remap = remaps[(size_t)t];
+        remap.resize(p.tables.keys.size());
         for (size_t k = 0; k < remap.size(); ++k) {
             const std::vector<uint8_t> &key = p.tables.keys[k];
             remap[k] = tables.intern(key.data(), key.data() + 16, (int)key.size() - 16);
         }
-        for (KeJpegDev &d : p.devs)
-            for (int c = 0; c < d.info.ncomp && !d.info.progressive; ++c) {
-                d.info.huff_dc[c] = remap[(size_t)d.info.huff_dc[c]];
-                d.info.huff_ac[c] = remap[(size_t)d.info.huff_ac[c]];
-            }
-        devs.insert(devs.end(), p.devs.begin(), p.devs.end());
-        which.insert(which.end(), p.which.begin(), p.which.end());
-        lo = std::min(lo, p.lo);
-        hi = std::max(hi, p.hi);
     }
-    if (devs.empty()) return KE_OK;
     // The 64 lanes of a wave step through their images block by block and finish together at best: neighbours in the device
-    // order should be images of like geometry and like compressed size (like amounts of work per block).
-    if (!std::getenv("KE_JPEG_KEEP_ORDER")) {
-        std::vector<size_t> order(devs.size());
-        std::iota(order.begin(), order.end(), (size_t)0);
-        auto key = [&](size_t k) {
-            const KeJpegInfo &in = devs[k].info;
-            return std::make_tuple(in.progressive, -(int64_t)in.mcus_x * in.mcus_y * in.ncomp, -(int64_t)(in.scan_end - in.scan_offset));
-        };
-        std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return key(a) < key(b); });
-        std::vector<KeJpegDev> sorted_devs(devs.size());
-        std::vector<int64_t> sorted_which(devs.size());
-        for (size_t k = 0; k < order.size(); ++k) { sorted_devs[k] = devs[order[k]]; sorted_which[k] = which[order[k]]; }
-        devs.swap(sorted_devs);
-        which.swap(sorted_which);
+    // order should be images of like geometry and like compressed size (like amounts of work per block).  The order is a sort
+    // of (key, file) pairs; the records themselves are gathered afterwards.
+    struct Key { uint64_t a, b; uint32_t i; };
+    std::vector<Key> order;
+    order.reserve((size_t)n);
+    const bool keep_order = std::getenv("KE_JPEG_KEEP_ORDER") != nullptr;
+    for (int64_t i = 0; i < n; ++i) {
+        const KeJpegDev &d = all[(size_t)i];
+        if (d.info.status != KE_JPEG_OK) continue;
+        const KeJpegInfo &in = d.info;
+        const uint64_t work = (uint64_t)in.mcus_x * in.mcus_y * in.ncomp, bytes = (d.end_on_device ? d.file_size : in.scan_end) - in.scan_offset;
+        order.push_back(keep_order ? Key{0, 0, (uint32_t)i} : Key{((uint64_t)(in.progressive ? 1 : 0) << 63) | (~work & 0x7FFFFFFFFFFFFFFFull), ~bytes, (uint32_t)i});
     }
-    // compressed bytes of the decodable files (one contiguous range of the caller's buffer) -> device
-    void *d_files;
-    KE_TRY(ke_reserve(ctx, KE_BUF_PIXELS, (size_t)(hi - lo) + 256, &d_files));   // the stream windows read up to 64 bytes past a file
-    KE_HIP(ctx, hipMemcpyAsync(d_files, files + lo, (size_t)(hi - lo), hipMemcpyHostToDevice, ctx->stream));
+    if (order.empty()) {
+        KE_HIP(ctx, hipStreamSynchronize(ctx->stream));        // the caller's buffer is still being read
+        return KE_OK;
+    }
+    if (!keep_order)
+        std::sort(order.begin(), order.end(), [](const Key &x, const Key &y) { return x.a != y.a ? x.a < y.a : x.b != y.b ? x.b < y.b : x.i < y.i; });
+    lap("merge tables + order");
+    const int64_t total = (int64_t)order.size();
+    const size_t meta_bytes = (size_t)total * sizeof(KeJpegDev) + (size_t)total * 4 + 64;
+    if (ctx->h_meta_bytes < meta_bytes) {
+        if (ctx->h_meta) (void)hipHostFree(ctx->h_meta);
+        ctx->h_meta = nullptr;
+        ctx->h_meta_bytes = 0;
+        KE_HIP(ctx, hipHostMalloc(&ctx->h_meta, meta_bytes + meta_bytes / 4, hipHostMallocDefault));
+        ctx->h_meta_bytes = meta_bytes + meta_bytes / 4;
+    }
+    KeJpegDev *devs = (KeJpegDev *)ctx->h_meta;                          // page-locked, device order
+    int32_t *h_st = (int32_t *)((uint8_t *)ctx->h_meta + (size_t)total * sizeof(KeJpegDev));
+    auto part_index = [&](int64_t i) { int t = 0; while (t + 1 < nparts && i >= parts[(size_t)t].last) ++t; return t; };
+    ke_parallel_ranges(total, [&](int64_t first, int64_t last, int) {
+        for (int64_t k = first; k < last; ++k) {
+            const int64_t i = order[(size_t)k].i;
+            KeJpegDev &d = devs[k];
+            d = all[(size_t)i];
+            const int t = part_index(i);
+            if (d.info.progressive) {
+                d.info.first_scan += scan_base[(size_t)t];
+            } else {
+                for (int c = 0; c < d.info.ncomp; ++c) {
+                    d.info.huff_dc[c] = remaps[(size_t)t][(size_t)d.info.huff_dc[c]];
+                    d.info.huff_ac[c] = remaps[(size_t)t][(size_t)d.info.huff_ac[c]];
+                }
+            }
+        }
+    });
+    all.reset();
+    lap("records into device order");
     void *d_tables;
     KE_TRY(ke_reserve(ctx, KE_BUF_JPEG_TABLES, tables.pool.size() * sizeof(KeHuffTable), &d_tables));
     KE_HIP(ctx, hipMemcpyAsync(d_tables, tables.pool.data(), tables.pool.size() * sizeof(KeHuffTable), hipMemcpyHostToDevice, ctx->stream));
@@ -823,15 +932,14 @@ KE_API int ke_jpeg_decode(ke_ctx *ctx, const uint8_t *files, const uint64_t *off
     KE_HIP(ctx, hipMemGetInfo(&free_b, &total_b));
     const uint64_t held = (uint64_t)ctx->buf[KE_BUF_TMP].bytes + ctx->buf[KE_BUF_SSIM_IN].bytes;
     const uint64_t budget = std::max<uint64_t>((uint64_t)2 << 30, std::min<uint64_t>((held + (uint64_t)free_b) / 2, (uint64_t)160 << 30));
-    size_t first = 0;
-    std::vector<int32_t> st;
+    int64_t first = 0;
     ke_time_begin(ctx, KE_T_JPEG);
-    while (first < devs.size()) {
+    while (first < total) {
         uint64_t coef_units = 0, plane_bytes = 0;
-        size_t last = first;
+        int64_t last = first;
         int max_blocks = 0, max_w = 0, max_h = 0;
         int64_t progressive_here = 0;
-        while (last < devs.size() && last - first < 65535) {     // the image index is blockIdx.y of the IDCT and colour kernels
+        while (last < total && last - first < (1 << 20)) {       // (the image index is a pair of grid dimensions: 65 535 x 65 535)
             KeJpegDev &d = devs[last];
             // progressive files: at most two waves of them per CU in one launch (measured: a third wave per CU slows all three
             // by more than it adds -- 65 536 files 458 ms in one launch, 417 in two)
@@ -860,19 +968,20 @@ KE_API int ke_jpeg_decode(ke_ctx *ctx, const uint8_t *files, const uint64_t *off
             max_h = std::max(max_h, d.info.height);
             ++last;
         }
-        const int64_t m = (int64_t)(last - first);
+        const int64_t m = last - first;
         void *d_imgs, *d_coef, *d_planes, *d_status;
         KE_TRY(ke_reserve(ctx, KE_BUF_META, (size_t)m * sizeof(KeJpegDev), &d_imgs));
         KE_TRY(ke_reserve(ctx, KE_BUF_TMP, (size_t)coef_units * 2 + 64, &d_coef));
         KE_TRY(ke_reserve(ctx, KE_BUF_SSIM_IN, (size_t)plane_bytes + 64, &d_planes));
         KE_TRY(ke_reserve(ctx, KE_BUF_OUT0, (size_t)m * 4, &d_status));
-        KE_HIP(ctx, hipMemcpyAsync(d_imgs, devs.data() + first, (size_t)m * sizeof(KeJpegDev), hipMemcpyHostToDevice, ctx->stream));
+        lap("layout + reserve");
+        KE_HIP(ctx, hipMemcpyAsync(d_imgs, devs + first, (size_t)m * sizeof(KeJpegDev), hipMemcpyHostToDevice, ctx->stream));
         // sequential files: no clearing of the coefficient array, every block of an image that decodes is written whole (a
         // damaged image's remaining blocks hold whatever was there, and its pixels are discarded with its status);
         // progressive files build their coefficients up scan by scan, from zero
         prog_list.clear();
         for (int64_t k = 0; k < m; ++k)
-            if (devs[first + (size_t)k].info.progressive) prog_list.push_back((int32_t)k);
+            if (devs[first + k].info.progressive) prog_list.push_back((int32_t)k);
         // images per wave: 64 once that makes two waves for every SIMD, fewer (down to 8) below that (measured: 65 536 files
         // 90.1 ms at 64 per wave, 86.4 at 32, 103 at 16; 16 384 files 38.3 at 16, 34.5 at 8)
         auto lanes_for = [&](int64_t images, int64_t waves_wanted) {
@@ -880,6 +989,8 @@ KE_API int ke_jpeg_decode(ke_ctx *ctx, const uint8_t *files, const uint64_t *off
             while (lanes > 8 && (images + lanes / 2 - 1) / (lanes / 2) <= waves_wanted) lanes /= 2;
             return lanes;
         };
+        hipLaunchKernelGGL(ke_jpeg_find_end, dim3((unsigned)m), dim3(64), 0, ctx->stream, (KeJpegDev *)d_imgs, m, (const uint8_t *)d_files,
+                           (int32_t *)d_status);
         if ((int64_t)prog_list.size() < m) {
             const int lanes = lanes_for(m, (int64_t)ctx->cu_count * 8);
             hipLaunchKernelGGL(ke_jpeg_entropy, dim3((unsigned)((m + lanes - 1) / lanes)), dim3(64), 0, ctx->stream, (const KeJpegDev *)d_imgs, m,
@@ -893,7 +1004,7 @@ KE_API int ke_jpeg_decode(ke_ctx *ctx, const uint8_t *files, const uint64_t *off
             while (run0 < prog_list.size()) {
                 size_t run1 = run0;
                 while (run1 + 1 < prog_list.size() && prog_list[run1 + 1] == prog_list[run1] + 1) ++run1;
-                const KeJpegDev &a = devs[first + (size_t)prog_list[run0]], &b = devs[first + (size_t)prog_list[run1]];
+                const KeJpegDev &a = devs[first + prog_list[run0]], &b = devs[first + prog_list[run1]];
                 const uint64_t from = a.coef_off, to = b.coef_off + (uint64_t)b.blocks_total * 64;
                 KE_HIP(ctx, hipMemsetAsync((int16_t *)d_coef + from, 0, (size_t)(to - from) * 2, ctx->stream));
                 run0 = run1 + 1;
@@ -904,15 +1015,18 @@ KE_API int ke_jpeg_decode(ke_ctx *ctx, const uint8_t *files, const uint64_t *off
                                (const int32_t *)d_list, np, (const uint8_t *)d_files, (const KeJpegScan *)d_scans, (int16_t *)d_coef,
                                (int32_t *)d_status, lanes);
         }
-        hipLaunchKernelGGL(ke_jpeg_idct, dim3((unsigned)((max_blocks + 255) / 256), (unsigned)m), dim3(256), 0, ctx->stream,
-                           (const KeJpegDev *)d_imgs, (const int16_t *)d_coef, (uint8_t *)d_planes, (int32_t *)d_status);
-        hipLaunchKernelGGL(ke_jpeg_colour, dim3((unsigned)((max_w + 255) / 256), (unsigned)((max_h + kColourRows - 1) / kColourRows), (unsigned)m), dim3(256), 0, ctx->stream,
-                           (const KeJpegDev *)d_imgs, (const uint8_t *)d_planes, pixels_out);
+        const unsigned gy = (unsigned)std::min<int64_t>(m, 65535), gz = (unsigned)((m + 65534) / 65535);
+        hipLaunchKernelGGL(ke_jpeg_idct, dim3((unsigned)((max_blocks + 255) / 256), gy, gz), dim3(256), 0, ctx->stream,
+                           (const KeJpegDev *)d_imgs, m, (const int16_t *)d_coef, (uint8_t *)d_planes, (int32_t *)d_status);
+        const int xblocks = (max_w + 255) / 256, yblocks = (max_h + kColourRows - 1) / kColourRows;
+        hipLaunchKernelGGL(ke_jpeg_colour, dim3((unsigned)(xblocks * yblocks), gy, gz), dim3(256), 0, ctx->stream,
+                           (const KeJpegDev *)d_imgs, m, xblocks, (const uint8_t *)d_planes, pixels_out);
         KE_HIP(ctx, hipGetLastError());
-        st.resize((size_t)m);
-        KE_HIP(ctx, hipMemcpyAsync(st.data(), d_status, (size_t)m * 4, hipMemcpyDeviceToHost, ctx->stream));
-        KE_HIP(ctx, hipStreamSynchronize(ctx->stream));                  // devs / st are host vectors; scratch is reused
-        for (int64_t k = 0; k < m; ++k) status_out[which[first + (size_t)k]] = st[(size_t)k];
+        KE_HIP(ctx, hipMemcpyAsync(h_st + first, d_status, (size_t)m * 4, hipMemcpyDeviceToHost, ctx->stream));
+        lap("enqueue");
+        KE_HIP(ctx, hipStreamSynchronize(ctx->stream));                  // prog_list is a host vector; the scratch is reused
+        lap("wait for the stream");
+        for (int64_t k = 0; k < m; ++k) status_out[order[(size_t)(first + k)].i] = h_st[first + k];
         first = last;
     }
     ke_time_end(ctx, KE_T_JPEG);

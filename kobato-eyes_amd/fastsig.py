@@ -62,6 +62,39 @@ def _to_signed64(x: int) -> int:
     return v - (1 << 64) if v >> 63 else v
 
 
+_strict_lock = threading.Lock()
+_strict_state = {"active": 0, "saved": False}
+
+
+class _StrictPillow:
+    """While any decode of this module is under way Pillow's process-wide ``ImageFile.LOAD_TRUNCATED_IMAGES`` is off; the last
+    one out puts back what it found (unless somebody else has switched it on in the meantime: then it stays on).
+
+    The reference's worker is a freshly spawned process (src/core/fastsig.py:81-85): the switch is at its default there, so a
+    truncated file raises and is dropped (:36-37).  Here the decoders may be threads of the calling process, where
+    ``safe_load_image`` (src/utils/image_io.py:60-138, and this package's restatement) leaves the switch ON for good after its
+    first call -- a truncated file would then be padded and hashed.  The decodes themselves run side by side; only the two
+    counter updates take the lock."""
+
+    def __enter__(self):
+        from PIL import ImageFile
+
+        with _strict_lock:
+            if _strict_state["active"] == 0:
+                _strict_state["saved"] = ImageFile.LOAD_TRUNCATED_IMAGES
+            ImageFile.LOAD_TRUNCATED_IMAGES = False
+            _strict_state["active"] += 1
+
+    def __exit__(self, *exc):
+        from PIL import ImageFile
+
+        with _strict_lock:
+            _strict_state["active"] -= 1
+            if _strict_state["active"] == 0 and not ImageFile.LOAD_TRUNCATED_IMAGES:
+                ImageFile.LOAD_TRUNCATED_IMAGES = _strict_state["saved"]
+        return False
+
+
 def _read_pixels(path_text: str):
     """Pixels of one file, or None for anything that cannot be opened (speed first: no reason kept)."""
     try:
@@ -70,7 +103,7 @@ def _read_pixels(path_text: str):
         path = Path(path_text)
         if not path.is_file():
             return None
-        with Image.open(path) as im:
+        with _StrictPillow(), Image.open(path) as im:
             return _phash.image_to_array(im)
     except Exception:
         return None
@@ -305,6 +338,10 @@ class _Pipeline:
         self.stage = _make_stage(device, int(os.environ.get("KE_STAGE_BYTES", str(256 << 20))), max(self.chunk, 4096))
         self.process_min = int(os.environ.get("KE_DECODE_PROCESS_MIN", "256"))
         self.bytes_per_image = 1 << 20                     # running estimate of a decoded image, for sizing the workers' jobs
+        # per-file bookkeeping is array work: a library scan is hundreds of thousands of files, and a microsecond of
+        # interpreter per file and step was a third of the seam's wall clock
+        self.paths = [str(t[1]) for t in tasks]
+        self.fids = np.fromiter((int(t[0]) for t in tasks), np.int64, len(tasks))
 
     def cancelled(self) -> bool:
         if not self.stopped and self.cancel_fn is not None:
@@ -333,63 +370,65 @@ class _Pipeline:
     # ---- the GPU decoders' share of a batch
     def _start_reads(self, start: int) -> dict:
         """The JPEG / PNG files of the batch that begins at ``start``, on their way into memory while the batch before is on
-        the GPU: {"files": position -> (kind, future of the file's bytes | None), "ahead": future of the context's FilesAhead
-        | None, "order": the positions in that buffer's order, JPEG files first}."""
+        the GPU.  Runs on a pool thread (the classification is a pass of the interpreter over the batch, the reading is the
+        library's): {"jpeg" / "png": positions (arrays, ascending), "blobs": position -> future of the file's bytes for a
+        stage without ``hash_files``, "ahead": the context's FilesAhead holding [JPEG files | PNG files] or None}."""
         gpu_jpeg = os.environ.get("KE_GPU_JPEG", "1") != "0"
         gpu_png = os.environ.get("KE_GPU_PNG", "1") != "0"
         by_path = hasattr(self.stage, "hash_files")          # the library reads the files itself, into page-locked memory
-        files = {}
-        for k in range(start, min(start + self.batch, len(self.tasks))):
-            low = str(self.tasks[k][1]).lower()
-            if gpu_jpeg and low.endswith(JPEG_SUFFIXES):
-                files[k] = ("jpeg", None if by_path else self.pool.submit(_read_bytes, self.tasks[k][1]))
-            elif gpu_png and low.endswith(PNG_SUFFIXES):
-                files[k] = ("png", None if by_path else self.pool.submit(_read_bytes, self.tasks[k][1]))
-        order = [k for k, v in files.items() if v[0] == "jpeg"] + [k for k, v in files.items() if v[0] == "png"]
-        ahead = None
-        if by_path and order and hasattr(self.stage, "read_ahead") and os.environ.get("KE_READ_AHEAD", "1") != "0":
-            jpegs = sum(1 for v in files.values() if v[0] == "jpeg")
-            ahead = self.pool.submit(self.stage.read_ahead, [str(self.tasks[k][1]) for k in order],
-                                     (("jpeg", 0, jpegs), ("png", jpegs, len(order))))
-        return {"files": files, "ahead": ahead, "order": order}
-
-    def _decode_on_gpu(self, reads: dict, out: dict) -> list:
-        """Fills ``out[position]`` for the files the GPU decoders take; returns the positions they left to Pillow."""
-        coded: dict = {"jpeg": ([], []), "png": ([], [])}
-        for k, (kind, fut) in reads["files"].items():
-            res = str(self.tasks[k][1]) if fut is None else fut.result()
-            if res is not None:
-                coded[kind][0].append(k)
-                coded[kind][1].append(res)
-        by_path = hasattr(self.stage, "hash_files")
-        held = None
-        if reads["ahead"] is not None:
+        stop = min(start + self.batch, len(self.tasks))
+        tails = [p[-5:].lower() for p in self.paths[start:stop]]
+        kind = np.fromiter((1 if t.endswith(JPEG_SUFFIXES) else 2 if t.endswith(PNG_SUFFIXES) else 0 for t in tails), np.int8, stop - start)
+        jpeg = start + np.nonzero(kind == 1)[0] if gpu_jpeg else np.zeros(0, np.int64)
+        png = start + np.nonzero(kind == 2)[0] if gpu_png else np.zeros(0, np.int64)
+        reads = {"jpeg": jpeg, "png": png, "blobs": {}, "ahead": None}
+        if not by_path:
+            reads["blobs"] = {int(k): self.pool.submit(_read_bytes, self.paths[k]) for k in np.concatenate([jpeg, png]).tolist()}
+        elif len(jpeg) + len(png) and hasattr(self.stage, "read_ahead") and os.environ.get("KE_READ_AHEAD", "1") != "0":
+            order = np.concatenate([jpeg, png]).tolist()
             try:
-                held = reads["ahead"].result()             # None: both buffers taken or too many bytes; the call reads the files
+                reads["ahead"] = self.stage.read_ahead([self.paths[k] for k in order], (("jpeg", 0, len(jpeg)), ("png", len(jpeg), len(order))))
             except Exception:
-                held = None
-        refused = []
+                reads["ahead"] = None                      # the decode call reads the files itself
+        return reads
+
+    def _decode_on_gpu(self, reads: dict, start: int, ph: np.ndarray, dh: np.ndarray, ok: np.ndarray) -> list:
+        """Fills ph / dh / ok (indexed by position - start) for the files the GPU decoders take; returns the positions they
+        left to Pillow."""
+        by_path = hasattr(self.stage, "hash_files")
+        held = reads["ahead"]
+        refused: list = []
         first = 0
         try:
-            for kind, (positions, blobs) in coded.items():
-                if not blobs or self.cancelled():
+            for kind in ("jpeg", "png"):
+                positions = reads[kind]
+                if len(positions) == 0:
                     continue
+                lo, first = first, first + len(positions)
+                if self.cancelled():
+                    continue
+                if not by_path:                            # a stage that takes bytes: files that cannot be read stay with Pillow
+                    got = [(k, reads["blobs"][k].result()) for k in positions.tolist()]
+                    positions = np.array([k for k, b in got if b is not None], np.int64)
+                    blobs = [b for _, b in got if b is not None]
+                    if not blobs:
+                        continue
                 try:
-                    if held is not None:                   # this kind's files are first .. first + len(positions) of the buffer
-                        ph, dh, st = self.stage.hash_ahead(held, first, first + len(positions), kind)
+                    if held is not None:                   # this kind's files are lo .. first of the buffer
+                        p, d, st = self.stage.hash_ahead(held, lo, first, kind)
+                    elif by_path:
+                        p, d, st = self.stage.hash_files([self.paths[k] for k in positions.tolist()], kind)
                     else:
-                        ph, dh, st = self.stage.hash_files(blobs, kind) if by_path else self.stage.jpeg_hash(blobs, kind)
+                        p, d, st = self.stage.jpeg_hash(blobs, kind)
                 except (RuntimeError, ValueError, MemoryError):      # e.g. no room on the device for this batch: Pillow decodes it
-                    refused.extend(positions)
+                    refused.extend(positions.tolist())
                     continue
-                finally:
-                    first += len(positions)
-                signed = zip(np.asarray(ph, np.uint64).view(np.int64).tolist(), np.asarray(dh, np.uint64).view(np.int64).tolist())
-                for k, sig, code in zip(positions, signed, np.asarray(st).tolist()):
-                    if code == 0:
-                        out[k] = sig
-                    else:                                  # outside the GPU decoder: Pillow decodes it, as the reference does
-                        refused.append(k)
+                good = np.asarray(st) == 0
+                at = positions[good] - start
+                ph[at] = np.asarray(p, np.uint64).view(np.int64)[good]
+                dh[at] = np.asarray(d, np.uint64).view(np.int64)[good]
+                ok[at] = True
+                refused.extend(positions[~good].tolist())  # outside the GPU decoder: Pillow decodes it, as the reference does
         finally:
             if held is not None:
                 held.release()
@@ -506,37 +545,57 @@ class _Pipeline:
 
     def run(self) -> Iterator[Tuple[int, Optional[Tuple[int, int]]]]:
         """Yields (file_id, hashes | None) in task order."""
-        for fids, sigs in self.run_batches():
-            yield from zip(fids, sigs)
+        for fids, ph, dh, ok in self.run_batches():
+            for fid, p, d, good in zip(fids.tolist(), ph.tolist(), dh.tolist(), ok.tolist()):
+                yield fid, ((p, d) if good else None)
 
     @staticmethod
-    def _drop_reads(reads) -> None:
-        ahead = reads["ahead"] if reads else None
-        if ahead is not None and ahead.done() and not ahead.cancelled() and ahead.exception() is None and ahead.result() is not None:
-            ahead.result().release()
-
-    def run_batches(self) -> Iterator[Tuple[List[int], List[Optional[Tuple[int, int]]]]]:
-        """Yields ([file_id], [hashes | None]) batch by batch, in task order."""
-        reads_next = None
+    def _drop_reads(future) -> None:
+        """A batch read ahead and never decoded gives its buffer back."""
+        if future is None:
+            return
         try:
-            reads_next = self._start_reads(0)
+            reads = future.result()
+        except Exception:
+            return
+        if reads and reads.get("ahead") is not None:
+            reads["ahead"].release()
+
+    def run_batches(self) -> Iterator[Tuple[np.ndarray, np.ndarray, np.ndarray, np.ndarray]]:
+        """Yields (file ids, pHash, dHash, done) of one batch after the other, in task order: int64 arrays (the hashes as the
+        signed values the table stores) and a mask of the files that were hashed."""
+        ahead_pool = ThreadPoolExecutor(max_workers=1)            # one batch is prepared while the one before it is on the GPU
+        next_reads = None
+        try:
+            next_reads = ahead_pool.submit(self._start_reads, 0)
             for start in range(0, len(self.tasks), self.batch):
                 stop = min(start + self.batch, len(self.tasks))
-                reads = reads_next
-                reads_next = self._start_reads(stop) if stop < len(self.tasks) else None
-                out: dict = {}
+                reads_future, next_reads = next_reads, None
                 if self.cancelled():
-                    self._drop_reads(reads)
+                    self._drop_reads(reads_future)
                     return
-                refused = self._decode_on_gpu(reads, out)
-                todo = sorted([k for k in range(start, stop) if k not in reads["files"]] + refused)
-                self._decode_with_pillow(todo, out)
+                reads = reads_future.result()
+                if stop < len(self.tasks):
+                    next_reads = ahead_pool.submit(self._start_reads, stop)
+                ph, dh = np.zeros(stop - start, np.int64), np.zeros(stop - start, np.int64)
+                ok = np.zeros(stop - start, bool)
+                refused = self._decode_on_gpu(reads, start, ph, dh, ok)
+                taken = np.zeros(stop - start, bool)
+                taken[reads["jpeg"] - start] = True
+                taken[reads["png"] - start] = True
+                todo = sorted((start + np.nonzero(~taken)[0]).tolist() + refused)
+                if todo:
+                    out: dict = {}
+                    self._decode_with_pillow(todo, out)
+                    for k, (p, d) in out.items():
+                        ph[k - start], dh[k - start], ok[k - start] = p, d, True
                 if self.stopped:                                  # abandoned half way: the caller returns what earlier batches gave
                     return
-                yield [int(t[0]) for t in self.tasks[start:stop]], [out.get(k) for k in range(start, stop)]
+                yield self.fids[start:stop], ph, dh, ok
         finally:
+            self._drop_reads(next_reads)                          # abandoned half way: the batch read ahead gives its buffer back
+            ahead_pool.shutdown(wait=True, cancel_futures=True)
             self.pool.shutdown(wait=True, cancel_futures=True)    # no thread may still be writing into a staging buffer
-            self._drop_reads(reads_next)                          # abandoned half way: the batch read ahead gives its buffer back
             try:
                 self.stage.wait(-1)
             except Exception:
@@ -565,8 +624,8 @@ def compute_signatures_mp(tasks: List[Task], *, max_workers: Optional[int] = Non
     pipeline = _Pipeline(tasks, workers, chunksize, device, cancel_fn)
     if cancel_fn is None:                           # nobody to ask between files: whole batches at a time
         seen = 0
-        for fids, sigs in pipeline.run_batches():
-            rows.extend((fid, sig[0], sig[1]) for fid, sig in zip(fids, sigs) if sig is not None)
+        for fids, ph, dh, ok in pipeline.run_batches():
+            rows.extend(zip(fids[ok].tolist(), ph[ok].tolist(), dh[ok].tolist()))
             if progress is not None:
                 before, seen = seen, seen + len(fids)
                 for mark in range((before // PROGRESS_STRIDE + 1) * PROGRESS_STRIDE, seen + 1, PROGRESS_STRIDE):

@@ -97,10 +97,16 @@ def test_scan_100k_equals_the_reference_digests(K):
         assert G.scan_listing_digests(edges, clusters) == (run["edges_sha256"], run["clusters_sha256"])
 
 
-@pytest.mark.parametrize("route", ["gpu_decoders", "pillow_threads"])
+@pytest.mark.parametrize("route", ["gpu_decoders", "pillow_threads", "pillow_threads_truncation_switch_on"])
 def test_worker_corpus_rows_equal_the_reference(K, tmp_path, monkeypatch, route):
+    from PIL import ImageFile
+
     tasks, expected = G.write_worker_corpus(tmp_path)
-    if route == "pillow_threads":
+    # the reference's workers are fresh processes: whatever the calling process did to Pillow's global truncation switch
+    # (safe_load_image leaves it on, src/utils/image_io.py:86) does not reach them
+    monkeypatch.setattr(ImageFile, "LOAD_TRUNCATED_IMAGES", route.endswith("switch_on"))
+    monkeypatch.setenv("KE_DECODE_PROCESS_MIN", "100000")            # threads, also with the switch on
+    if route.startswith("pillow_threads"):
         monkeypatch.setenv("KE_GPU_JPEG", "0")
         monkeypatch.setenv("KE_GPU_PNG", "0")
     seen = []

@@ -314,8 +314,8 @@ def test_fastsig_progress_cadence_over_whole_batches(K, monkeypatch):
 
         def run_batches(self):
             for lo in range(0, len(self.tasks), 128):
-                part = self.tasks[lo:lo + 128]
-                yield [t[0] for t in part], [None if t[0] % 50 == 0 else (-t[0], t[0]) for t in part]
+                fids = np.array([t[0] for t in self.tasks[lo:lo + 128]], np.int64)
+                yield fids, -fids, fids.copy(), fids % 50 != 0
 
     monkeypatch.setattr(fs, "_Pipeline", FakePipeline)
     for total, marks in ((450, [200, 400, 450]), (400, [200, 400]), (199, [199]), (128, [128])):

@@ -197,8 +197,17 @@ int ke_png_decode(ke_ctx *ctx, const uint8_t *files, const uint64_t *offsets, co
  * file carries an EXIF orientation of 2..8 (JPEG APP1; PNG eXIf or a "Raw profile type ..." text chunk -- or EXIF data that
  * cannot be followed); TRANSPARENCY: a PNG tRNS chunk.  Host only. */
 enum { KE_CAVEAT_ORIENTATION = 1, KE_CAVEAT_TRANSPARENCY = 2 };
+/* ke_jpeg_caveats also reports the orientation itself in bits 8..11 (1..8) when the tag could be followed: (flags >> 8) & 15. */
 int ke_jpeg_caveats(const uint8_t *files, const uint64_t *offsets, const uint64_t *sizes, int64_t n, int32_t *flags_out);
 int ke_png_caveats(const uint8_t *files, const uint64_t *offsets, const uint64_t *sizes, int64_t n, int32_t *flags_out);
+
+/* The loader's normalisation itself, for pixels that are on the device already (decoded by ke_jpeg_decode / ke_png_decode):
+ * image k (widths[k] x heights[k], channels[k] = 3 or 4, at src + src_offsets[k]) -> RGB at dst + dst_offsets[k], turned as
+ * ImageOps.exif_transpose turns it for orientations[k] in 1..8 (src/utils/image_io.py:116-120, src/ui/dup_refine_parallel.py:67-70;
+ * 5..8 swap width and height) and, for 4 channels, composited over white as Image.alpha_composite + convert("RGB") do
+ * (src/utils/image_io.py:137-151) -- Pillow's integer arithmetic, bit for bit.  src, dst: device; the arrays: host.  Blocks. */
+int ke_normalise_rgb(ke_ctx *ctx, const uint8_t *src, const uint64_t *src_offsets, const int32_t *widths, const int32_t *heights,
+                     const int32_t *channels, const int32_t *orientations, int64_t n, uint8_t *dst, const uint64_t *dst_offsets);
 
 /* Debug/parity hook: the resampled luma tiles the hashes are computed from
  * (reference sig.phash._to_grayscale, src/sig/phash.py:21-26).  tile32_out: n*1024 bytes

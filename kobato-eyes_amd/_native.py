@@ -29,7 +29,7 @@ EXPORTS = (
     "ke_band_pairs_after_size",
     "ke_stage_create", "ke_stage_create_shared", "ke_stage_destroy", "ke_stage_acquire", "ke_stage_submit_hash", "ke_stage_wait",
     "ke_comm_unique_id", "ke_comm_create", "ke_comm_destroy", "ke_allgather_u64", "ke_allgather_hashes", "ke_allgather_edges",
-    "ke_interleave_shards", "ke_host_alloc", "ke_host_free", "ke_host_pack", "ke_host_read_files", "ke_jpeg_probe", "ke_jpeg_decode", "ke_png_probe", "ke_png_decode", "ke_jpeg_caveats", "ke_png_caveats", "ke_cluster_labels", "ke_ssim_pairs_uniform", "ke_ssim_pairs", "ke_ssim_set_mode", "ke_resize_luma_uniform", "ke_fit_luma_uniform", "ke_tile_ahash", "ke_sad_pairs", "ke_synth_rgb",
+    "ke_interleave_shards", "ke_host_alloc", "ke_host_free", "ke_host_pack", "ke_host_read_files", "ke_jpeg_probe", "ke_jpeg_decode", "ke_png_probe", "ke_png_decode", "ke_jpeg_caveats", "ke_png_caveats", "ke_normalise_rgb", "ke_cluster_labels", "ke_ssim_pairs_uniform", "ke_ssim_pairs", "ke_ssim_set_mode", "ke_resize_luma_uniform", "ke_fit_luma_uniform", "ke_tile_ahash", "ke_sad_pairs", "ke_synth_rgb",
     "ke_synth_rgb_indexed",
     "ke_synth_hashes", "ke_last_kernel_ms",
 )
@@ -131,6 +131,7 @@ def load_library() -> C.CDLL:
         lib.ke_png_decode.argtypes = [vp, vp, vp, vp, i64, vp, vp, vp]
         lib.ke_jpeg_caveats.argtypes = [vp, vp, vp, i64, vp]
         lib.ke_png_caveats.argtypes = [vp, vp, vp, i64, vp]
+        lib.ke_normalise_rgb.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, vp, vp]
         lib.ke_band_pairs_after_size.argtypes = [vp, vp, vp, i64, i32, i32, dbl, i64, vp]
         lib.ke_hamming_scan.argtypes = [vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, dbl, i64, vp, i64,
                                         C.POINTER(i64), vp]
@@ -151,7 +152,7 @@ def load_library() -> C.CDLL:
                      "ke_hash_images", "ke_hash_uniform", "ke_hash_images_ex", "ke_hash_uniform_ex", "ke_luma_tiles_uniform", "ke_hamming_scan", "ke_band_pairs_after_size",
                      "ke_stage_create", "ke_stage_create_shared", "ke_stage_destroy", "ke_stage_acquire", "ke_stage_submit_hash", "ke_stage_wait",
                      "ke_comm_unique_id", "ke_comm_create", "ke_comm_destroy", "ke_allgather_u64", "ke_allgather_hashes", "ke_allgather_edges",
-                     "ke_interleave_shards", "ke_host_alloc", "ke_host_free", "ke_host_pack", "ke_host_read_files", "ke_jpeg_probe", "ke_jpeg_decode", "ke_png_probe", "ke_png_decode", "ke_jpeg_caveats", "ke_png_caveats", "ke_cluster_labels", "ke_ssim_pairs_uniform", "ke_ssim_pairs", "ke_ssim_set_mode", "ke_resize_luma_uniform", "ke_fit_luma_uniform", "ke_tile_ahash",
+                     "ke_interleave_shards", "ke_host_alloc", "ke_host_free", "ke_host_pack", "ke_host_read_files", "ke_jpeg_probe", "ke_jpeg_decode", "ke_png_probe", "ke_png_decode", "ke_jpeg_caveats", "ke_png_caveats", "ke_normalise_rgb", "ke_cluster_labels", "ke_ssim_pairs_uniform", "ke_ssim_pairs", "ke_ssim_set_mode", "ke_resize_luma_uniform", "ke_fit_luma_uniform", "ke_tile_ahash",
                      "ke_sad_pairs", "ke_synth_rgb", "ke_synth_rgb_indexed", "ke_synth_hashes"):
             getattr(lib, name).restype = C.c_int
         _lib = lib
@@ -636,6 +637,44 @@ class Context:
                 self.free(dev)
                 raise
         return dev, out_off, w, h, c, st, flags
+
+    def normalise_rgb(self, src: int, src_offsets, widths, heights, channels, orientations, *, by_shape: bool = False):
+        """Images on the device (decoded files) -> a device buffer of their own (the caller frees it) holding them as the
+        reference's loader would hand them over: turned by their EXIF orientation, RGBA composited over white
+        (ke_normalise_rgb).  Returns (device ptr, byte offsets, widths, heights) of the RGB results, in input order;
+        ``by_shape``: results of one (width, height) lie back to back without padding (a group starts on 16 bytes), so that
+        each group can go to the uniform-batch kernels as it is."""
+        so = np.ascontiguousarray(src_offsets, dtype=np.uint64)
+        w, h = np.ascontiguousarray(widths, dtype=np.int32), np.ascontiguousarray(heights, dtype=np.int32)
+        c, o = np.ascontiguousarray(channels, dtype=np.int32), np.ascontiguousarray(orientations, dtype=np.int32)
+        n = len(so)
+        turned = o >= 5
+        ow, oh = np.where(turned, h, w).astype(np.int32), np.where(turned, w, h).astype(np.int32)
+        nbytes = ow.astype(np.int64) * oh * 3
+        do = np.zeros(n, np.uint64)
+        if by_shape:
+            order = np.lexsort((oh, ow))
+            at, prev = 0, None
+            for k in order.tolist():
+                shape = (int(ow[k]), int(oh[k]))
+                if shape != prev:
+                    at, prev = (at + 15) & ~15, shape
+                do[k] = at
+                at += int(nbytes[k])
+            total = at
+        else:
+            padded = (nbytes + 15) & ~np.int64(15)
+            do[1:] = np.cumsum(padded[:-1]).astype(np.uint64)
+            total = int(padded.sum())
+        dev = self.malloc(total + 64)
+        try:
+            with self._lock:
+                self._check(self._lib.ke_normalise_rgb(self._h, src, _addr(so), _addr(w), _addr(h), _addr(c), _addr(o), n, dev, _addr(do)),
+                            "ke_normalise_rgb")
+        except Exception:
+            self.free(dev)
+            raise
+        return dev, do, ow, oh
 
     def release_decode_buffers(self) -> None:
         """Give back the page-locked packing buffer and the device decode buffer (they are kept between calls otherwise)."""

@@ -781,7 +781,8 @@ KE_API int ke_jpeg_caveats(const uint8_t *files, const uint64_t *offsets, const 
     ke_parallel_ranges(n, [=](int64_t lo, int64_t hi, int) {
         for (int64_t i = lo; i < hi; ++i) {
             const int o = sizes[i] >= 4 ? jpeg_orientation(files + offsets[i], (size_t)sizes[i]) : 1;
-            flags_out[i] = (o < 0 || (o >= 2 && o <= 8)) ? KE_CAVEAT_ORIENTATION : 0;
+            // bits 8..11: the orientation itself where the tag could be followed (1..8), for callers that apply it on the device
+            flags_out[i] = ((o < 0 || (o >= 2 && o <= 8)) ? KE_CAVEAT_ORIENTATION : 0) | (o >= 1 && o <= 8 ? o << 8 : 0);
         }
     });
     return KE_OK;

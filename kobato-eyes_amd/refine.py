@@ -124,11 +124,25 @@ def refine_pairs(pairs: Sequence[tuple], *, thresholds: Optional[RefinementThres
             if not dev:
                 continue
             buffers.append(dev)
-            ok = (st == 0) & (c == 3) & (flags == 0) & (np.maximum(w, h) <= MAX_SIDE)
+            fits = (st == 0) & (np.maximum(w, h) <= MAX_SIDE)          # larger ones are shrunk by the loader (draft mode + LANCZOS)
+            ok = fits & (c == 3) & ((flags & 3) == 0)
             for p, good, o, ww, hh in zip(paths, ok.tolist(), off.tolist(), w.tolist(), h.tolist()):
                 if good:
                     placed[p] = (dev + int(o), ww, hh)
             count["gpu_decodes"] += int(ok.sum())
+            # what the loader does to the rest (src/utils/image_io.py:116-131) happens on the device as well: the EXIF
+            # orientation of a JPEG file applied (every camera writes one), an RGBA PNG composited over white
+            orient = (flags >> 8) & 15
+            turn = fits & (c == 3) & ((flags & 3) == 1) & (orient >= 2) & (orient <= 8) if kind == "jpeg" else np.zeros(len(paths), bool)
+            over = fits & (c == 4) & ((flags & 3) == 0) if kind == "png" else np.zeros(len(paths), bool)
+            fix = np.nonzero(turn | over)[0]
+            if len(fix):
+                dev2, off2, w2, h2 = ctx.normalise_rgb(dev, off[fix], w[fix], h[fix], c[fix], np.where(turn[fix], orient[fix], 1))
+                buffers.append(dev2)
+                for k, o2, ww, hh in zip(fix.tolist(), off2.tolist(), w2.tolist(), h2.tolist()):
+                    placed[paths[k]] = (dev2 + int(o2), ww, hh)
+                count["gpu_decodes"] += len(fix)
+                count["gpu_normalised"] = count.get("gpu_normalised", 0) + len(fix)
 
     def run(chunk: list, placed: dict, arrays: dict, buffers: list) -> None:
         """One ``ke_ssim_pairs`` call for the pairs of this run (the library groups them: one fit launch per (source size,

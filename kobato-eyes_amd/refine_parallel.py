@@ -116,6 +116,22 @@ def _thumbnails_decoded_on_gpu(paths: Sequence[Path], side: int, device: int) ->
                     for k, i in enumerate(idx.tolist()):
                         if st[i] == 0 and not flags[i] & 1:
                             out[part[i]] = thumbs[k]
+                # files to turn first (src/ui/dup_refine_parallel.py:67-70: ImageOps.exif_transpose before the resize -- every
+                # camera writes the tag): turned on the device into a buffer of their own, then shrunk group by group
+                orient = (flags >> 8) & 15
+                turn = np.nonzero((st == 0) & (c == 3) & ((flags & 1) == 1) & (orient >= 2) & (orient <= 8) & (off != not_laid))[0]
+                if len(turn):
+                    dev2, off2, w2, h2 = ctx.normalise_rgb(dev, off[turn], w[turn], h[turn], c[turn], orient[turn], by_shape=True)
+                    try:
+                        order = np.argsort(off2, kind="stable")
+                        shapes2 = np.stack([w2[order], h2[order]], 1)
+                        cuts2 = np.nonzero((shapes2[1:] != shapes2[:-1]).any(1))[0] + 1
+                        for run in np.split(order, cuts2):
+                            thumbs = ctx.resize_luma_uniform(dev2 + int(off2[run[0]]), len(run), int(w2[run[0]]), int(h2[run[0]]), 3, side, side, filter=1)
+                            for k, j in enumerate(run.tolist()):
+                                out[part[int(turn[j])]] = thumbs[k]
+                    finally:
+                        ctx.free(dev2)
             except (RuntimeError, ValueError):
                 pass
             finally:

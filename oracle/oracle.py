@@ -410,3 +410,31 @@ def ssim_luma(a: np.ndarray, b: np.ndarray) -> float:
     b = np.ascontiguousarray(b, dtype=np.uint8)
     assert a.shape == b.shape and a.ndim == 2
     return float(lib().ko_ssim_luma(_ptr(a), _ptr(b), a.shape[1], a.shape[0]))
+
+
+# --------------------------------------------------------------------------- loader normalisation (test infrastructure)
+def normalise_rgb(px: np.ndarray, orientation: int = 1) -> np.ndarray:
+    """What the reference's defensive loader makes of decoded pixels (src/utils/image_io.py:116-131, 137-151): RGBA composited
+    over white as Image.alpha_composite + convert("RGB") do (Pillow's AlphaComposite.c in integers), then turned as
+    ImageOps.exif_transpose turns an image whose EXIF orientation is `orientation` (1..8).  px: HxWx3 or HxWx4 u8."""
+    px = np.asarray(px, np.uint8)
+    if px.shape[2] == 4:
+        sa = px[..., 3:4].astype(np.int64)
+        c = px[..., :3].astype(np.int64)
+        t = c * (sa * 128) + 255 * (255 * 128 - sa * 128) + (0x80 << 7)
+        px = np.where(sa == 0, 255, (((t >> 8) + t) >> 8) >> 7).astype(np.uint8)
+    if orientation == 2:
+        px = px[:, ::-1]
+    elif orientation == 3:
+        px = px[::-1, ::-1]
+    elif orientation == 4:
+        px = px[::-1]
+    elif orientation == 5:
+        px = px.transpose(1, 0, 2)
+    elif orientation == 6:
+        px = px[::-1].transpose(1, 0, 2)
+    elif orientation == 7:
+        px = px[::-1, ::-1].transpose(1, 0, 2)
+    elif orientation == 8:
+        px = px[:, ::-1].transpose(1, 0, 2)
+    return np.ascontiguousarray(px)

@@ -260,13 +260,25 @@ def test_refine_pairs_decodes_on_the_gpu_only_what_the_loader_leaves_alone(K, tm
     exif1 = Image.Exif()
     exif1[0x0112] = 1
     put(9, "upright.jpg", Image.fromarray(noisy), quality=88, exif=exif1.tobytes())
+    # every orientation the tag can ask for (turned on the device: ke_normalise_rgb), alpha of every strength incl. 0 and 255
+    for o in (2, 3, 4, 5, 7, 8):
+        ex = Image.Exif()
+        ex[0x0112] = o
+        put(10 + o, f"turned{o}.jpg", Image.fromarray(noisy if o % 2 else base), quality=90, exif=ex.tobytes())
+    alpha = rng.integers(0, 256, base.shape[:2], dtype=np.uint8)
+    alpha[:8] = 0
+    alpha[8:16] = 255
+    put(20, "alpha_any.png", Image.fromarray(np.dstack([noisy, alpha]), "RGBA"))
     pairs = [(a, b, files[a], files[b]) for a, b in [(0, 1), (0, 2), (1, 2), (0, 3), (3, 2), (0, 4), (4, 2), (0, 5), (5, 1), (6, 0), (7, 2),
-                                                      (6, 7), (8, 0), (8, 8), (9, 0), (9, 2)]]
+                                                      (6, 7), (8, 0), (8, 8), (9, 0), (9, 2), (12, 0), (13, 1), (14, 0), (15, 3), (17, 3),
+                                                      (18, 15), (20, 4), (20, 2)]]
     th = K.RefinementThresholds(ssim=0.8)
     one_by_one = [K.refine_pair(a, b, pa, pb, thresholds=th) for a, b, pa, pb in pairs]
     stats = {}
     assert K.refine_pairs(pairs, thresholds=th, stats=stats) == one_by_one
-    assert stats["decodes"] == 10 and stats["gpu_decodes"] == 4, stats          # a.jpg, b.jpg, c.png, upright.jpg
+    # a.jpg, b.jpg, c.png, upright.jpg as they are; rotated.jpg, the six turned*.jpg, alpha.png and alpha_any.png normalised
+    # on the device; gray, palette and the 4100-pixel-wide file go through the loader
+    assert stats["decodes"] == 17 and stats["gpu_decodes"] == 13 and stats["gpu_normalised"] == 9, stats
     assert any(m.is_duplicate for m in one_by_one) and any(not m.is_duplicate for m in one_by_one)
     os.environ["KE_GPU_REFINE_DECODE"] = "0"
     try:
@@ -305,16 +317,23 @@ def test_shipped_refine_stage_kernels_and_dropins(K, tmp_path):
         assert np.array_equal(lan, O.hash_image(px, want_tiles=True)[2]), name
     for a, b, mae in g["mae"]:
         assert RP._mae01(thumbs[a], thumbs[b]) == mae
-    # the same thumbnails with the files decoded on the GPU (what refine_by_tilehash_parallel does for .jpg / .png), a JPEG
-    # stored rotated excluded: that one is for Image.open + exif_transpose
+    # the same thumbnails with the files decoded on the GPU (what refine_by_tilehash_parallel does for .jpg / .png), JPEG files
+    # stored rotated included: == Image.open + exif_transpose + resize
     turned = tmp_path / "turned.jpg"
     exif = Image.Exif()
     exif[0x0112] = 8
     Image.fromarray(next(px for _, px in G.refine_corpus() if px.ndim == 3 and px.shape[2] == 3)).save(turned, quality=90, exif=exif.tobytes())
     plain = tmp_path / "plain.jpg"
     Image.fromarray(next(px for _, px in G.refine_corpus() if px.ndim == 3 and px.shape[2] == 3)).save(plain, quality=90)
-    on_gpu = RP._thumbnails_decoded_on_gpu(list(paths.values()) + [turned, plain], 32, 0)
-    assert set(on_gpu) == set(paths.values()) | {plain}
+    more = []
+    for o in (2, 3, 4, 5, 6, 7):                     # every other orientation, on images of two shapes
+        ex = Image.Exif()
+        ex[0x0112] = o
+        src = [px for _, px in G.refine_corpus() if px.ndim == 3 and px.shape[2] == 3][o % 3]
+        more.append(tmp_path / f"turned{o}.jpg")
+        Image.fromarray(src).save(more[-1], quality=90, exif=ex.tobytes())
+    on_gpu = RP._thumbnails_decoded_on_gpu(list(paths.values()) + [turned, plain] + more, 32, 0)
+    assert set(on_gpu) == set(paths.values()) | {plain, turned} | set(more)        # turned on the device (ke_normalise_rgb)
     for p, t in on_gpu.items():
         assert np.array_equal(t, RP._thumbnails([RP._decode(p)], 32, 0)[0]), p
 

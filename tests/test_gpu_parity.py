@@ -884,3 +884,43 @@ def test_scan_sweep_random_tables():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz_scan.py"), "120", "99"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_loader_normalisation_on_the_device(ctx):
+    """ke_normalise_rgb == the oracle (pinned against Pillow's exif_transpose and alpha_composite in the CPU suite) for every
+    orientation, RGB and RGBA sources, odd sizes, one call."""
+    rng = np.random.default_rng(23)
+    imgs, orient = [], []
+    for k, (w, h) in enumerate([(53, 37), (1, 1), (64, 48), (7, 200), (301, 5), (128, 128), (17, 16), (96, 97)]):
+        for o in range(1, 9):
+            ch = 3 if (k + o) % 2 else 4
+            px = rng.integers(0, 256, (h, w, ch), dtype=np.uint8)
+            if ch == 4:
+                px[: max(1, h // 4), :, 3] = 0
+                px[max(1, h // 4): max(2, h // 2), :, 3] = 255
+            imgs.append(px)
+            orient.append(o)
+    sizes = [(a.size + 15) & ~15 for a in imgs]
+    offs = np.concatenate([[0], np.cumsum(sizes[:-1])]).astype(np.uint64)
+    flat = np.zeros(sum(sizes), np.uint8)
+    for a, o in zip(imgs, offs.tolist()):
+        flat[o:o + a.size] = a.reshape(-1)
+    src = ctx.malloc(len(flat) + 64)
+    try:
+        ctx.memcpy(src, flat, len(flat))
+        for by_shape in (False, True):
+            dev, do, ow, oh = ctx.normalise_rgb(src, offs, [a.shape[1] for a in imgs], [a.shape[0] for a in imgs],
+                                                [a.shape[2] for a in imgs], orient, by_shape=by_shape)
+            try:
+                for a, o, d, w2, h2 in zip(imgs, orient, do.tolist(), ow.tolist(), oh.tolist()):
+                    exp = O.normalise_rgb(a, o)
+                    assert exp.shape == (h2, w2, 3)
+                    got = np.empty(exp.shape, np.uint8)
+                    ctx.memcpy(got, dev + d, got.nbytes)
+                    assert np.array_equal(got, exp), (a.shape, o)
+            finally:
+                ctx.free(dev)
+    finally:
+        ctx.free(src)
+    with pytest.raises(ValueError):
+        ctx.normalise_rgb(src, [0], [4], [4], [3], [9])

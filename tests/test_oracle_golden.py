@@ -193,3 +193,26 @@ def test_degenerate_tiles_are_pinned():
         got_p, got_d, _, _, got_m = O.hash_image(px, want_tiles=True)
         assert (got_p, got_d) == (ph, dh), name
         assert np.float32(got_m) == np.float32(margin), name
+
+
+def test_loader_normalisation_matches_installed_pillow(tmp_path):
+    """oracle.normalise_rgb (what ke_normalise_rgb is held against) == ImageOps.exif_transpose of a file carrying each
+    orientation, and == Image.alpha_composite over white + convert("RGB") for every (channel value, alpha) pair."""
+    Image = pytest.importorskip("PIL.Image")
+    from PIL import ImageOps
+
+    rng = np.random.default_rng(17)
+    a = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    for o in range(1, 9):
+        ex = Image.Exif()
+        ex[0x0112] = o
+        p = tmp_path / f"o{o}.png"                              # PNG: lossless, and Pillow reads its eXIf chunk
+        Image.fromarray(a).save(p, exif=ex.tobytes())
+        with Image.open(p) as im:
+            ref = np.asarray(ImageOps.exif_transpose(im))
+        assert np.array_equal(O.normalise_rgb(a, o), ref), o
+    cc, aa = np.meshgrid(np.arange(256), np.arange(256))
+    px = np.stack([cc, 255 - cc, (cc * 7) % 256, aa], -1).astype(np.uint8)
+    bg = Image.new("RGBA", (256, 256), "WHITE")
+    bg.alpha_composite(Image.fromarray(px, "RGBA"))
+    assert np.array_equal(O.normalise_rgb(px), np.asarray(bg.convert("RGB")))

@@ -1,11 +1,11 @@
 #!/usr/bin/env bash
 # Collects everything DESIGN.md section 5 quotes for the tree it is run from, on the GPU box:
-#   gpurun --timeout 1100 -- 'bash profiles/collect.sh r02'
+#   gpurun --timeout 1150 -- 'bash profiles/collect.sh r03'        (round 3: part 2 with `bash profiles/collect.sh r03 more`)
 # Outputs land under gpurun_out/<tag>_*; `python profiles/summarize.py <tag> ...` (see README.md) condenses them into profiles/.
 # rocprofv3 gets the program itself after `--` (python3 bench.py ...), never a wrapper; counters are collected in their
 # own passes (FETCH_SIZE and WRITE_SIZE do not fit one pass; no trace domains beside --pmc).
 set -uo pipefail
-tag="${1:-r02}"
+tag="${1:-r03}"
 root="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
 out="$root/gpurun_out"
 mkdir -p "$out"
@@ -13,6 +13,30 @@ cd /tmp && export TMPDIR=/tmp
 B="$root/bench.py"
 run() { echo "== $*" >&2; "$@"; echo "rc=$?" >&2; }
 
+if [ "${2:-}" = "more" ]; then
+    # ---- second call of a round (the first one fills its time limit): everything DESIGN.md section 5 quotes beyond the headline
+    # pHash + dHash in one launch (what the batch-hasher seam runs), its kernel statistics
+    run python3 "$B" --steps 10 --warmup 3 --dhash --no-cpu-baseline --no-h2d --no-decode > "$out/${tag}_bench_dhash.json" 2> "$out/${tag}_bench_dhash.err"
+    run rocprofv3 --kernel-trace --stats --output-format csv -d "$out/${tag}_stats_dhash" -- python3 "$B" --steps 10 --warmup 3 --dhash --no-cpu-baseline --no-h2d --no-decode > "$out/${tag}_stats_dhash.log" 2>&1
+    # the self-launched form of the bench (the parent starts the rank under torch.distributed.run; RCCL exchange on one rank)
+    run python3 "$B" --gpus 1 --self-launch --steps 10 --warmup 3 --no-cpu-baseline --no-h2d --no-decode > "$out/${tag}_bench_selflaunch.json" 2> "$out/${tag}_bench_selflaunch.err"
+    # BASELINE configs[4] share on one GPU: 125 000 mixed-resolution images, pHash alone and both hashes, kernel statistics
+    : > "$out/${tag}_mixed.jsonl"
+    run python3 "$root/benchmarks/bench_mixed.py" --images 125000 >> "$out/${tag}_mixed.jsonl" 2>> "$out/${tag}_mixed.err"
+    run python3 "$root/benchmarks/bench_mixed.py" --images 125000 --dhash >> "$out/${tag}_mixed.jsonl" 2>> "$out/${tag}_mixed.err"
+    run rocprofv3 --kernel-trace --stats --output-format csv -d "$out/${tag}_stats_mixed" -- python3 "$root/benchmarks/bench_mixed.py" --images 125000 --dhash --reps 2 > "$out/${tag}_stats_mixed.log" 2>&1
+    # every (width, height) of that config on its own
+    run python3 "$root/benchmarks/shape_grid.py" > "$out/${tag}_shape_grid_phash.txt" 2>> "$out/${tag}_mixed.err"
+    run python3 "$root/benchmarks/shape_grid.py" dhash > "$out/${tag}_shape_grid_both.txt" 2>> "$out/${tag}_mixed.err"
+    # per-kernel lines (hash shapes with and without dHash, scan at 100 000 / 1 000 000, SSIM pairs)
+    run python3 "$root/benchmarks/bench_kernels.py" --cases hash,scan,ssim > "$out/${tag}_kernels.jsonl" 2> "$out/${tag}_kernels.err"
+    # the seams: scanner (Python objects in, clusters out), decode call phases
+    run python3 "$root/benchmarks/bench_scanner.py" > "$out/${tag}_scanner.jsonl" 2> "$out/${tag}_scanner.err"
+    run python3 "$root/benchmarks/bench_scanner.py" --funnel --sizes 1000000 >> "$out/${tag}_scanner.jsonl" 2>> "$out/${tag}_scanner.err"
+    run python3 "$root/benchmarks/decode_phases.py" 4096,16384,32768,65536 > "$out/${tag}_decode_phases.jsonl" 2> "$out/${tag}_decode_phases.err"
+    ls "$out" | grep "^${tag}_" | head -60
+    exit 0
+fi
 # 1. the bench lines themselves
 run python3 "$B" --steps 10 --warmup 3 > "$out/${tag}_bench.json" 2> "$out/${tag}_bench.err"
 run python3 "$B" --steps 10 --warmup 3 --ssim-threshold 0.95 --no-cpu-baseline --no-h2d --no-decode > "$out/${tag}_bench_ssim095.json" 2> "$out/${tag}_bench_ssim095.err"

@@ -8,7 +8,7 @@ import shutil
 import subprocess
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 here = os.path.dirname(os.path.abspath(__file__))
 g = os.path.join(os.path.dirname(here), "gpurun_out")
 pmc = sorted(glob.glob(os.path.join(g, f"{tag}_pmc_*")))
@@ -29,6 +29,20 @@ if os.path.exists(os.path.join(g, f"{tag}_decode.jsonl")):
         found = glob.glob(os.path.join(g, f"{tag}_stats_{fmt}", "**", "*_kernel_stats.csv"), recursive=True)
         if found:
             shutil.copy(sorted(found, key=os.path.getmtime)[-1], os.path.join(here, f"{tag}_{fmt}_decode_kernel_stats.csv"))
+# round 3 extras (collect.sh <tag> more): copied as they are, JSON lines filtered from whatever else the programs printed
+for name in (f"{tag}_bench_dhash.json", f"{tag}_bench_selflaunch.json", f"{tag}_mixed.jsonl", f"{tag}_kernels.jsonl", f"{tag}_scanner.jsonl",
+             f"{tag}_decode_phases.jsonl"):
+    src = os.path.join(g, name)
+    if os.path.exists(src):
+        open(os.path.join(here, name), "w").writelines(l for l in open(src) if l.startswith("{"))
+for name in (f"{tag}_shape_grid_phash.txt", f"{tag}_shape_grid_both.txt"):
+    src = os.path.join(g, name)
+    if os.path.exists(src):
+        open(os.path.join(here, name), "w").writelines(l for l in open(src) if not l.startswith(("==", "rc=")) and "amdgpu.ids" not in l)
+for sub, dst in (("stats_dhash", f"{tag}_dhash_kernel_stats.csv"), ("stats_mixed", f"{tag}_mixed125k_kernel_stats.csv")):
+    found = glob.glob(os.path.join(g, f"{tag}_{sub}", "**", "*_kernel_stats.csv"), recursive=True)
+    if found:
+        shutil.copy(sorted(found, key=os.path.getmtime)[-1], os.path.join(here, dst))
 h = json.load(open(os.path.join(here, f"{tag}_pmc.json")))["hash"]
 json.dump({"kernel": "ke_phash_fused_mx<8,5,false,false,3,false>", "images_per_launch": 100000, "side": 512,
            "source": f"profiles/{tag}_pmc.json: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, bench.py --steps 2 --warmup 1 "

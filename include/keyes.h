@@ -183,7 +183,8 @@ int ke_jpeg_decode(ke_ctx *ctx, const uint8_t *files, const uint64_t *offsets, c
  * Image.open by construction (zlib/deflate, the five scanline filters).  One thread per image walks the deflate stream
  * (literals to their place, LZ77 copies recorded), one wave per image then makes the copies and one wave per image undoes the
  * filters and checks the stream's Adler-32; throughput comes from the batch.  Chunk CRCs are verified where Pillow verifies
- * them (every chunk but IDAT).  16-bit, gray+alpha, interlaced and animated files and rows wider than 16384 pixels:
+ * them (every chunk but IDAT).  16-bit, interlaced and animated files (8-bit gray + alpha files are taken: they decode to their gray samples, what
+ * convert("L") makes of mode "LA") and rows wider than 16384 pixels:
  * KE_JPEG_UNSUPPORTED_ (1) per file, damaged ones KE_JPEG_CORRUPT_ (2).  Arguments and conventions as ke_jpeg_probe /
  * ke_jpeg_decode; channels is 1, 3 or 4. */
 int ke_png_probe(const uint8_t *files, const uint64_t *offsets, const uint64_t *sizes, int64_t n, int32_t *widths,

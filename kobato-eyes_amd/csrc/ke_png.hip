@@ -369,7 +369,7 @@ __global__ __launch_bounds__(64) void ke_png_unfilter(const KePngDev *__restrict
     __shared__ uint8_t s_lut[MAPPED ? 256 : 4];
     const int64_t i = blockIdx.x;
     const KePngDev &d = imgs[i];
-    if (d.info.channels != BPP || (d.info.mapped != 0) != MAPPED || status[i] != KE_PNG_OK) return;
+    if (d.info.fbpp != BPP || (d.info.mapped != 0) != MAPPED || status[i] != KE_PNG_OK) return;
     const int lane = threadIdx.x;
     if (MAPPED) {
         for (int k = lane; k < 256; k += 64) s_lut[k] = d.info.lut[k];
@@ -478,10 +478,19 @@ __global__ __launch_bounds__(64) void ke_png_unfilter(const KePngDev *__restrict
                 ow[0] = o[0] | (o[1] << 24);
                 ow[1 % kWords] = (o[1] >> 8) | (o[2] << 16);
                 ow[2 % kWords] = (o[2] >> 16) | (o[3] << 8);
+            } else if (BPP == 2) {
+                ow[0] = o[0] | (o[1] << 16);
+                ow[1 % kWords] = o[2] | (o[3] << 16);
             } else {
                 ow[0] = o[0] | (o[1] << 8) | (o[2] << 16) | (o[3] << 24);
             }
-            if (MAPPED) {
+            if (BPP == 2) {
+                // gray + alpha: only the gray samples leave (one byte per pixel, rows of `width` bytes)
+                const uint32_t gray = (o[0] & 255u) | ((o[1] & 255u) << 8) | ((o[2] & 255u) << 16) | ((o[3] & 255u) << 24);
+                uint8_t *wp = dst + (size_t)row * W + (size_t)g * 4;
+                if (valid == 4) __builtin_memcpy(wp, &gray, 4);
+                else for (int e = 0; e < valid; ++e) wp[e] = (uint8_t)(gray >> (8 * e));
+            } else if (MAPPED) {
                 const int depth = d.info.depth, per = 8 / depth, px = d.info.width;
                 const uint32_t top = (1u << depth) - 1u;
                 uint8_t *wp = dst + (size_t)row * px;
@@ -674,7 +683,7 @@ KE_API int ke_png_decode(ke_ctx *ctx, const uint8_t *files, const uint64_t *offs
                 }
             zbytes += zl;
             raw_bytes += rw;
-            max_groups = std::max(max_groups, (it.d.info.row_bytes / (it.d.info.mapped ? 1 : it.d.info.channels) + 3) >> 2);
+            max_groups = std::max(max_groups, (it.d.info.row_bytes / (it.d.info.mapped ? 1 : it.d.info.fbpp) + 3) >> 2);
             devs.push_back(it.d);
             ++last;
         }
@@ -706,8 +715,8 @@ KE_API int ke_png_decode(ke_ctx *ctx, const uint8_t *files, const uint64_t *offs
                            (const uint2 *)d_rec, (const int32_t *)d_status, (const uint32_t *)d_nrec);
         const size_t row_lds = (size_t)max_groups * 16;
         // one launch per kind present in the sub-batch (a workgroup whose image is of another kind returns at once)
-        bool kinds[4] = {false, false, false, false};
-        for (const KePngDev &d : devs) kinds[d.info.mapped ? 3 : d.info.channels == 1 ? 0 : d.info.channels == 3 ? 1 : 2] = true;
+        bool kinds[5] = {false, false, false, false, false};
+        for (const KePngDev &d : devs) kinds[d.info.mapped ? 3 : d.info.fbpp == 2 ? 4 : d.info.channels == 1 ? 0 : d.info.channels == 3 ? 1 : 2] = true;
 #define KE_UNFILTER(BPP, MAPPED)                                                                                                    \
     hipLaunchKernelGGL((ke_png_unfilter<BPP, MAPPED>), dim3((unsigned)m), dim3(64), row_lds, ctx->stream, (const KePngDev *)d_imgs,  \
                        (const uint8_t *)d_raw, pixels_out, (int32_t *)d_status, (const uint32_t *)d_adler)
@@ -715,6 +724,7 @@ KE_API int ke_png_decode(ke_ctx *ctx, const uint8_t *files, const uint64_t *offs
         if (kinds[1]) KE_UNFILTER(3, false);
         if (kinds[2]) KE_UNFILTER(4, false);
         if (kinds[3]) KE_UNFILTER(1, true);
+        if (kinds[4]) KE_UNFILTER(2, false);
 #undef KE_UNFILTER
         KE_HIP(ctx, hipGetLastError());
         st.resize((size_t)m);

@@ -3,7 +3,7 @@
 // scanline filters of the PNG specification (None, Sub, Up, Average, Paeth).  Lossless, so "the pixels Pillow yields" is a
 // matter of following the two specifications; what is decoded is what `Image.open(path)` hands the reference's batch hasher
 // (src/core/fastsig.py:31-34) for 8-bit grayscale, RGB and RGBA files without interlacing.  Everything else (palette, 16-bit,
-// gray+alpha, Adam7) is refused by the parser and stays with Pillow.  Palette files and grayscale files of 1 / 2 / 4 bits are
+// Adam7) is refused by the parser and stays with Pillow.  Palette files and grayscale files of 1 / 2 / 4 bits are
 // decoded to the luma Pillow's `convert("L")` makes of them -- which is what the reference's hashes see (src/sig/phash.py:25):
 // samples unpacked most significant bits first, mapped through a 256-entry table (palette entry -> L by ImagingConvert's
 // rounded 16-bit weights; 1 / 2 / 4-bit gray scaled to 0..255).
@@ -39,6 +39,9 @@ struct KePngInfo {
     int32_t depth;                       // bits per sample in the file: 8, or 1 / 2 / 4 for the mapped kinds below
     int32_t mapped;                      // palette files and grayscale below 8 bits: samples are indices into `lut`, the
     uint8_t lut[256];                    // luma Pillow's convert("L") gives each of them (the reference hashes that)
+    int32_t fbpp;                        // bytes per pixel in the file = the filters' unit: `channels`, except gray + alpha (2):
+                                         // such a file decodes to its gray samples alone -- what convert("L") makes of mode "LA",
+                                         // i.e. what the reference hashes (src/sig/phash.py:25)
 };
 
 KE_PNG_HD uint32_t ke_brev32(uint32_t v) {

@@ -2,7 +2,7 @@
 // signature, IHDR, where the IDAT payloads lie (their concatenation is one zlib stream per image), IEND; chunk CRCs are
 // verified where Pillow's ChunkStream verifies them (a damaged file raises there and the reference drops it,
 // src/core/fastsig.py:36-37).  8-bit grayscale, RGB
-// and RGBA without interlacing are taken; palette, 16-bit, sub-byte depths, gray+alpha and Adam7 files are KE_PNG_UNSUPPORTED
+// and RGBA without interlacing are taken; 16-bit and Adam7 files are KE_PNG_UNSUPPORTED (palette / sub-byte gray / gray + alpha files decode to the luma convert("L") gives them)
 // and stay with Pillow.
 #pragma once
 
@@ -72,7 +72,8 @@ static inline void ke_parse_png(const uint8_t *p, size_t size, std::vector<KePng
             info.height = (int32_t)be32(pos + 12);
             const int depth = data[8], ctype = data[9], comp = data[10], filt = data[11], lace = data[12];
             if (info.width <= 0 || info.height <= 0 || comp != 0 || filt != 0) return;
-            info.channels = (ctype == 0 || ctype == 3) ? 1 : ctype == 2 ? 3 : ctype == 6 ? 4 : 0;
+            info.channels = (ctype == 0 || ctype == 3 || ctype == 4) ? 1 : ctype == 2 ? 3 : ctype == 6 ? 4 : 0;
+            info.fbpp = ctype == 4 ? 2 : info.channels;
             const bool sub8 = (ctype == 0 || ctype == 3) && (depth == 1 || depth == 2 || depth == 4);
             if (!(depth == 8 || sub8) || info.channels == 0 || lace != 0 || info.width > KE_PNG_MAX_WIDTH ||
                 (uint64_t)info.width * info.height > (1ull << 28)) {
@@ -83,7 +84,7 @@ static inline void ke_parse_png(const uint8_t *p, size_t size, std::vector<KePng
             }
             info.depth = depth;
             info.mapped = (ctype == 3 || sub8) ? 1 : 0;
-            info.row_bytes = (int32_t)(((int64_t)info.width * info.channels * depth + 7) / 8);
+            info.row_bytes = (int32_t)(((int64_t)info.width * info.fbpp * depth + 7) / 8);
             palette = ctype == 3;
             if (info.mapped && !palette)                      // 1 / 2 / 4-bit gray: Pillow's "1", "L;2", "L;4" unpackers scale to 0..255
                 for (int v = 0; v < (1 << depth); ++v) info.lut[v] = (uint8_t)(v * 255 / ((1 << depth) - 1));

@@ -70,6 +70,16 @@ int ko_png_decode(const uint8_t *file, uint64_t size, uint8_t *out) {
         }
         return KE_PNG_OK;
     }
+    if (info.fbpp != info.channels) {                        // gray + alpha: unfilter the two-byte pixels, keep the gray samples
+        std::vector<uint8_t> rows((size_t)rb * info.height);
+        for (int y = 0; y < info.height; ++y) {
+            const uint8_t *row = raw.data() + (size_t)y * (rb + 1);
+            if (ke_png_unfilter_row(row[0], row + 1, y ? rows.data() + (size_t)(y - 1) * rb : nullptr, rows.data() + (size_t)y * rb, rb, info.fbpp) != KE_PNG_OK)
+                return KE_PNG_CORRUPT;
+            for (int x = 0; x < info.width; ++x) out[(size_t)y * info.width + x] = rows[(size_t)y * rb + (size_t)x * info.fbpp];
+        }
+        return KE_PNG_OK;
+    }
     for (int y = 0; y < info.height; ++y) {
         const uint8_t *row = raw.data() + (size_t)y * (rb + 1);
         if (ke_png_unfilter_row(row[0], row + 1, y ? out + (size_t)(y - 1) * rb : nullptr, out + (size_t)y * rb, rb, info.channels) != KE_PNG_OK)

@@ -63,6 +63,14 @@ def mapped(full: bool = False):
         Image.fromarray(rng.integers(0, 2, (h, w), dtype=np.uint8) * 255).convert("1").save(b, "PNG")
         data = b.getvalue()
         yield f"bilevel_{w}x{h}", data, np.asarray(Image.open(io.BytesIO(data)).convert("L"))
+        la = np.stack([rng.integers(0, 256, (h, w), dtype=np.uint8), rng.integers(0, 256, (h, w), dtype=np.uint8)], -1)
+        if (w, h) == (101, 77):
+            la[:, :, 0] = np.repeat(np.repeat(rng.integers(0, 256, (h // 8 + 1, w // 8 + 1), dtype=np.uint8), 8, 0), 8, 1)[:h, :w]
+        for kw in ({}, {"compress_level": 9}) if full or (w, h) == (64, 64) else ({},):
+            b = io.BytesIO()                                         # gray + alpha: the reference hashes convert("L") = the gray band
+            Image.fromarray(la, "LA").save(b, "PNG", **kw)
+            data = b.getvalue()
+            yield f"LA_{w}x{h}_{kw}", data, np.asarray(Image.open(io.BytesIO(data)).convert("L"))
         for depth in (2, 4):                                         # grayscale below 8 bits: rows packed by hand
             per = 8 // depth
             vals = rng.integers(0, 1 << depth, (h, w), dtype=np.uint8)
@@ -126,10 +134,6 @@ def refused():
     """Yields (name, file bytes, expected status): 1 = left to Pillow, 2 = damaged."""
     rng = np.random.default_rng(4)
     a = rng.integers(0, 256, (20, 30, 3), dtype=np.uint8)
-    for mode in ("LA",):
-        b = io.BytesIO()
-        Image.fromarray(a).convert(mode).save(b, "PNG")
-        yield f"mode_{mode}", b.getvalue(), 1
     b = io.BytesIO()
     Image.fromarray(a).convert("P").save(b, "PNG")
     pal = b.getvalue()

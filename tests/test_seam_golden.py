@@ -5,6 +5,7 @@ family (src/core/fastsig.py:24-37)."""
 from __future__ import annotations
 
 import io
+import os
 import warnings
 
 import numpy as np
@@ -52,26 +53,33 @@ def test_scan_100k_oracle_equals_reference_digests():
         assert G.scan_listing_digests(triples, clusters) == (run["edges_sha256"], run["clusters_sha256"])
 
 
-def test_worker_corpus_host_normalisation_plus_oracle_equals_reference():
-    """What the build's Pillow route does on the host (Image.open -> image_to_array: L / RGB / RGBA untouched, every other
-    mode through convert("L")) followed by the oracle's hashes == the reference worker's row for every file of the corpus;
-    files the reference drops fail to open or decode here as well."""
-    Image = pytest.importorskip("PIL.Image")
-    from kobato_eyes_amd.phash import image_to_array
+def test_worker_corpus_host_normalisation_plus_oracle_equals_reference(tmp_path):
+    """What the build's Pillow route does on the host (fastsig._read_pixels: Image.open -> image_to_array -- L / RGB / RGBA
+    untouched, every other mode through convert("L") -- strict about truncation whatever Pillow's process-wide switch says)
+    followed by the oracle's hashes == the reference worker's row for every file of the corpus; files the reference drops fail
+    to open or decode here as well.  Run once with the switch as it is and once with it on (safe_load_image leaves it on)."""
+    pytest.importorskip("PIL.Image")
+    from PIL import ImageFile
 
-    n_rows = 0
-    for name, data, fid, row, opened_as in G.worker_golden():
-        got = None
-        if data is not None:
-            try:
+    from kobato_eyes_amd import fastsig
+
+    tasks, expected = G.write_worker_corpus(tmp_path)
+    rows = {r[0]: r for r in expected}
+    saved = ImageFile.LOAD_TRUNCATED_IMAGES
+    try:
+        for switch in (False, True):
+            ImageFile.LOAD_TRUNCATED_IMAGES = switch
+            n_rows = 0
+            for fid, path in tasks:
                 with warnings.catch_warnings():
                     warnings.simplefilter("ignore")
-                    with Image.open(io.BytesIO(data)) as im:
-                        arr = image_to_array(im)
-                p, d = O.hash_image(arr)
-                got = (fid, O.to_signed64(p), O.to_signed64(d))
-            except Exception:
+                    arr = fastsig._read_pixels(path)
                 got = None
-        assert got == row, name
-        n_rows += row is not None
-    assert n_rows >= 60
+                if arr is not None and arr.size:
+                    p, d = O.hash_image(arr)
+                    got = (fid, O.to_signed64(p), O.to_signed64(d))
+                assert got == rows.get(fid), (os.path.basename(path), switch)
+                n_rows += got is not None
+            assert n_rows >= 60 and ImageFile.LOAD_TRUNCATED_IMAGES == switch      # the switch is put back as it was found
+    finally:
+        ImageFile.LOAD_TRUNCATED_IMAGES = saved

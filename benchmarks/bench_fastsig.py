@@ -26,7 +26,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--images", type=int, default=16384)
     ap.add_argument("--side", type=int, default=512)
-    ap.add_argument("--format", choices=["jpeg", "png", "mixed"], default="jpeg")
+    ap.add_argument("--format", choices=["jpeg", "png", "mixed", "bmp", "webp", "tiff"], default="jpeg",
+                    help="bmp / webp / tiff: formats outside the GPU decoders -- the whole batch takes the Pillow route (decoder processes)")
+    ap.add_argument("--distinct", type=int, default=128, help="distinct images behind the files")
     ap.add_argument("--content", choices=["corpus", "drawing"], default="corpus")
     ap.add_argument("--pillow-sample", type=int, default=4096, help="files of the batch given to the Pillow-route run")
     args = ap.parse_args()
@@ -35,7 +37,7 @@ def main():
     from kobato_eyes_amd import _native, fastsig
 
     ctx = _native.get_context(0)
-    distinct, s = 128, args.side
+    distinct, s = args.distinct, args.side
     px = ctx.synth_rgb(20260604, 0, distinct, s, s)
     if args.content == "drawing":
         rng = np.random.default_rng(11)
@@ -43,9 +45,12 @@ def main():
         px = np.repeat(np.repeat(cells, 16, 1), 16, 2)[:, :s, :s].copy()
         px[:, ::48, :, :] = 0
         px[:, :, ::64, :] = 0
-    encoded = {"jpeg": [], "png": []}
+    encoded = {"jpeg": [], "png": [], "bmp": [], "webp": [], "tiff": []}
+    wanted = ("jpeg", "png") if args.format == "mixed" else (args.format,)
     for k in range(distinct):
-        for fmt, kw in (("jpeg", {"quality": 85, "subsampling": 2}), ("png", {})):
+        for fmt, kw in (("jpeg", {"quality": 85, "subsampling": 2}), ("png", {}), ("bmp", {}), ("webp", {"quality": 85, "method": 0}), ("tiff", {})):
+            if fmt not in wanted:
+                continue
             b = io.BytesIO()
             Image.fromarray(px[k]).save(b, fmt.upper(), **kw)
             encoded[fmt].append(b.getvalue())
@@ -54,7 +59,7 @@ def main():
         items, nbytes = [], 0
         for i in range(args.images):
             fmt = args.format if args.format != "mixed" else ("jpeg", "png")[i & 1]
-            path = os.path.join(root, f"f{i:07d}.{'jpg' if fmt == 'jpeg' else 'png'}")
+            path = os.path.join(root, f"f{i:07d}.{'jpg' if fmt == 'jpeg' else fmt}")
             data = encoded[fmt][i % distinct]
             with open(path, "wb") as fh:
                 fh.write(data)

@@ -33,10 +33,13 @@ def _listing(clusters):
     return [{"keeper_id": c.keeper_id, "entries": [[e.file.file_id, e.best_hamming] for e in c.files]} for c in clusters]
 
 
-def test_config0_arrays_hash_scan_cluster_equal_the_reference(K):
+@pytest.mark.parametrize("dispatch", ["single_pass_forced", "default"])
+def test_config0_arrays_hash_scan_cluster_equal_the_reference(K, monkeypatch, dispatch):
     g = G.config0_golden()
     ctx = K._native.get_context(0)
     n, side = g["n"], g["side"]
+    if dispatch == "default":                       # the library's own choice of kernels (tests/conftest.py lifts it otherwise)
+        monkeypatch.delenv("KE_FUSED_MIN_IMAGES", raising=False)
     px = ctx.synth_rgb(20260604, 0, n, side, side)
     ph, dh = ctx.hash_uniform(px, n, side, side, 3)
     assert np.asarray(ph, np.uint64).view(np.int64).tolist() == g["phash_s64"]

@@ -95,8 +95,9 @@ class _StrictPillow:
         return False
 
 
-def _read_pixels(path_text: str):
-    """Pixels of one file, or None for anything that cannot be opened (speed first: no reason kept)."""
+def _read_pixels(path_text: str, room: Optional[int] = None):
+    """Pixels of one file, or None for anything that cannot be opened (speed first: no reason kept).  With ``room``: a file
+    whose pixels would not fit is not decoded at all -- its decoded size (an int) comes back instead (the header says it)."""
     try:
         from PIL import Image
 
@@ -104,6 +105,10 @@ def _read_pixels(path_text: str):
         if not path.is_file():
             return None
         with _StrictPillow(), Image.open(path) as im:
+            if room is not None:
+                need = _decoded_bytes(im)
+                if need > room:
+                    return int(need)
             return _phash.image_to_array(im)
     except Exception:
         return None
@@ -144,19 +149,40 @@ def _decode_into_shared(job):
         _worker_maps[shm_path] = view
     out, cursor, end = [], start, start + length
     for p in paths:
-        arr = _read_pixels(p)
-        if arr is None or arr.size == 0:
+        off = (cursor + 15) & ~15
+        arr = _read_pixels(p, room=end - off)
+        if arr is None or (not isinstance(arr, int) and arr.size == 0):
             out.append(None)
             continue
-        off = (cursor + 15) & ~15
-        if off + arr.size > end:
-            out.append("spill")
+        if isinstance(arr, int):                      # does not fit what is left of the region: not decoded, its size handed back
+            out.append(("spill", arr))
             continue
         view[off:off + arr.size] = arr.reshape(-1)
         cursor = off + int(arr.size)
         h, w = arr.shape[:2]
         out.append((off, w, h, 1 if arr.ndim == 2 else arr.shape[2]))
     return out
+
+
+def _decoded_bytes(image) -> int:
+    """Bytes image_to_array will produce for an opened (not yet decoded) Pillow image: L / RGB / RGBA / RGBX keep their bands,
+    every other mode goes through convert("L")."""
+    w, h = image.size
+    return w * h * (len(image.mode) if image.mode in ("RGB", "RGBA", "RGBX") else 1)
+
+
+def _probe_decoded_bytes(paths: Sequence[str]) -> int:
+    """Largest decoded size among a few files, from their headers alone (0 when none opens)."""
+    from PIL import Image
+
+    largest = 0
+    for p in paths:
+        try:
+            with Image.open(p) as im:
+                largest = max(largest, _decoded_bytes(im))
+        except Exception:
+            pass
+    return largest
 
 
 _pools: dict = {}
@@ -467,42 +493,67 @@ class _Pipeline:
         """The Pillow share on decoder PROCESSES: every round hands each worker a job of a few files and a region of the
         shared staging buffer to write them into; the buffer of round k is copied and hashed while round k+1 decodes."""
         pool = _process_pool(self.workers)
+        # Camera-sized files of formats outside the GPU decoders (WebP, TIFF, BMP ...): the staging buffers are sized so that
+        # every worker can hold two images of the size the first files announce in their headers (up to 2 GB per buffer); with
+        # the default 256 MB a 12-megapixel batch kept three of fifteen decoders busy.
+        if self.bytes_per_image == 1 << 20 and todo:
+            seen = _probe_decoded_bytes([self.paths[k] for k in todo[:16]])
+            if seen:
+                self.bytes_per_image = seen
+                want = min(2 << 30, 2 * seen * self.workers)
+                if want > self.stage.stage_bytes and "KE_STAGE_BYTES" not in os.environ:
+                    try:
+                        self.stage.wait(-1)
+                        self.stage = _make_stage(self.device, want, max(self.chunk, 4096))
+                    except Exception:
+                        pass
+        if not getattr(self.stage, "shared_paths", None):
+            return self._decode_with_threads(todo, out)
         shared_paths = self.stage.shared_paths
+        queue = list(todo)
         previous, pending, at = None, [], 0
-        spilled: list = []                                        # larger than their worker's region: the thread route takes them
+        oversize: list = []                                       # larger than a whole staging buffer: hashed on their own
         try:
-            while at < len(todo) and not self.cancelled():
+            while at < len(queue) and not self.cancelled():
                 slot, _ = self.stage.acquire()
-                # a worker's region holds at least two images of the size seen so far: camera-sized files mean fewer workers
-                # per round with a larger share of the buffer each, not files that are decoded, dropped and decoded again
-                active = int(max(1, min(self.workers, self.stage.stage_bytes // max(2 * self.bytes_per_image, 1))))
+                # a worker's region holds two images of the size seen so far (one, when the buffer has no room for that):
+                # camera-sized files mean fewer workers per round with a larger share of the buffer each
+                per_image = max(self.bytes_per_image, 1)
+                active = int(max(1, min(self.workers, self.stage.stage_bytes // (2 * per_image))))
+                if active < self.workers:
+                    active = int(max(active, min(self.workers, self.stage.stage_bytes // (per_image + 4096))))
                 region = (self.stage.stage_bytes // active) & ~4095
-                per_job = int(min(64, max(1, region // (2 * max(self.bytes_per_image, 1)))))
+                per_job = int(min(64, max(1, region // (2 * per_image))))
                 pending = []
                 for r in range(active):
-                    part = todo[at:at + per_job]
+                    part = queue[at:at + per_job]
                     if not part:
                         break
                     at += len(part)
-                    job = (shared_paths[slot], r * region, region, [str(self.tasks[k][1]) for k in part])
+                    job = (shared_paths[slot], r * region, region, [self.paths[k] for k in part])
                     pending.append((part, pool.submit(_decode_into_shared, job)))
                 if previous is not None:
                     self._collect(previous[1], previous[0], previous[2], out)
                     previous = None
-                positions, placed, nbytes = [], [], 0
+                positions, placed, nbytes, again = [], [], 0, []
                 for part, fut in pending:
                     for k, res in zip(part, fut.result()):
-                        if res == "spill":
-                            spilled.append(k)
-                        elif res is not None:
-                            placed.append((len(positions), res))
-                            positions.append(k)
-                            nbytes += res[1] * res[2] * res[3]
+                        if res is None:
+                            continue
+                        if res[0] == "spill":                     # not decoded: its header says how much room it needs
+                            if res[1] + 4096 > self.stage.stage_bytes:
+                                oversize.append(k)
+                            else:
+                                again.append(k)
+                                self.bytes_per_image = max(self.bytes_per_image, int(res[1]))
+                            continue
+                        placed.append((len(positions), res))
+                        positions.append(k)
+                        nbytes += res[1] * res[2] * res[3]
                 pending = []
-                if placed:
+                if placed and not again:
                     self.bytes_per_image = max(1, nbytes // len(placed))
-                elif spilled:
-                    self.bytes_per_image = min(self.stage.stage_bytes, self.bytes_per_image * 2)     # nothing fitted: larger regions next round
+                queue[at:at] = again                              # next round, with regions that hold them
                 handle = None
                 if placed:
                     handle = self.stage.submit(slot, [d[0] for _, d in placed], [d[1] for _, d in placed],
@@ -517,8 +568,8 @@ class _Pipeline:
                     fut.result()
                 except Exception:
                     pass
-        if spilled:
-            self._decode_with_threads(sorted(spilled), out)
+        if oversize:
+            self._decode_with_threads(sorted(oversize), out)
 
     def _decode_with_pillow(self, todo: Sequence[int], out: dict) -> None:
         if self.workers > 1 and len(todo) >= self.process_min and getattr(self.stage, "shared_paths", None):

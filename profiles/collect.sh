@@ -34,6 +34,12 @@ if [ "${2:-}" = "more" ]; then
     run python3 "$root/benchmarks/bench_scanner.py" > "$out/${tag}_scanner.jsonl" 2> "$out/${tag}_scanner.err"
     run python3 "$root/benchmarks/bench_scanner.py" --funnel --sizes 1000000 >> "$out/${tag}_scanner.jsonl" 2>> "$out/${tag}_scanner.err"
     run python3 "$root/benchmarks/decode_phases.py" 4096,16384,32768,65536 > "$out/${tag}_decode_phases.jsonl" 2> "$out/${tag}_decode_phases.err"
+    # the Pillow route (formats outside the GPU decoders; decoder processes into shared page-locked buffers), small and camera-sized images
+    : > "$out/${tag}_fastsig_pillow_route.jsonl"
+    for spec in "webp 512 128 8192" "webp 2048 32 1024" "tiff 1024 64 2048" "bmp 3500 16 256"; do
+        set -- $spec
+        run python3 "$root/benchmarks/bench_fastsig.py" --format "$1" --side "$2" --distinct "$3" --images "$4" --pillow-sample "$4" >> "$out/${tag}_fastsig_pillow_route.jsonl" 2>> "$out/${tag}_decode_phases.err"
+    done
     ls "$out" | grep "^${tag}_" | head -60
     exit 0
 fi

@@ -545,7 +545,7 @@ class Context:
     def png_hash(self, blobs, *, want_dhash=True):
         return self.jpeg_hash(blobs, want_dhash=want_dhash, kind="png")
 
-    def _jpeg_to_device(self, blobs, kind: str = "jpeg", *, paths=None, ahead=None):
+    def _jpeg_to_device(self, blobs, kind: str = "jpeg", *, paths=None, ahead=None, skip=None):
         """Decode what the GPU decoder takes into the context's decode buffer (device memory, grown on demand and kept:
         allocating tens of GB per call costs up to a second): (device ptr or 0, byte offsets, widths, heights, channels,
         status).  Call with the lock held and keep it until the pixels have been used."""
@@ -554,7 +554,7 @@ class Context:
         with self._lock:
             if ahead is not None:                        # files lo..hi of a batch some thread has read already
                 held, lo, hi = ahead
-                flat, offsets, sizes = held.flat, np.ascontiguousarray(held.offsets[lo:hi]), np.ascontiguousarray(held.sizes[lo:hi])
+                flat, offsets, sizes = held.flat, np.ascontiguousarray(held.offsets[lo:hi]), np.array(held.sizes[lo:hi], np.uint64)
             else:
                 flat, offsets, sizes = self._pack_blobs_pinned(blobs) if paths is None else self._read_files_pinned(paths)
             known = ahead[0].probed.get((kind, ahead[1], ahead[2])) if ahead is not None else None
@@ -565,6 +565,10 @@ class Context:
                 if rc != KE_OK:
                     raise ValueError(f"ke_{kind}_probe: bad arguments")
             _leave_bombs_to_pillow(w, h, st, sizes)
+            if skip is not None:                         # files the caller keeps for another decoder: as if refused
+                skip = np.asarray(skip, bool)
+                st[skip & (st == 0)] = 1
+                sizes[skip] = 0
             nbytes = np.where(st == 0, w.astype(np.int64) * h * c, 0)
             padded = (nbytes + 15) & ~np.int64(15)
             out_off = np.zeros(n, np.uint64)
@@ -714,7 +718,7 @@ class Context:
         """jpeg_hash for files on disk: read (host threads, page-locked buffer), decoded and hashed on the GPU."""
         return self.jpeg_hash(None, want_dhash=want_dhash, kind=kind, paths=list(paths))
 
-    def jpeg_hash(self, blobs, *, want_dhash=True, kind: str = "jpeg", paths=None, ahead=None):
+    def jpeg_hash(self, blobs, *, want_dhash=True, kind: str = "jpeg", paths=None, ahead=None, skip=None):
         """pHash / dHash of JPEG files, decoded and hashed without the pixels leaving the GPU.  Returns (phash u64[n],
         dhash u64[n] | None, status int32[n]); status != 0 = not handled here (decode the file with Pillow).  The files come
         as bytes (``blobs``), as ``paths`` the library reads, or as ``ahead = (FilesAhead, lo, hi)``: files lo..hi of a batch
@@ -726,12 +730,13 @@ class Context:
             return ph, dh, np.zeros(0, np.int32)
         with self._lock:
             try:
-                dev, out_off, w, h, c, st = self._jpeg_to_device(blobs, kind, paths=paths, ahead=ahead)
+                dev, out_off, w, h, c, st = self._jpeg_to_device(blobs, kind, paths=paths, ahead=ahead, skip=skip)
             except _BatchTooLarge:
                 half = n // 2
                 parts = [self.jpeg_hash(None if blobs is None else blobs[lo:hi], want_dhash=want_dhash, kind=kind,
                                         paths=None if paths is None else paths[lo:hi],
-                                        ahead=None if ahead is None else (ahead[0], ahead[1] + lo, ahead[1] + hi))
+                                        ahead=None if ahead is None else (ahead[0], ahead[1] + lo, ahead[1] + hi),
+                                        skip=None if skip is None else np.asarray(skip, bool)[lo:hi])
                          for lo, hi in ((0, half), (half, n))]
                 return (np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts]) if want_dhash else None,
                         np.concatenate([p[2] for p in parts]))

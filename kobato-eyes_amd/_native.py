@@ -928,16 +928,19 @@ class Context:
         return out
 
 
-_default: dict[int, Context] = {}
+_default: dict = {}
 _default_lock = threading.Lock()
 
 
-def get_context(device: int = 0) -> Context:
-    """Process-wide context per device (created on first use)."""
+def get_context(device: int = 0, role: str = "") -> Context:
+    """Process-wide context per device (created on first use).  ``role``: a second context of the same device with its own
+    stream, lock and scratch (the batch hasher keeps its pinned staging route on one, so that decoder processes are served
+    while a long GPU decode call holds the main context)."""
+    key = device if not role else (device, role)
     with _default_lock:
-        ctx = _default.get(device)
+        ctx = _default.get(key)
         if ctx is None:
-            ctx = _default[device] = Context(device)
+            ctx = _default[key] = Context(device)
         return ctx
 
 

@@ -268,39 +268,42 @@ class _GpuStage:
 
     def __init__(self, device: int, stage_bytes: int, max_images: int) -> None:
         self.device = device
-        self.ctx = _native.get_context(device)
+        self.ctx = _native.get_context(device)                  # GPU decode calls, read-ahead buffers
+        # the staging route lives on a context of its own (own stream, lock, scratch): the decoder processes' buffers are
+        # copied and hashed while a GPU decode call -- seconds for large PNG streams -- holds the main one
+        self.sctx = _native.get_context(device, "staging")
         stage_bytes = (int(stage_bytes) + 4095) & ~4095
         shared = os.environ.get("KE_DECODE_PROCESSES", "1") != "0" and os.path.isdir("/dev/shm")
         geom = (stage_bytes, max_images, shared)
-        if getattr(self.ctx, "_stage_geom", None) != geom:
-            old = getattr(self.ctx, "_stage_shared", None)     # stays mapped until the library has let go of it
+        if getattr(self.sctx, "_stage_geom", None) != geom:
+            old = getattr(self.sctx, "_stage_shared", None)    # stays mapped until the library has let go of it
             buffers = None
             if shared:
                 try:
                     buffers = _SharedBuffers(stage_bytes)
-                    self.ctx.stage_create_shared(buffers.addresses, stage_bytes, max_images)
+                    self.sctx.stage_create_shared(buffers.addresses, stage_bytes, max_images)
                 except (OSError, RuntimeError, ValueError):
                     if buffers is not None:
                         buffers.close()
                     buffers, shared = None, False
             if not shared:
-                self.ctx.stage_create(stage_bytes, max_images, 2)
-            self.ctx._stage_shared = buffers
-            self.ctx._stage_geom = (stage_bytes, max_images, shared)
+                self.sctx.stage_create(stage_bytes, max_images, 2)
+            self.sctx._stage_shared = buffers
+            self.sctx._stage_geom = (stage_bytes, max_images, shared)
             if old is not None:
                 old.close()
-        buffers = getattr(self.ctx, "_stage_shared", None)
+        buffers = getattr(self.sctx, "_stage_shared", None)
         self.shared_paths = buffers.paths if buffers is not None else None     # slot k <-> shared_paths[k]
         self.stage_bytes = stage_bytes
 
     def acquire(self):
-        return self.ctx.stage_acquire()
+        return self.sctx.stage_acquire()
 
     def submit(self, slot, offsets, widths, heights, channels):
-        return self.ctx.stage_submit_hash(slot, offsets, widths, heights, channels, want_dhash=True)
+        return self.sctx.stage_submit_hash(slot, offsets, widths, heights, channels, want_dhash=True)
 
     def wait(self, slot: int) -> None:
-        self.ctx.stage_wait(slot)
+        self.sctx.stage_wait(slot)
 
     def jpeg_hash(self, blobs, kind: str = "jpeg"):
         """(phash, dhash, status) of JPEG / PNG files decoded on the GPU (``ke_jpeg_decode`` / ``ke_png_decode`` ->
@@ -426,8 +429,8 @@ class _Pipeline:
         stream whatever its size -- about 0.45 us per symbol, i.e. 0.9 us per compressed byte of a textured image -- while a
         decoder process gets through about 250 MB of decoded pixels per second.  2 048 textured 2048 x 2048 files: 5.1 s on
         the GPU, 6.2 s on 16 host threads; 512 of them: 5.7 s against 1.5 s.  With the sizes known (the files are in memory,
-        their headers parsed) the k largest files go to the processes, k minimising (longest stream left for the GPU) +
-        (decoded bytes moved to the processes) in those terms.  KE_PNG_GPU_US_PER_BYTE / KE_PILLOW_MB_PER_S set the two rates;
+        their headers parsed) the k largest files go to the processes, k minimising the larger of (longest stream left for the
+        GPU) and (decoded bytes moved to the processes) in those terms -- the two shares are worked off side by side.  KE_PNG_GPU_US_PER_BYTE / KE_PILLOW_MB_PER_S set the two rates;
         KE_PNG_GPU_US_PER_BYTE=0 sends every PNG file to the GPU, as before."""
         gpu_rate = float(os.environ.get("KE_PNG_GPU_US_PER_BYTE", "0.9")) * 1e-6
         if gpu_rate <= 0.0:
@@ -445,16 +448,17 @@ class _Pipeline:
         order = np.argsort(-np.where(st == 0, sizes, 0.0), kind="stable")
         longest_left = np.concatenate([np.where(st == 0, sizes, 0.0)[order] * gpu_rate + 4e-3, [0.0]])   # + the launches' fixed cost
         moved = np.concatenate([[0.0], np.cumsum(decoded[order]) * cpu_rate])
-        k = int(np.argmin(longest_left + moved))
+        k = int(np.argmin(np.maximum(longest_left, moved)))     # the two shares run side by side (run_batches)
         if k == 0:
             return None
         mask = np.zeros(n, bool)
         mask[order[:k]] = True
         return mask
 
-    def _decode_on_gpu(self, reads: dict, start: int, ph: np.ndarray, dh: np.ndarray, ok: np.ndarray) -> list:
+    def _decode_on_gpu(self, reads: dict, start: int, ph: np.ndarray, dh: np.ndarray, ok: np.ndarray, png_skip=None) -> list:
         """Fills ph / dh / ok (indexed by position - start) for the files the GPU decoders take; returns the positions they
-        left to Pillow."""
+        left to Pillow (``png_skip``: PNG files the caller has given to the decoder processes already -- not decoded here, not
+        returned)."""
         by_path = hasattr(self.stage, "hash_files")
         held = reads["ahead"]
         refused: list = []
@@ -475,9 +479,8 @@ class _Pipeline:
                         continue
                 try:
                     if held is not None:                   # this kind's files are lo .. first of the buffer
-                        skip = self._png_for_pillow(held, lo, first) if kind == "png" else None
+                        skip = png_skip if kind == "png" else None
                         if skip is not None and skip.all():
-                            refused.extend(positions.tolist())
                             continue
                         p, d, st = self.stage.hash_ahead(held, lo, first, kind) if skip is None else \
                             self.stage.hash_ahead(held, lo, first, kind, skip=skip)
@@ -493,7 +496,8 @@ class _Pipeline:
                 ph[at] = np.asarray(p, np.uint64).view(np.int64)[good]
                 dh[at] = np.asarray(d, np.uint64).view(np.int64)[good]
                 ok[at] = True
-                refused.extend(positions[~good].tolist())  # outside the GPU decoder: Pillow decodes it, as the reference does
+                left = ~good if (kind != "png" or png_skip is None) else (~good & ~png_skip)
+                refused.extend(positions[left].tolist())   # outside the GPU decoder: Pillow decodes it, as the reference does
         finally:
             if held is not None:
                 held.release()
@@ -669,16 +673,37 @@ class _Pipeline:
                     next_reads = ahead_pool.submit(self._start_reads, stop)
                 ph, dh = np.zeros(stop - start, np.int64), np.zeros(stop - start, np.int64)
                 ok = np.zeros(stop - start, bool)
-                refused = self._decode_on_gpu(reads, start, ph, dh, ok)
                 taken = np.zeros(stop - start, bool)
                 taken[reads["jpeg"] - start] = True
                 taken[reads["png"] - start] = True
-                todo = sorted((start + np.nonzero(~taken)[0]).tolist() + refused)
+                png_skip = None
+                if reads["ahead"] is not None and len(reads["png"]):
+                    png_skip = self._png_for_pillow(reads["ahead"], len(reads["jpeg"]), len(reads["jpeg"]) + len(reads["png"]))
+                todo = (start + np.nonzero(~taken)[0]).tolist() + (reads["png"][png_skip].tolist() if png_skip is not None else [])
+                # the Pillow share (other formats, the PNG files given to the processes) beside the GPU decoders' share: its
+                # staging route has a context of its own, so neither waits for the other's calls
+                out: dict = {}
+                failure: list = []
+                side = None
                 if todo:
-                    out: dict = {}
-                    self._decode_with_pillow(todo, out)
-                    for k, (p, d) in out.items():
-                        ph[k - start], dh[k - start], ok[k - start] = p, d, True
+                    def pillow_share(positions=sorted(todo)):
+                        try:
+                            self._decode_with_pillow(positions, out)
+                        except BaseException as exc:              # re-raised on the pipeline's thread
+                            failure.append(exc)
+                    side = threading.Thread(target=pillow_share, name="ke-pillow-share")
+                    side.start()
+                try:
+                    refused = self._decode_on_gpu(reads, start, ph, dh, ok, png_skip)
+                finally:
+                    if side is not None:
+                        side.join()
+                if failure:
+                    raise failure[0]
+                if refused and not self.stopped:
+                    self._decode_with_pillow(sorted(refused), out)
+                for k, (p, d) in out.items():
+                    ph[k - start], dh[k - start], ok[k - start] = p, d, True
                 if self.stopped:                                  # abandoned half way: the caller returns what earlier batches gave
                     return
                 yield self.fids[start:stop], ph, dh, ok

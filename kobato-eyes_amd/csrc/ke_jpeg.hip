@@ -632,7 +632,17 @@ __device__ __forceinline__ void chroma4(const uint8_t *in0, const uint8_t *in1, 
 }
 
 __device__ __forceinline__ int4 upsample4_fast(const uint8_t *plane, int pw, int cw, int ch, int hfac, int vfac, int x0, int y) {
-    if (hfac == 1) {                                          // vfac is 1 too: the samples themselves, x0 a multiple of 4
+    if (hfac == 1 && vfac == 2) {                             // 4:4:0 (h1v2_fancy_upsample): two dwords, 3:1 between the rows
+        const int r0 = y >> 1;
+        int r1 = (y & 1) ? r0 + 1 : r0 - 1;
+        r1 = r1 < 0 ? 0 : (r1 > ch - 1 ? ch - 1 : r1);
+        const uint32_t a = *reinterpret_cast<const uint32_t *>(plane + (__umul24(r0, pw) + (uint32_t)x0));
+        const uint32_t b = *reinterpret_cast<const uint32_t *>(plane + (__umul24(r1, pw) + (uint32_t)x0));
+        const int bias = (y & 1) ? 2 : 1;
+        return make_int4((int)((a & 255u) * 3u + (b & 255u) + bias) >> 2, (int)(((a >> 8) & 255u) * 3u + ((b >> 8) & 255u) + bias) >> 2,
+                         (int)(((a >> 16) & 255u) * 3u + ((b >> 16) & 255u) + bias) >> 2, (int)((a >> 24) * 3u + (b >> 24) + bias) >> 2);
+    }
+    if (hfac == 1) {                                          // the samples themselves, x0 a multiple of 4
         const uint32_t v = *reinterpret_cast<const uint32_t *>(plane + (__umul24(y, pw) + (uint32_t)x0));
         return make_int4((int)(v & 255u), (int)((v >> 8) & 255u), (int)((v >> 16) & 255u), (int)(v >> 24));
     }

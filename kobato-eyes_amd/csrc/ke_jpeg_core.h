@@ -427,6 +427,12 @@ KE_HD bool ke_idct_islow(Blk &blk, uint8_t *out, int stride) {
 // libjpeg replicates the last real column and row).
 KE_HD int ke_upsample_at(const uint8_t *plane, int pw, int cw, int ch, int hfac, int vfac, int x, int y) {
     if (hfac == 1 && vfac == 1) return plane[(long)y * pw + x];
+    if (hfac == 1) {                                 // h1v2_fancy_upsample (4:4:0, e.g. a 4:2:2 file turned by jpegtran): the nearer
+        const int r0 = y >> 1;                       // row weighs 3, the one above (even rows, bias 1) or below (odd, bias 2) weighs 1
+        int r1 = (y & 1) ? r0 + 1 : r0 - 1;          // -- whatever the component's width (jinit_upsampler asks for no minimum here)
+        r1 = r1 < 0 ? 0 : (r1 > ch - 1 ? ch - 1 : r1);
+        return (plane[(long)r0 * pw + x] * 3 + plane[(long)r1 * pw + x] + ((y & 1) ? 2 : 1)) >> 2;
+    }
     // jinit_upsampler picks the fancy filters only for components more than two samples wide; narrower ones are replicated
     if (cw <= 2) return plane[(long)(y / vfac) * pw + x / hfac];
     if (hfac == 2 && vfac == 1) {                    // h2v1_fancy_upsample
@@ -457,8 +463,12 @@ KE_HD int ke_upsample_at(const uint8_t *plane, int pw, int cw, int ch, int hfac,
 // The same for the four output samples x0 .. x0+3 of row y at once (x0 a multiple of 4): the chroma neighbourhood is read
 // once.  Must equal ke_upsample_at sample by sample (oracle/keyes_jpeg_cpu.cpp checks it).
 KE_HD void ke_upsample4(const uint8_t *plane, int pw, int cw, int ch, int hfac, int vfac, int x0, int y, int *out) {
+    if (hfac == 1 && vfac == 2) {                             // 4:4:0
+        for (int k = 0; k < 4; ++k) out[k] = ke_upsample_at(plane, pw, cw, ch, 1, 2, x0 + k, y);
+        return;
+    }
     if (hfac == 1) {
-        const uint8_t *row = plane + (long)y * pw + x0;      // vfac is 1 too (the parser admits 1x1, 2x1, 2x2)
+        const uint8_t *row = plane + (long)y * pw + x0;
         for (int k = 0; k < 4; ++k) out[k] = row[k];
         return;
     }

@@ -265,10 +265,10 @@ static inline void ke_parse_jpeg(const uint8_t *p, size_t size, KeJpegTables &ta
                 if (info.ncomp == 3) {
                     if (adobe_transform == 0) return give_up(KE_JPEG_UNSUPPORTED);
                     if (adobe_transform < 0 && comp_id[0] == 'R' && comp_id[1] == 'G' && comp_id[2] == 'B') return give_up(KE_JPEG_UNSUPPORTED);
-                    // luma at full resolution, both chroma planes alike, factors 1x1 / 2x1 / 2x2
+                    // luma at full resolution, both chroma planes alike, factors 1x1 / 2x1 / 2x2 / 1x2 (4:4:0)
                     const int h = info.hs[0], v = info.vs[0];
                     if (info.hs[1] != 1 || info.vs[1] != 1 || info.hs[2] != 1 || info.vs[2] != 1) return give_up(KE_JPEG_UNSUPPORTED);
-                    if (!((h == 1 && v == 1) || (h == 2 && v == 1) || (h == 2 && v == 2))) return give_up(KE_JPEG_UNSUPPORTED);
+                    if (!((h == 1 && v == 1) || (h == 2 && v == 1) || (h == 2 && v == 2) || (h == 1 && v == 2))) return give_up(KE_JPEG_UNSUPPORTED);
                 } else {
                     info.hs[0] = info.vs[0] = 1;             // a single component is never subsampled (its factors are ignored)
                 }

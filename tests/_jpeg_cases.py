@@ -59,11 +59,29 @@ def supported(full: bool = False):
                 except TypeError:                      # a Pillow without the restart options
                     continue
                 yield f"restart_{list(kw)[0]}_{list(kw.values())[0]}_s{sub}_p{int(prog)}", data, np.asarray(Image.open(io.BytesIO(data)))
+    # 4:4:0 (what jpegtran makes of a 4:2:2 file it turns): a 4:2:2 file with the luma sampling byte of its frame header set
+    # to 1x2 -- the scan is the same bit stream (two luma blocks, Cb, Cr per MCU), laid out as two block rows instead of two
+    # columns; the picture is scrambled, the arithmetic (block order, h1v2 triangle upsampling) is what is compared
+    # (sizes whose MCU count is the same either way: the stream must neither run dry nor have blocks left over)
+    for (w, h) in ((128, 128), (61, 57), (200, 195), (16, 16), (33, 40), (7, 5), (2, 2)):
+        assert -(-w // 16) * -(-h // 8) == -(-w // 8) * -(-h // 16)
+        for prog in (False, True):
+            b = _image(rng, w, h, 2)
+            data = with_luma_sampling(_save(b, quality=88, subsampling=1, progressive=prog), 0x12)
+            yield f"{w}x{h}_440_p{int(prog)}", data, np.asarray(Image.open(io.BytesIO(data)))
     # a DQT between the scans of a progressive file is legal; libjpeg keeps the table that was in effect at a component's first
     # scan (jdinput.c latch_quant_tables), so the redefinition changes nothing for components already seen
     for sub in (0, 2):
         data = with_dqt_between_scans(_save(a, quality=85, subsampling=sub, progressive=True), 1)
         yield f"progressive_dqt_between_scans_s{sub}", data, np.asarray(Image.open(io.BytesIO(data)))
+
+
+def with_luma_sampling(data: bytes, factors: int) -> bytes:
+    """The file with the sampling byte of its first frame component set to `factors` (0x12 = 1 x 2)."""
+    d = bytearray(data)
+    sof = max(data.find(b"\xff\xc0"), data.find(b"\xff\xc2"))
+    d[sof + 11] = factors
+    return bytes(d)
 
 
 def with_dqt_between_scans(data: bytes, value: int) -> bytes:

@@ -156,7 +156,7 @@ int ke_stage_wait(ke_ctx *ctx, int32_t slot);
 /* ---- JPEG decode on the GPU: `Image.open(path)` + pixel access of the reference's batch hasher (src/core/fastsig.py:31-34;
  * the decode half of north-star step 1) for Huffman-coded JPEGs with 8-bit samples -- sequential files with one interleaved
  * scan and progressive files (spectral selection + successive approximation, any scan script) -- grayscale ("L") or YCbCr at
- * 4:4:4 / 4:2:2 / 4:2:0 ("RGB").  The pixels are libjpeg's as Pillow drives it (islow IDCT, fancy upsampling, jdcolor's
+ * 4:4:4 / 4:2:2 / 4:2:0 / 4:4:0 ("RGB").  The pixels are libjpeg's as Pillow drives it (islow IDCT, fancy upsampling, jdcolor's
  * fixed-point YCbCr -> RGB), bit for bit; everything else (arithmetic coding, 12-bit, CMYK/YCCK, RGB-coded, other samplings,
  * sequential files in several scans, progressive files whose first AC coefficients are not refined to the last bit -- libjpeg
  * smooths those -- and files with a block whose IDCT leaves 16 bits, which no encoder writes and on which libjpeg's C and SIMD

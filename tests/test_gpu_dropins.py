@@ -422,3 +422,28 @@ def test_cli_scan_dups_over_sqlite(K, tmp_path):
     assert got[1:] == want and len(exp) >= 1
     stored = sqlite3.connect(db).execute("SELECT COUNT(*) FROM signatures").fetchone()[0]
     assert stored == len(rows)                                       # every readable present file now has a row
+
+
+def test_fast_fill_can_be_cancelled_half_way_and_called_again(K, tmp_path, monkeypatch):
+    """A cancel callback stops the run between batches / chunks (src/core/fastsig.py:86-90: the partial list comes back, in
+    input order); read-ahead buffers, staging buffers and the Pillow share's thread are given back: the next call works."""
+    items, arrays = _corpus(tmp_path, n=12)
+    more = []
+    for k in range(300):                                             # JPEG, PNG and BMP copies: every route has work
+        src = arrays[1 + k % 12]
+        p = tmp_path / f"more_{k:04d}.{('jpg', 'png', 'bmp')[k % 3]}"
+        Image.fromarray(src).save(p)
+        more.append((1000 + k, str(p)))
+    monkeypatch.setenv("KE_GPU_BATCH_CANCELLABLE", "64")             # several batches
+    full = K.compute_signatures_mp(more, max_workers=3, chunksize=8)
+    assert [r[0] for r in full] == [fid for fid, _ in more]
+    calls = {"n": 0}
+
+    def cancel():
+        calls["n"] += 1
+        return calls["n"] > 150
+
+    part = K.compute_signatures_mp(more, max_workers=3, chunksize=8, cancel_fn=cancel)
+    assert 0 < len(part) < len(full) and part == full[:len(part)]
+    assert K.compute_signatures_mp(more, max_workers=3, chunksize=8, cancel_fn=lambda: True) == []
+    assert K.compute_signatures_mp(more, max_workers=3, chunksize=8) == full          # nothing was left behind

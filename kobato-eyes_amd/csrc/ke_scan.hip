@@ -52,6 +52,7 @@ struct ScanArgs {
     ke_edge *edges;
     int64_t capacity;
     unsigned long long *counters;  // [0] pairs, [1] sum of shared bands, [2] edges
+    int xcd_remap;
 };
 
 __device__ __forceinline__ int popc64(uint32_t lo, uint32_t hi) { return __popc(lo) + __popc(hi); }
@@ -121,7 +122,15 @@ __global__ __launch_bounds__(256) void ke_scan_expand(const uint64_t *__restrict
 __global__ __launch_bounds__(kThreads) void ke_scan_tiles(const ScanArgs a) {
     __shared__ ke_v4i s_b[2][kChunk / 16 * 64];      // two chunks of 16 operand tiles
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int64_t t = a.first_tile + (int64_t)blockIdx.x * a.tile_step;
+    // workgroup b runs on XCD b mod 8 (round-robin dispatch), each XCD has its own L2: XCD x takes the x-th eighth of this
+    // launch's tiles, consecutive tiles (which share their row operands) on one L2 instead of on eight.  KE_SCAN_XCD=0: off.
+    int64_t slot = blockIdx.x;
+    if (a.xcd_remap) {
+        const int64_t per = ((int64_t)gridDim.x + 7) / 8;
+        slot = (int64_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+        if (slot >= (int64_t)gridDim.x) return;
+    }
+    const int64_t t = a.first_tile + slot * a.tile_step;
     if (t >= a.n_tiles) return;
     // Tiles of the upper triangle, row-major: row block rb owns column chunks kCPR*rb .. ncc-1, so
     // offset(rb) = rb*ncc - kCPR*rb*(rb-1)/2.  Invert with a float estimate and an exact fix-up.
@@ -437,7 +446,11 @@ int ke_launch_scan(ke_ctx *ctx, const uint64_t *d_hashes, const int64_t *d_ids, 
         hipLaunchKernelGGL(ke_scan_expand, dim3((unsigned)((n_pad * 4 + 255) / 256)), dim3(256), 0, ctx->stream, d_hashes, n, n_pad,
                            (ke_v4i *)exp);
         if (my_tiles > 0x7fffffffLL) return ke_fail(ctx, KE_EUNSUPPORTED, "too many tiles for one launch");
-        hipLaunchKernelGGL(ke_scan_tiles, dim3((unsigned)my_tiles), dim3(kThreads), 0, ctx->stream, a);
+        static const int xcd = [] { const char *e = std::getenv("KE_SCAN_XCD"); return e ? std::atoi(e) : 0; }();
+        a.xcd_remap = xcd;
+        // with the remap the grid is padded to a multiple of 8 so that every slot exists on some workgroup
+        const int64_t grid = xcd ? (my_tiles + 7) / 8 * 8 : my_tiles;
+        hipLaunchKernelGGL(ke_scan_tiles, dim3((unsigned)grid), dim3(kThreads), 0, ctx->stream, a);
         KE_HIP(ctx, hipGetLastError());
     }
     ke_time_end(ctx, KE_T_SCAN);

@@ -448,6 +448,8 @@ class _Pipeline:
         order = np.argsort(-np.where(st == 0, sizes, 0.0), kind="stable")
         longest_left = np.concatenate([np.where(st == 0, sizes, 0.0)[order] * gpu_rate + 4e-3, [0.0]])   # + the launches' fixed cost
         moved = np.concatenate([[0.0], np.cumsum(decoded[order]) * cpu_rate])
+        if self.workers not in _pools:                          # starting the decoder processes costs about a second and a half, once
+            moved[1:] += float(os.environ.get("KE_DECODE_POOL_START_S", "1.5"))
         k = int(np.argmin(np.maximum(longest_left, moved)))     # the two shares run side by side (run_batches)
         if k == 0:
             return None

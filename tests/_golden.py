@@ -253,3 +253,12 @@ def write_worker_corpus(td):
         if row is not None:
             expected.append(row)
     return tasks, expected
+
+
+def refine_turned_golden():
+    """(json, {name: file bytes}): the reference's shipped refine stage run on files the loader has to normalise first
+    (JPEG files of every EXIF orientation, RGBA and gray + alpha PNG; make_golden.make_refine_turned)."""
+    with open(os.path.join(GOLDEN, "refine_turned_golden.json")) as fh:
+        g = json.load(fh)
+    z = np.load(os.path.join(GOLDEN, "refine_turned_corpus.npz"))
+    return g, {str(n): z[f"f{k}"].tobytes() for k, n in enumerate(z["names"])}

@@ -772,8 +772,94 @@ def make_worker():
     print("  total bytes", sum(len(b) for _, b in corpus))
 
 
+def make_refine_turned():
+    """The shipped refine stage on files the loader has to normalise first (src/ui/dup_refine_parallel.py:59-83, 203-207:
+    Image.open + ImageOps.exif_transpose + convert("L") + BILINEAR resize): JPEG files carrying every EXIF orientation, RGBA and
+    gray + alpha PNG files -- written once, stored as bytes, through the reference's own tile_ahash_bits / _load_small_gray /
+    _mae01 and both refine_by_* functions."""
+    import io
+    import tempfile
+    from dataclasses import dataclass
+
+    import ui.dup_refine_parallel as R
+
+    @dataclass
+    class F:
+        file_id: int
+        path: Path
+
+    @dataclass
+    class E:
+        file: F
+
+    @dataclass
+    class Cl:
+        files: list
+        keeper_id: int
+
+    rng = np.random.default_rng(77)
+    base = O.synth_rgb(2001, 200, 152)
+    near = np.clip(base.astype(np.int16) + rng.integers(-3, 4, base.shape), 0, 255).astype(np.uint8)
+    other = O.synth_rgb(2002, 200, 152)
+    files = []
+
+    def put(name, img, fmt, **kw):
+        b = io.BytesIO()
+        img.save(b, fmt, **kw)
+        files.append((name, b.getvalue()))
+
+    for o in range(1, 9):
+        ex = Image.Exif()
+        ex[0x0112] = o
+        # stored so that the loader's turn brings every one of them back to the same upright picture (o = 1 is upright)
+        src = {1: near, 2: near[:, ::-1], 3: near[::-1, ::-1], 4: near[::-1], 5: near.transpose(1, 0, 2), 6: near.transpose(1, 0, 2)[:, ::-1],
+               7: near[::-1, ::-1].transpose(1, 0, 2), 8: near.transpose(1, 0, 2)[::-1]}[o]
+        put(f"turned{o}.jpg", Image.fromarray(np.ascontiguousarray(src)), "JPEG", quality=93, exif=ex.tobytes(), progressive=bool(o % 2))
+    put("upright.jpg", Image.fromarray(base), "JPEG", quality=93)
+    put("other.jpg", Image.fromarray(other), "JPEG", quality=90)
+    alpha = rng.integers(0, 256, base.shape[:2], dtype=np.uint8)
+    put("rgba.png", Image.fromarray(np.dstack([near, alpha]), "RGBA"), "PNG")
+    put("la.png", Image.fromarray(np.dstack([np.asarray(Image.fromarray(near).convert("L")), alpha]), "LA"), "PNG")
+    out = {"names": [n for n, _ in files], "cases": {}, "clusters": []}
+    store = {"names": np.array(out["names"])}
+    for k, (_, data) in enumerate(files):
+        store[f"f{k}"] = np.frombuffer(data, np.uint8)
+    with tempfile.TemporaryDirectory() as td:
+        paths = {}
+        for name, data in files:
+            paths[name] = Path(td) / name
+            paths[name].write_bytes(data)
+        thumbs = {}
+        for name, p in paths.items():
+            thumbs[name] = R._load_small_gray(p, 128)
+            out["cases"][name] = {"ahash": {f"{g}x{t}": format(R.tile_ahash_bits(p, grid=g, tile=t), "x") for g, t in ((4, 8), (8, 4))},
+                                  "thumb128_sha256": sha(thumbs[name]), "thumb32_sha256": sha(R._load_small_gray(p, 32))}
+        out["mae"] = [[a, b, R._mae01(thumbs[a], thumbs[b])] for a, b in
+                      [("upright.jpg", "turned1.jpg"), ("upright.jpg", "turned6.jpg"), ("turned3.jpg", "turned8.jpg"), ("upright.jpg", "rgba.png"),
+                       ("rgba.png", "la.png"), ("upright.jpg", "other.jpg")]]
+        ids = {n: k + 1 for k, n in enumerate(paths)}
+        groups = [(["upright.jpg"] + [f"turned{o}.jpg" for o in range(1, 9)], "upright.jpg"), (["rgba.png", "la.png", "other.jpg"], "rgba.png"),
+                  (["turned5.jpg", "other.jpg", "turned2.jpg"], "turned5.jpg")]
+        clusters = [Cl([E(F(ids[n], paths[n])) for n in members], ids[keeper]) for members, keeper in groups]
+        out["cluster_inputs"] = [{"members": m, "keeper": k} for m, k in groups]
+        for max_bits in (4, 400, 1024):
+            res = R.refine_by_tilehash_parallel(clusters, grid=4, tile=8, max_bits=max_bits, io_workers=2)
+            out["clusters"].append({"stage": "tilehash", "max_bits": max_bits, "result": [[cl.keeper_id, [e.file.file_id for e in cl.files]] for cl in res]})
+        for thr in (0.004, 0.02, 0.2):
+            res = R.refine_by_pixels_parallel(clusters, mae_thr=thr, thumb_size=128, workers=1)
+            out["clusters"].append({"stage": "pixels", "mae_thr": thr, "result": sorted([cl.keeper_id, [e.file.file_id for e in cl.files]] for cl in res)})
+        out["ids"] = ids
+    np.savez_compressed(os.path.join(HERE, "refine_turned_corpus.npz"), **store)
+    with open(os.path.join(HERE, "refine_turned_golden.json"), "w") as fh:
+        json.dump(out, fh, indent=1)
+    print("refine_turned:", len(files), "files;", [(c["stage"], len(c["result"])) for c in out["clusters"]], "mae", [round(m[2], 5) for m in out["mae"]])
+
+
 if __name__ == "__main__":
     logging.basicConfig(level=logging.WARNING)
+    if "--only-refine-turned" in sys.argv:
+        make_refine_turned()
+        raise SystemExit(0)
     if "--only-seams" in sys.argv:
         make_config0()
         make_worker()
@@ -802,3 +888,4 @@ if __name__ == "__main__":
     make_config0()
     make_worker()
     make_scan100k()
+    make_refine_turned()

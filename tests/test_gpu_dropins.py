@@ -447,3 +447,66 @@ def test_fast_fill_can_be_cancelled_half_way_and_called_again(K, tmp_path, monke
     assert 0 < len(part) < len(full) and part == full[:len(part)]
     assert K.compute_signatures_mp(more, max_workers=3, chunksize=8, cancel_fn=lambda: True) == []
     assert K.compute_signatures_mp(more, max_workers=3, chunksize=8) == full          # nothing was left behind
+
+
+def test_shipped_refine_stage_on_turned_and_transparent_files_equals_the_reference(K, tmp_path):
+    """JPEG files of every EXIF orientation, RGBA and gray + alpha PNG through tile_ahash_bits / _load_small_gray / _mae01 /
+    refine_by_tilehash_parallel / refine_by_pixels_parallel == what the reference's own ui.dup_refine_parallel returned for
+    the same bytes (tests/golden/refine_turned_golden.json) -- by the GPU decoders with the turn applied on the device
+    (ke_normalise_rgb), and with KE_GPU_REFINE_DECODE=0 (Pillow)."""
+    import hashlib
+    from dataclasses import dataclass
+
+    import _golden as G
+    from kobato_eyes_amd import refine_parallel as RP
+
+    g, blobs = G.refine_turned_golden()
+    paths = {}
+    for name, data in blobs.items():
+        paths[name] = tmp_path / name
+        paths[name].write_bytes(data)
+
+    @dataclass
+    class F:
+        file_id: int
+        path: object
+
+    @dataclass
+    class E:
+        file: F
+
+    @dataclass
+    class Cl:
+        files: list
+        keeper_id: int
+
+    ids = g["ids"]
+    clusters = [Cl([E(F(ids[n], paths[n])) for n in c["members"]], ids[c["keeper"]]) for c in g["cluster_inputs"]]
+    for route in ("gpu", "pillow"):
+        if route == "pillow":
+            os.environ["KE_GPU_REFINE_DECODE"] = "0"
+        try:
+            if route == "gpu":
+                on_gpu = RP._thumbnails_decoded_on_gpu(list(paths.values()), 128, 0)
+                assert set(on_gpu) == set(paths.values())                      # every one of these files stays on the GPU route
+                for name, p in paths.items():
+                    assert hashlib.sha256(on_gpu[p].tobytes()).hexdigest() == g["cases"][name]["thumb128_sha256"], name
+                on_gpu32 = RP._thumbnails_decoded_on_gpu(list(paths.values()), 32, 0)
+                for name, p in paths.items():
+                    assert hashlib.sha256(on_gpu32[p].tobytes()).hexdigest() == g["cases"][name]["thumb32_sha256"], name
+            for name, p in paths.items():
+                for key, hexbits in g["cases"][name]["ahash"].items():
+                    grid, tile = (int(v) for v in key.split("x"))
+                    assert format(K.tile_ahash_bits(p, grid=grid, tile=tile), "x") == hexbits, (route, name, key)
+                assert hashlib.sha256(RP._load_small_gray(p, 128).tobytes()).hexdigest() == g["cases"][name]["thumb128_sha256"], (route, name)
+            for a, b, mae in g["mae"]:
+                assert RP._mae01(RP._load_small_gray(paths[a], 128), RP._load_small_gray(paths[b], 128)) == mae
+            for c in g["clusters"]:
+                if c["stage"] == "tilehash":
+                    res = K.refine_by_tilehash_parallel(clusters, grid=4, tile=8, max_bits=c["max_bits"], io_workers=2)
+                    assert [[cl.keeper_id, [e.file.file_id for e in cl.files]] for cl in res] == c["result"], (route, c["max_bits"])
+                else:
+                    res = K.refine_by_pixels_parallel(clusters, mae_thr=c["mae_thr"], thumb_size=128, workers=1)
+                    assert sorted([cl.keeper_id, [e.file.file_id for e in cl.files]] for cl in res) == c["result"], (route, c["mae_thr"])
+        finally:
+            os.environ.pop("KE_GPU_REFINE_DECODE", None)

@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--distinct", type=int, default=4096,
                     help="distinct images encoded (the batch cycles through them; few copies of each, so that the lanes of a wave hold different images)")
     ap.add_argument("--progressive", action="store_true", help="JPEG: progressive files (libjpeg's default scan script)")
+    ap.add_argument("--interlaced", action="store_true", help="PNG: Adam7 files (Pillow has no writer for them: built here, Sub filter on every row)")
     ap.add_argument("--content", choices=["corpus", "drawing"], default="corpus",
                     help="corpus: the synthetic corpus images (textured, photograph-like: PNG stays near half its raw size); "
                          "drawing: flat 16-px cells, a few ramps and thin outlines (illustration-like: PNG shrinks 20-50x)")
@@ -49,8 +50,30 @@ def main():
         px[:, s // 3: s // 2, :, 1] = ramp[None, None, :]                 # a band with a horizontal ramp in one channel
         px[:, ::48, :, :] = 0                                             # outlines
         px[:, :, ::64, :] = 0
+    def adam7(a):
+        import struct
+        import zlib
+
+        raw = bytearray()
+        for (x0, y0, dx, dy) in ((0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)):
+            sub = a[y0::dy, x0::dx]
+            if sub.shape[0] == 0 or sub.shape[1] == 0:
+                continue
+            rows = sub.reshape(sub.shape[0], -1).astype(np.int16)
+            f = rows.copy()
+            f[:, 3:] -= rows[:, :-3]
+            raw += np.concatenate([np.ones((rows.shape[0], 1), np.uint8), (f & 255).astype(np.uint8)], 1).tobytes()
+
+        def ch(t, d):
+            return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d))
+
+        h, w = a.shape[:2]
+        return b"\x89PNG\r\n\x1a\n" + ch(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 1)) + ch(b"IDAT", zlib.compress(bytes(raw), 6)) + ch(b"IEND", b"")
+
     def encode(k):
         b = io.BytesIO()
+        if args.format == "png" and args.interlaced:
+            return adam7(px[k])
         if args.format == "png":
             Image.fromarray(px[k]).save(b, "PNG")
         else:
@@ -87,7 +110,7 @@ def main():
         list(ex.map(dec, sample, chunksize=8))
     t_cpu = time.perf_counter() - t0
     wall, kern = float(np.median(t_wall)), float(np.median(t_kern))
-    print(json.dumps({"case": args.format + ("_progressive" if args.progressive else "") + "_decode", "content": args.content, "distinct": distinct, "images": args.images, "side": args.side, "quality": args.quality,
+    print(json.dumps({"case": args.format + ("_progressive" if args.progressive else "") + ("_adam7" if args.interlaced else "") + "_decode", "content": args.content, "distinct": distinct, "images": args.images, "side": args.side, "quality": args.quality,
                       "subsampling": ["4:4:4", "4:2:2", "4:2:0"][args.subsampling], "compressed_mb": comp_bytes / 1e6,
                       "decode_kernels_ms": kern, "decode_images_per_s": args.images / (kern * 1e-3),
                       "decode_plus_hash_wall_ms": wall * 1e3, "decode_plus_hash_images_per_s": args.images / wall,

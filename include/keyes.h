@@ -177,14 +177,15 @@ int ke_jpeg_probe(const uint8_t *files, const uint64_t *offsets, const uint64_t 
 int ke_jpeg_decode(ke_ctx *ctx, const uint8_t *files, const uint64_t *offsets, const uint64_t *sizes, int64_t n,
                    uint8_t *pixels_out, const uint64_t *out_offsets, int32_t *status_out);
 
-/* ---- PNG decode on the GPU: the same step for PNG files without interlacing: 8-bit grayscale ("L"), RGB and RGBA pixels as
+/* ---- PNG decode on the GPU: the same step for PNG files, Adam7-interlaced or not: 8-bit grayscale ("L"), RGB and RGBA pixels as
  * they are; palette files (1 / 2 / 4 / 8 bits) and grayscale of 1 / 2 / 4 bits as the luma `convert("L")` makes of them --
  * what the reference's hashes see for such a file (src/sig/phash.py:25) -- with channels = 1.  Lossless, hence the pixels of
  * Image.open by construction (zlib/deflate, the five scanline filters).  One thread per image walks the deflate stream
  * (literals to their place, LZ77 copies recorded), one wave per image then makes the copies and one wave per image undoes the
  * filters and checks the stream's Adler-32; throughput comes from the batch.  Chunk CRCs are verified where Pillow verifies
- * them (every chunk but IDAT).  16-bit, interlaced and animated files (8-bit gray + alpha files are taken: they decode to their gray samples, what
- * convert("L") makes of mode "LA") and rows wider than 16384 pixels:
+ * them (every chunk but IDAT).  An interlaced file is seven reduced images one after another in the stream: the same kernels,
+ * the unfilter pass run once per reduced image and its pixels scattered to their places.  8-bit gray + alpha files decode to
+ * their gray samples, what convert("L") makes of mode "LA".  16-bit and animated files and rows wider than 16384 pixels:
  * KE_JPEG_UNSUPPORTED_ (1) per file, damaged ones KE_JPEG_CORRUPT_ (2).  Arguments and conventions as ke_jpeg_probe /
  * ke_jpeg_decode; channels is 1, 3 or 4. */
 int ke_png_probe(const uint8_t *files, const uint64_t *offsets, const uint64_t *sizes, int64_t n, int32_t *widths,

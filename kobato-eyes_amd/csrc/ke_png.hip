@@ -1,4 +1,4 @@
-// ke_png.hip -- PNG decoding on the GPU (8-bit grayscale / RGB / RGBA, no interlacing): the other half of the decode step in
+// ke_png.hip -- PNG decoding on the GPU (8-bit grayscale / RGB / RGBA / gray + alpha, palette and sub-byte files; Adam7 too): the other half of the decode step in
 // front of the hash path.  Replaces `Image.open(path)` + pixel access of the reference's batch hasher
 // (src/core/fastsig.py:31-34) for the files it takes; the format is lossless, so the pixels are Pillow's by construction of
 // the two specifications followed in ke_png_core.h (zlib/deflate, the five scanline filters).
@@ -13,7 +13,8 @@
 //   ke_png_unfilter  ONE WAVE PER IMAGE: a pixel needs its left, upper and upper-left neighbours, so lane l takes rows
 //                    l, l + 64, ... and runs one group of four pixels behind lane l - 1; the row above arrives by a lane shift
 //                    (lane 63 -> lane 0 through an LDS row).  The same pass sums the Adler-32 of the filtered bytes by rows
-//                    and holds it against the stream's trailer.
+//                    and holds it against the stream's trailer.  An Adam7 file is seven such images one after another in
+//                    the stream (ke_adam7_pass); the same loop runs once per pass and scatters the pixels (ADAM7 instances).
 #include <algorithm>
 
 #include "ke_internal.h"
@@ -213,7 +214,7 @@ __global__ __launch_bounds__(64) void ke_png_inflate(const KePngDev *__restrict_
     tab.dsym_ = s_dsym + threadIdx.x;
     tab.nib_ = reinterpret_cast<uint32_t *>(work + (size_t)i * kWorkBytes);
     tab.lim0 = tab.lim1 = tab.base0 = tab.base1 = Oct{0, 0, 0, 0, 0, 0, 0, 0};
-    const uint32_t want = (uint32_t)(d.info.row_bytes + 1) * (uint32_t)d.info.height;
+    const uint32_t want = d.info.raw_len;
     uint32_t trailer = 0;
     int rc = ke_inflate_zlib(bits, sink, d.info.zlen, want, tab, &trailer);
     if (rc == KE_PNG_OK && sink.n != want) rc = KE_PNG_CORRUPT;
@@ -361,7 +362,7 @@ __device__ __forceinline__ uint32_t recon_pixel(int m1, int m2, int m3, int m4, 
 // MAPPED: palette files and grayscale below 8 bits.  The filters work on the packed bytes (one byte is the filter unit);
 // every byte then unpacks to 8 / depth samples, most significant bits first, and each sample goes out as the luma in the
 // image's table.
-template <int BPP, bool MAPPED>
+template <int BPP, bool MAPPED, bool ADAM7>
 __global__ __launch_bounds__(64) void ke_png_unfilter(const KePngDev *__restrict__ imgs, const uint8_t *__restrict__ raw,
                                                       uint8_t *__restrict__ out, int32_t *__restrict__ status,
                                                       const uint32_t *__restrict__ adler) {
@@ -369,173 +370,205 @@ __global__ __launch_bounds__(64) void ke_png_unfilter(const KePngDev *__restrict
     __shared__ uint8_t s_lut[MAPPED ? 256 : 4];
     const int64_t i = blockIdx.x;
     const KePngDev &d = imgs[i];
-    if (d.info.fbpp != BPP || (d.info.mapped != 0) != MAPPED || status[i] != KE_PNG_OK) return;
+    if (d.info.fbpp != BPP || (d.info.mapped != 0) != MAPPED || (d.info.interlace != 0) != ADAM7 || status[i] != KE_PNG_OK) return;
     const int lane = threadIdx.x;
     if (MAPPED) {
         for (int k = lane; k < 256; k += 64) s_lut[k] = d.info.lut[k];
         __syncthreads();
     }
-    const int W = d.info.row_bytes / BPP, H = d.info.height;      // filter units per row (pixels, or packed bytes)
-    const uint32_t rb = (uint32_t)W * BPP, stride = rb + 1;
-    const int groups = (W + 3) >> 2;                  // four pixels at a time
-    const int period = groups > 64 ? groups : 64;     // lane 0 starts its next row only after lane 63 has started the one above
-    const int rounds = (H + 63) >> 6;
     const uint8_t *src = raw + d.raw_off;
     uint8_t *dst = out + d.out_off;
-    const uint64_t total = (uint64_t)stride * (uint64_t)H;
+    const uint64_t total = d.info.raw_len;
     constexpr int kWords = BPP == 1 ? 1 : BPP;        // dwords of four pixels
+    uint32_t bad = 0, s1 = 0, s2 = 0;                 // Adler totals mod 65521
+    uint64_t pass_off = 0;                            // where this pass's rows start in the stream
+    for (int pass = 0; pass < (ADAM7 ? 7 : 1); ++pass) {
+        KeAdam7 geo{0, 0, 1, 1, d.info.width, d.info.height};
+        int W = d.info.row_bytes / BPP;                   // filter units per row (pixels, or packed bytes)
+        if (ADAM7) {
+            geo = ke_adam7_pass(pass, d.info.width, d.info.height);
+            if (geo.w == 0 || geo.h == 0) continue;
+            W = ((geo.w * BPP * (MAPPED ? d.info.depth : 8) + 7) >> 3) / BPP;
+        }
+        const int H = geo.h;
+        const uint32_t rb = (uint32_t)W * BPP, stride = rb + 1;
+        const int groups = (W + 3) >> 2;                  // four pixels at a time
+        const int period = groups > 64 ? groups : 64;     // lane 0 starts its next row only after lane 63 has started the one above
+        const int rounds = (H + 63) >> 6;
 
-    int row = lane, g = -lane;                        // this step's group; g < 0: not started
-    uint32_t ft = 0, bad = 0;
-    uint32_t o[4] = {0, 0, 0, 0};                     // the four pixels of the previous step (what lane + 1 sees above)
-    uint32_t up3 = 0;                                 // upper-left of the next group: the last pixel above of this one
-    uint32_t a1 = 0, c32 = 0, s1 = 0, s2 = 0;         // Adler: bytes, offset-weighted bytes of this row; totals mod 65521
-    u32x4 ahead[kWords];                              // the filtered bytes of four groups
-    uint32_t behind[4 * kWords];                      // the reconstructed bytes of four groups
-    uint64_t b64 = 0;
-    const int steps = rounds * period + 63;
-    for (int t = 0; t <= steps; ++t) {
-        // the row above: what the lane before produced in the previous step (same group index)
-        uint32_t up[4];
+        int row = lane, g = -lane;                        // this step's group; g < 0: not started
+        uint32_t ft = 0;
+        uint32_t o[4] = {0, 0, 0, 0};                     // the four pixels of the previous step (what lane + 1 sees above)
+        uint32_t up3 = 0;                                 // upper-left of the next group: the last pixel above of this one
+        uint32_t a1 = 0, c32 = 0;                         // Adler: bytes, offset-weighted bytes of this row
+        u32x4 ahead[kWords];                              // the filtered bytes of four groups
+        uint32_t behind[4 * kWords];                      // the reconstructed bytes of four groups
+        uint64_t b64 = 0;
+        const int steps = rounds * period + 63;
+        for (int t = 0; t <= steps; ++t) {
+            // the row above: what the lane before produced in the previous step (same group index)
+            uint32_t up[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) up[k] = (uint32_t)__shfl_up((int)o[k], 1);
-        const bool active = g >= 0 && g < groups && row < H;
-        if (lane == 0 && active && row > 0) {
+            for (int k = 0; k < 4; ++k) up[k] = (uint32_t)__shfl_up((int)o[k], 1);
+            const bool active = g >= 0 && g < groups && row < H;
+            if (lane == 0 && active && row > 0) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) up[k] = s_row[4 * g + k];
-        }
-        if (row == 0) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) up[k] = 0;
-        }
-        if (active) {
-            const uint8_t *rp = src + (size_t)row * stride;
-            if (g == 0) {
-                ft = rp[0];
-                bad |= ft > 4;
-                up3 = 0;
-                o[3] = 0;                             // nothing to the left
-                a1 = ft; c32 = 0; b64 = 0;            // the filter byte sits at offset 0
+                for (int k = 0; k < 4; ++k) up[k] = s_row[4 * g + k];
             }
-            const int valid = min(4, W - 4 * g);      // pixels of this group
-            const uint32_t j0 = 1u + (uint32_t)g * (4 * BPP);
-            // The filtered bytes of four groups at a time (16-byte loads): every lane reads its own row, 64 cache lines per
-            // load instruction, and with dword loads each of them is fetched from L2 ten times over (the lines of all the
-            // waves of a CU do not fit its L1).  A read may run up to 63 bytes past the row: the scratch has that slack.
-            if ((g & 3) == 0) {
+            if (row == 0) {
 #pragma unroll
-                for (int q = 0; q < kWords; ++q) ahead[q] = ld16(rp + j0 + 16 * q);
+                for (int k = 0; k < 4; ++k) up[k] = 0;
             }
-            uint32_t xw[kWords];
-#pragma unroll
-            for (int q = 0; q < kWords; ++q) {
-                // dword q of group (g & 3) among the 4 * kWords buffered: element (g & 3) * kWords + q
-                uint32_t v = 0;
-#pragma unroll
-                for (int part = 0; part < 4; ++part) {
-                    const int at = part * kWords + q;
-                    const u32x4 from = ahead[at >> 2];
-                    const uint32_t w = (at & 3) == 0 ? from.x : (at & 3) == 1 ? from.y : (at & 3) == 2 ? from.z : from.w;
-                    v = (g & 3) == part ? w : v;
+            if (active) {
+                const uint8_t *rp = src + pass_off + (size_t)row * stride;
+                if (g == 0) {
+                    ft = rp[0];
+                    bad |= ft > 4;
+                    up3 = 0;
+                    o[3] = 0;                             // nothing to the left
+                    a1 = ft; c32 = 0; b64 = 0;            // the filter byte sits at offset 0
                 }
-                const int have = valid * BPP - 4 * q;                     // bytes of this dword that belong to the row
-                xw[q] = have >= 4 ? v : have <= 0 ? 0u : (v & ((1u << (8 * have)) - 1u));
-            }
-            // Adler-32 terms of these bytes: sum and offset-weighted sum
+                const int valid = min(4, W - 4 * g);      // pixels of this group
+                const uint32_t j0 = 1u + (uint32_t)g * (4 * BPP);
+                // The filtered bytes of four groups at a time (16-byte loads): every lane reads its own row, 64 cache lines per
+                // load instruction, and with dword loads each of them is fetched from L2 ten times over (the lines of all the
+                // waves of a CU do not fit its L1).  A read may run up to 63 bytes past the row: the scratch has that slack.
+                if ((g & 3) == 0) {
 #pragma unroll
-            for (int q = 0; q < kWords; ++q) {
-                const uint32_t sum = __builtin_amdgcn_udot4(xw[q], 0x01010101u, 0u, false);
-                a1 += sum;
-                c32 = __builtin_amdgcn_udot4(xw[q], 0x03020100u, c32, false);
-                b64 += (uint64_t)(j0 + 4 * q) * sum;
-            }
-            uint32_t x[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                uint32_t v = 0;
-#pragma unroll
-                for (int ch = 0; ch < BPP; ++ch) {
-                    const int e = k * BPP + ch;
-                    v |= ((xw[e >> 2] >> (8 * (e & 3))) & 255u) << (8 * ch);
+                    for (int q = 0; q < kWords; ++q) ahead[q] = ld16(rp + j0 + 16 * q);
                 }
-                x[k] = v;
-            }
-            uint32_t left = o[3], ul = up3;
-            const int m1 = -(int)(ft == 1), m2 = -(int)(ft == 2), m3 = -(int)(ft == 3), m4 = -(int)(ft >= 4);
+                uint32_t xw[kWords];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                o[k] = recon_pixel<BPP>(m1, m2, m3, m4, x[k], left, up[k], ul);
-                left = o[k];
-                ul = up[k];
-            }
-            up3 = up[3];
-            // the reconstructed bytes, in stream order
-            uint32_t ow[kWords];
-            if (BPP == 4) {
+                for (int q = 0; q < kWords; ++q) {
+                    // dword q of group (g & 3) among the 4 * kWords buffered: element (g & 3) * kWords + q
+                    uint32_t v = 0;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) ow[q % kWords] = o[q];
-            } else if (BPP == 3) {
-                ow[0] = o[0] | (o[1] << 24);
-                ow[1 % kWords] = (o[1] >> 8) | (o[2] << 16);
-                ow[2 % kWords] = (o[2] >> 16) | (o[3] << 8);
-            } else if (BPP == 2) {
-                ow[0] = o[0] | (o[1] << 16);
-                ow[1 % kWords] = o[2] | (o[3] << 16);
-            } else {
-                ow[0] = o[0] | (o[1] << 8) | (o[2] << 16) | (o[3] << 24);
-            }
-            if (BPP == 2) {
-                // gray + alpha: only the gray samples leave (one byte per pixel, rows of `width` bytes)
-                const uint32_t gray = (o[0] & 255u) | ((o[1] & 255u) << 8) | ((o[2] & 255u) << 16) | ((o[3] & 255u) << 24);
-                uint8_t *wp = dst + (size_t)row * W + (size_t)g * 4;
-                if (valid == 4) __builtin_memcpy(wp, &gray, 4);
-                else for (int e = 0; e < valid; ++e) wp[e] = (uint8_t)(gray >> (8 * e));
-            } else if (MAPPED) {
-                const int depth = d.info.depth, per = 8 / depth, px = d.info.width;
-                const uint32_t top = (1u << depth) - 1u;
-                uint8_t *wp = dst + (size_t)row * px;
-                for (int e = 0; e < valid; ++e) {
-                    const uint32_t byte = (ow[0] >> (8 * e)) & 255u;
-                    const int x0 = (4 * g + e) * per;
-                    for (int q = 0; q < per && x0 + q < px; ++q) wp[x0 + q] = s_lut[(byte >> (8 - depth * (q + 1))) & top];
-                }
-            } else if (((g | 3) + 1) * 4 <= W) {
-                // one of four whole groups in a row: gathered, written with 16-byte stores when the fourth is done
-#pragma unroll
-                for (int part = 0; part < 4; ++part)
-#pragma unroll
-                    for (int q = 0; q < kWords; ++q) {
+                    for (int part = 0; part < 4; ++part) {
                         const int at = part * kWords + q;
-                        behind[at] = (g & 3) == part ? ow[q] : behind[at];
+                        const u32x4 from = ahead[at >> 2];
+                        const uint32_t w = (at & 3) == 0 ? from.x : (at & 3) == 1 ? from.y : (at & 3) == 2 ? from.z : from.w;
+                        v = (g & 3) == part ? w : v;
                     }
-                if ((g & 3) == 3) {
-                    uint8_t *wp = dst + (size_t)row * rb + (size_t)(g - 3) * (4 * BPP);
-#pragma unroll
-                    for (int q = 0; q < kWords; ++q) st16(wp + 16 * q, u32x4{behind[4 * q], behind[4 * q + 1], behind[4 * q + 2], behind[4 * q + 3]});
+                    const int have = valid * BPP - 4 * q;                     // bytes of this dword that belong to the row
+                    xw[q] = have >= 4 ? v : have <= 0 ? 0u : (v & ((1u << (8 * have)) - 1u));
                 }
-            } else {                                      // the groups at the end of a row that do not fill a block of four
-                uint8_t *wp = dst + (size_t)row * rb + (size_t)g * (4 * BPP);
-                if (valid == 4) {
+                // Adler-32 terms of these bytes: sum and offset-weighted sum
 #pragma unroll
-                    for (int q = 0; q < kWords; ++q) __builtin_memcpy(wp + 4 * q, &ow[q], 4);
+                for (int q = 0; q < kWords; ++q) {
+                    const uint32_t sum = __builtin_amdgcn_udot4(xw[q], 0x01010101u, 0u, false);
+                    a1 += sum;
+                    c32 = __builtin_amdgcn_udot4(xw[q], 0x03020100u, c32, false);
+                    b64 += (uint64_t)(j0 + 4 * q) * sum;
+                }
+                uint32_t x[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    uint32_t v = 0;
+#pragma unroll
+                    for (int ch = 0; ch < BPP; ++ch) {
+                        const int e = k * BPP + ch;
+                        v |= ((xw[e >> 2] >> (8 * (e & 3))) & 255u) << (8 * ch);
+                    }
+                    x[k] = v;
+                }
+                uint32_t left = o[3], ul = up3;
+                const int m1 = -(int)(ft == 1), m2 = -(int)(ft == 2), m3 = -(int)(ft == 3), m4 = -(int)(ft >= 4);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    o[k] = recon_pixel<BPP>(m1, m2, m3, m4, x[k], left, up[k], ul);
+                    left = o[k];
+                    ul = up[k];
+                }
+                up3 = up[3];
+                // the reconstructed bytes, in stream order
+                uint32_t ow[kWords];
+                if (BPP == 4) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) ow[q % kWords] = o[q];
+                } else if (BPP == 3) {
+                    ow[0] = o[0] | (o[1] << 24);
+                    ow[1 % kWords] = (o[1] >> 8) | (o[2] << 16);
+                    ow[2 % kWords] = (o[2] >> 16) | (o[3] << 8);
+                } else if (BPP == 2) {
+                    ow[0] = o[0] | (o[1] << 16);
+                    ow[1 % kWords] = o[2] | (o[3] << 16);
                 } else {
-                    for (int e = 0; e < valid * BPP; ++e) wp[e] = (uint8_t)(ow[e >> 2] >> (8 * (e & 3)));
+                    ow[0] = o[0] | (o[1] << 8) | (o[2] << 16) | (o[3] << 24);
+                }
+                if (ADAM7) {
+                    // the pass's pixels go to (x0 + k dx, y0 + row dy) of the whole image, one at a time
+                    const int px = d.info.width;
+                    uint8_t *wp = dst + (size_t)(geo.y0 + row * geo.dy) * px * (MAPPED || BPP == 2 ? 1 : BPP);
+                    if (MAPPED) {
+                        const int depth = d.info.depth, per = 8 / depth;
+                        const uint32_t top = (1u << depth) - 1u;
+                        for (int e = 0; e < valid; ++e) {
+                            const uint32_t byte = (ow[0] >> (8 * e)) & 255u;
+                            const int k0 = (4 * g + e) * per;
+                            for (int q = 0; q < per && k0 + q < geo.w; ++q)
+                                wp[geo.x0 + (k0 + q) * geo.dx] = s_lut[(byte >> (8 - depth * (q + 1))) & top];
+                        }
+                    } else {
+                        for (int e = 0; e < valid; ++e) {
+                            const size_t x = (size_t)(geo.x0 + (4 * g + e) * geo.dx);
+                            if (BPP == 2 || BPP == 1) wp[x] = (uint8_t)o[e];
+                            else for (int ch = 0; ch < BPP; ++ch) wp[x * BPP + ch] = (uint8_t)(o[e] >> (8 * ch));
+                        }
+                    }
+                } else if (BPP == 2) {
+                    // gray + alpha: only the gray samples leave (one byte per pixel, rows of `width` bytes)
+                    const uint32_t gray = (o[0] & 255u) | ((o[1] & 255u) << 8) | ((o[2] & 255u) << 16) | ((o[3] & 255u) << 24);
+                    uint8_t *wp = dst + (size_t)row * W + (size_t)g * 4;
+                    if (valid == 4) __builtin_memcpy(wp, &gray, 4);
+                    else for (int e = 0; e < valid; ++e) wp[e] = (uint8_t)(gray >> (8 * e));
+                } else if (MAPPED) {
+                    const int depth = d.info.depth, per = 8 / depth, px = d.info.width;
+                    const uint32_t top = (1u << depth) - 1u;
+                    uint8_t *wp = dst + (size_t)row * px;
+                    for (int e = 0; e < valid; ++e) {
+                        const uint32_t byte = (ow[0] >> (8 * e)) & 255u;
+                        const int x0 = (4 * g + e) * per;
+                        for (int q = 0; q < per && x0 + q < px; ++q) wp[x0 + q] = s_lut[(byte >> (8 - depth * (q + 1))) & top];
+                    }
+                } else if (((g | 3) + 1) * 4 <= W) {
+                    // one of four whole groups in a row: gathered, written with 16-byte stores when the fourth is done
+#pragma unroll
+                    for (int part = 0; part < 4; ++part)
+#pragma unroll
+                        for (int q = 0; q < kWords; ++q) {
+                            const int at = part * kWords + q;
+                            behind[at] = (g & 3) == part ? ow[q] : behind[at];
+                        }
+                    if ((g & 3) == 3) {
+                        uint8_t *wp = dst + (size_t)row * rb + (size_t)(g - 3) * (4 * BPP);
+#pragma unroll
+                        for (int q = 0; q < kWords; ++q) st16(wp + 16 * q, u32x4{behind[4 * q], behind[4 * q + 1], behind[4 * q + 2], behind[4 * q + 3]});
+                    }
+                } else {                                      // the groups at the end of a row that do not fill a block of four
+                    uint8_t *wp = dst + (size_t)row * rb + (size_t)g * (4 * BPP);
+                    if (valid == 4) {
+#pragma unroll
+                        for (int q = 0; q < kWords; ++q) __builtin_memcpy(wp + 4 * q, &ow[q], 4);
+                    } else {
+                        for (int e = 0; e < valid * BPP; ++e) wp[e] = (uint8_t)(ow[e >> 2] >> (8 * (e & 3)));
+                    }
+                }
+                if (lane == 63) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) s_row[4 * g + k] = o[k];
+                }
+                if (g == groups - 1) {
+                    // this row's share of the sums: byte j of the row sits (total - row * stride - j) bytes before the end
+                    const uint64_t after = total - pass_off - (uint64_t)row * stride;
+                    const uint64_t weighted = b64 + c32;
+                    s1 = (s1 + a1 % 65521u) % 65521u;
+                    s2 = (uint32_t)((s2 + (after % 65521u) * (uint64_t)(a1 % 65521u) + 65521u - weighted % 65521u) % 65521u);
                 }
             }
-            if (lane == 63) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) s_row[4 * g + k] = o[k];
-            }
-            if (g == groups - 1) {
-                // this row's share of the sums: byte j of the row sits (total - row * stride - j) bytes before the end
-                const uint64_t after = total - (uint64_t)row * stride;
-                const uint64_t weighted = b64 + c32;
-                s1 = (s1 + a1 % 65521u) % 65521u;
-                s2 = (uint32_t)((s2 + (after % 65521u) * (uint64_t)(a1 % 65521u) + 65521u - weighted % 65521u) % 65521u);
-            }
+            ++g;
+            if (g == period) { g = 0; row += 64; }
         }
-        ++g;
-        if (g == period) { g = 0; row += 64; }
+        pass_off += (uint64_t)stride * (uint64_t)H;
     }
     // s1 = 1 + sum of bytes, s2 = total + sum of (distance to the end) * byte   (mod 65521)
 #pragma unroll
@@ -666,7 +699,7 @@ KE_API int ke_png_decode(ke_ctx *ctx, const uint8_t *files, const uint64_t *offs
         while (last < items.size()) {
             Item &it = items[last];
             const uint64_t zl = ((uint64_t)it.d.info.zlen + 15) & ~15ull;
-            const uint64_t want = ((uint64_t)it.d.info.row_bytes + 1) * it.d.info.height;
+            const uint64_t want = it.d.info.raw_len;
             const uint64_t rw = (want + 32 + 15) & ~15ull, rc = want / 3 + 2;      // a copy covers at least 3 bytes
             if (last > first && zbytes + zl + raw_bytes + rw + (nrecs + rc) * 8 > budget) break;
             it.d.info.zoff = 0;
@@ -715,16 +748,22 @@ KE_API int ke_png_decode(ke_ctx *ctx, const uint8_t *files, const uint64_t *offs
                            (const uint2 *)d_rec, (const int32_t *)d_status, (const uint32_t *)d_nrec);
         const size_t row_lds = (size_t)max_groups * 16;
         // one launch per kind present in the sub-batch (a workgroup whose image is of another kind returns at once)
-        bool kinds[5] = {false, false, false, false, false};
-        for (const KePngDev &d : devs) kinds[d.info.mapped ? 3 : d.info.fbpp == 2 ? 4 : d.info.channels == 1 ? 0 : d.info.channels == 3 ? 1 : 2] = true;
-#define KE_UNFILTER(BPP, MAPPED)                                                                                                    \
-    hipLaunchKernelGGL((ke_png_unfilter<BPP, MAPPED>), dim3((unsigned)m), dim3(64), row_lds, ctx->stream, (const KePngDev *)d_imgs,  \
+        bool kinds[10] = {};
+        for (const KePngDev &d : devs)
+            kinds[(d.info.mapped ? 3 : d.info.fbpp == 2 ? 4 : d.info.channels == 1 ? 0 : d.info.channels == 3 ? 1 : 2) + (d.info.interlace ? 5 : 0)] = true;
+#define KE_UNFILTER(BPP, MAPPED, ADAM7)                                                                                                    \
+    hipLaunchKernelGGL((ke_png_unfilter<BPP, MAPPED, ADAM7>), dim3((unsigned)m), dim3(64), row_lds, ctx->stream, (const KePngDev *)d_imgs,  \
                        (const uint8_t *)d_raw, pixels_out, (int32_t *)d_status, (const uint32_t *)d_adler)
-        if (kinds[0]) KE_UNFILTER(1, false);
-        if (kinds[1]) KE_UNFILTER(3, false);
-        if (kinds[2]) KE_UNFILTER(4, false);
-        if (kinds[3]) KE_UNFILTER(1, true);
-        if (kinds[4]) KE_UNFILTER(2, false);
+        if (kinds[0]) KE_UNFILTER(1, false, false);
+        if (kinds[1]) KE_UNFILTER(3, false, false);
+        if (kinds[2]) KE_UNFILTER(4, false, false);
+        if (kinds[3]) KE_UNFILTER(1, true, false);
+        if (kinds[4]) KE_UNFILTER(2, false, false);
+        if (kinds[5]) KE_UNFILTER(1, false, true);
+        if (kinds[6]) KE_UNFILTER(3, false, true);
+        if (kinds[7]) KE_UNFILTER(4, false, true);
+        if (kinds[8]) KE_UNFILTER(1, true, true);
+        if (kinds[9]) KE_UNFILTER(2, false, true);
 #undef KE_UNFILTER
         KE_HIP(ctx, hipGetLastError());
         st.resize((size_t)m);

@@ -2,8 +2,8 @@
 // Pillow (oracle/keyes_png_cpu.cpp): zlib/deflate decompression (RFC 1950 / 1951) of the concatenated IDAT data and the five
 // scanline filters of the PNG specification (None, Sub, Up, Average, Paeth).  Lossless, so "the pixels Pillow yields" is a
 // matter of following the two specifications; what is decoded is what `Image.open(path)` hands the reference's batch hasher
-// (src/core/fastsig.py:31-34) for 8-bit grayscale, RGB and RGBA files without interlacing.  Everything else (palette, 16-bit,
-// Adam7) is refused by the parser and stays with Pillow.  Palette files and grayscale files of 1 / 2 / 4 bits are
+// (src/core/fastsig.py:31-34) for 8-bit grayscale, RGB and RGBA files, interlaced (Adam7) or not.  16-bit files are refused by
+// the parser and stay with Pillow.  Palette files and grayscale files of 1 / 2 / 4 bits are
 // decoded to the luma Pillow's `convert("L")` makes of them -- which is what the reference's hashes see (src/sig/phash.py:25):
 // samples unpacked most significant bits first, mapped through a 256-entry table (palette entry -> L by ImagingConvert's
 // rounded 16-bit weights; 1 / 2 / 4-bit gray scaled to 0..255).
@@ -42,7 +42,25 @@ struct KePngInfo {
     int32_t fbpp;                        // bytes per pixel in the file = the filters' unit: `channels`, except gray + alpha (2):
                                          // such a file decodes to its gray samples alone -- what convert("L") makes of mode "LA",
                                          // i.e. what the reference hashes (src/sig/phash.py:25)
+    int32_t interlace;                   // 1: Adam7 -- the stream holds seven reduced images one after another (ke_adam7_pass)
+    uint32_t raw_len;                    // filtered bytes the stream inflates to: every row of every pass, filter-type bytes included
 };
+
+// Adam7 (PNG specification, "Interlace methods"): pass p (0..6) is the image of the pixels (x0 + k dx, y0 + j dy), w x h of
+// them, filtered as an image of its own; a pass without pixels has no bytes in the stream at all.
+struct KeAdam7 { int x0, y0, dx, dy, w, h; };
+KE_PNG_HD KeAdam7 ke_adam7_pass(int p, int width, int height) {
+    KeAdam7 a;
+    a.x0 = (0x00102040 >> (4 * p)) & 15;     // 0 4 0 2 0 1 0
+    a.y0 = (0x01020400 >> (4 * p)) & 15;     // 0 0 4 0 2 0 1
+    a.dx = (0x01224488 >> (4 * p)) & 15;     // 8 8 4 4 2 2 1
+    a.dy = (0x02244888 >> (4 * p)) & 15;     // 8 8 8 4 4 2 2
+    a.w = (width - a.x0 + a.dx - 1) / a.dx;
+    a.h = (height - a.y0 + a.dy - 1) / a.dy;
+    if (a.w < 0) a.w = 0;
+    if (a.h < 0) a.h = 0;
+    return a;
+}
 
 KE_PNG_HD uint32_t ke_brev32(uint32_t v) {
 #ifdef __HIP_DEVICE_COMPILE__

@@ -2,8 +2,8 @@
 // signature, IHDR, where the IDAT payloads lie (their concatenation is one zlib stream per image), IEND; chunk CRCs are
 // verified where Pillow's ChunkStream verifies them (a damaged file raises there and the reference drops it,
 // src/core/fastsig.py:36-37).  8-bit grayscale, RGB
-// and RGBA without interlacing are taken; 16-bit and Adam7 files are KE_PNG_UNSUPPORTED (palette / sub-byte gray / gray + alpha files decode to the luma convert("L") gives them)
-// and stay with Pillow.
+// and RGBA are taken, interlaced (Adam7) or not; 16-bit files are KE_PNG_UNSUPPORTED and stay with Pillow (palette / sub-byte
+// gray / gray + alpha files decode to the luma convert("L") gives them).
 #pragma once
 
 #include <cstring>
@@ -75,7 +75,7 @@ static inline void ke_parse_png(const uint8_t *p, size_t size, std::vector<KePng
             info.channels = (ctype == 0 || ctype == 3 || ctype == 4) ? 1 : ctype == 2 ? 3 : ctype == 6 ? 4 : 0;
             info.fbpp = ctype == 4 ? 2 : info.channels;
             const bool sub8 = (ctype == 0 || ctype == 3) && (depth == 1 || depth == 2 || depth == 4);
-            if (!(depth == 8 || sub8) || info.channels == 0 || lace != 0 || info.width > KE_PNG_MAX_WIDTH ||
+            if (!(depth == 8 || sub8) || info.channels == 0 || lace > 1 || info.width > KE_PNG_MAX_WIDTH ||
                 (uint64_t)info.width * info.height > (1ull << 28)) {
                 info.status = KE_PNG_UNSUPPORTED;
                 if (!(depth == 1 || depth == 2 || depth == 4 || depth == 8 || depth == 16) || ctype > 6 || ctype == 1 || ctype == 5 || lace > 1)
@@ -85,6 +85,16 @@ static inline void ke_parse_png(const uint8_t *p, size_t size, std::vector<KePng
             info.depth = depth;
             info.mapped = (ctype == 3 || sub8) ? 1 : 0;
             info.row_bytes = (int32_t)(((int64_t)info.width * info.fbpp * depth + 7) / 8);
+            info.interlace = lace;
+            uint64_t raw_len = ((uint64_t)info.row_bytes + 1) * (uint64_t)info.height;
+            if (lace) {
+                raw_len = 0;
+                for (int pass = 0; pass < 7; ++pass) {
+                    const KeAdam7 a = ke_adam7_pass(pass, info.width, info.height);
+                    if (a.w > 0 && a.h > 0) raw_len += (((uint64_t)a.w * info.fbpp * depth + 7) / 8 + 1) * (uint64_t)a.h;
+                }
+            }
+            info.raw_len = (uint32_t)raw_len;            // at most 2^28 pixels of 4 bytes + a filter byte per row
             palette = ctype == 3;
             if (info.mapped && !palette)                      // 1 / 2 / 4-bit gray: Pillow's "1", "L;2", "L;4" unpackers scale to 0..255
                 for (int v = 0; v < (1 << depth); ++v) info.lut[v] = (uint8_t)(v * 255 / ((1 << depth) - 1));

@@ -45,8 +45,7 @@ int ko_png_decode(const uint8_t *file, uint64_t size, uint8_t *out) {
     if (info.status != KE_PNG_OK) return info.status;
     std::vector<uint8_t> stream;
     for (const KePngSeg &s : segs) stream.insert(stream.end(), file + s.off, file + s.off + s.len);
-    const int rb = info.row_bytes;
-    const size_t want = (size_t)(rb + 1) * info.height;
+    const size_t want = info.raw_len;
     std::vector<uint8_t> raw;
     raw.reserve(want);
     MemSrc src{stream.data(), info.zlen};
@@ -56,34 +55,35 @@ int ko_png_decode(const uint8_t *file, uint64_t size, uint8_t *out) {
     uint32_t adler = 0;
     if (ke_inflate_zlib(bits, sink, info.zlen, (uint32_t)want, t, &adler) != KE_PNG_OK) return KE_PNG_CORRUPT;
     if (raw.size() != want || ke_adler32(raw.data(), raw.size()) != adler) return KE_PNG_CORRUPT;
-    if (info.mapped) {                                       // packed samples: unfilter the bytes, unpack, map to luma
-        std::vector<uint8_t> rows((size_t)rb * info.height);
-        for (int y = 0; y < info.height; ++y) {
-            const uint8_t *row = raw.data() + (size_t)y * (rb + 1);
-            if (ke_png_unfilter_row(row[0], row + 1, y ? rows.data() + (size_t)(y - 1) * rb : nullptr, rows.data() + (size_t)y * rb, rb, 1) != KE_PNG_OK)
-                return KE_PNG_CORRUPT;
-            for (int x = 0; x < info.width; ++x) {
-                const int bit = x * info.depth;
-                const uint32_t byte = rows[(size_t)y * rb + (bit >> 3)];
-                out[(size_t)y * info.width + x] = info.lut[(byte >> (8 - info.depth - (bit & 7))) & ((1u << info.depth) - 1u)];
+    // every pass (one for a file without interlacing) is a filtered image of its own: unfilter its rows, then put its samples
+    // where they belong -- packed samples unpacked and mapped to luma, gray + alpha reduced to the gray samples
+    const int out_bpp = (info.mapped || info.fbpp != info.channels) ? 1 : info.channels;
+    const int unit = info.mapped ? 1 : info.fbpp;
+    const uint8_t *at = raw.data();
+    std::vector<uint8_t> rows;
+    for (int pass = 0; pass < (info.interlace ? 7 : 1); ++pass) {
+        KeAdam7 a{0, 0, 1, 1, info.width, info.height};
+        if (info.interlace) a = ke_adam7_pass(pass, info.width, info.height);
+        if (a.w == 0 || a.h == 0) continue;
+        const int rb = (int)(((int64_t)a.w * info.fbpp * info.depth + 7) / 8);
+        rows.assign((size_t)rb * a.h, 0);
+        for (int y = 0; y < a.h; ++y) {
+            const uint8_t *row = at + (size_t)y * (rb + 1);
+            uint8_t *cur = rows.data() + (size_t)y * rb;
+            if (ke_png_unfilter_row(row[0], row + 1, y ? cur - rb : nullptr, cur, rb, unit) != KE_PNG_OK) return KE_PNG_CORRUPT;
+            uint8_t *dst = out + ((size_t)(a.y0 + y * a.dy) * info.width + a.x0) * out_bpp;
+            for (int x = 0; x < a.w; ++x, dst += (size_t)a.dx * out_bpp) {
+                if (info.mapped) {
+                    const int bit = x * info.depth;
+                    dst[0] = info.lut[(cur[bit >> 3] >> (8 - info.depth - (bit & 7))) & ((1u << info.depth) - 1u)];
+                } else if (out_bpp == 1) {
+                    dst[0] = cur[(size_t)x * info.fbpp];
+                } else {
+                    for (int c = 0; c < out_bpp; ++c) dst[c] = cur[(size_t)x * out_bpp + c];
+                }
             }
         }
-        return KE_PNG_OK;
-    }
-    if (info.fbpp != info.channels) {                        // gray + alpha: unfilter the two-byte pixels, keep the gray samples
-        std::vector<uint8_t> rows((size_t)rb * info.height);
-        for (int y = 0; y < info.height; ++y) {
-            const uint8_t *row = raw.data() + (size_t)y * (rb + 1);
-            if (ke_png_unfilter_row(row[0], row + 1, y ? rows.data() + (size_t)(y - 1) * rb : nullptr, rows.data() + (size_t)y * rb, rb, info.fbpp) != KE_PNG_OK)
-                return KE_PNG_CORRUPT;
-            for (int x = 0; x < info.width; ++x) out[(size_t)y * info.width + x] = rows[(size_t)y * rb + (size_t)x * info.fbpp];
-        }
-        return KE_PNG_OK;
-    }
-    for (int y = 0; y < info.height; ++y) {
-        const uint8_t *row = raw.data() + (size_t)y * (rb + 1);
-        if (ke_png_unfilter_row(row[0], row + 1, y ? out + (size_t)(y - 1) * rb : nullptr, out + (size_t)y * rb, rb, info.channels) != KE_PNG_OK)
-            return KE_PNG_CORRUPT;
+        at += (size_t)(rb + 1) * a.h;
     }
     return KE_PNG_OK;
 }

@@ -1,6 +1,6 @@
 """PNG files for the decoder tests, made with the installed Pillow: what the GPU decoder takes (8-bit L / RGB / RGBA, every
-compression level incl. stored blocks and optimised encoding, sizes from 1x1) and what it hands back (palette, gray+alpha,
-16-bit, 1-bit, interlaced, truncated, damaged)."""
+compression level incl. stored blocks and optimised encoding, sizes from 1x1; palette, sub-byte, gray+alpha and Adam7 files)
+and what it hands back (16-bit, truncated, damaged)."""
 from __future__ import annotations
 
 import io
@@ -128,6 +128,100 @@ def handmade(full: bool = False):
         for level in (6, 9):
             data = _container(rows.tobytes(), w, h, ctype, level, 0, 1 << 30)
             yield f"periodic_{w}x{h}_c{ctype}_l{level}", data, np.asarray(Image.open(io.BytesIO(data)))
+
+
+_ADAM7 = ((0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2))
+
+
+def _filtered(rows: np.ndarray, unit: int, types) -> bytes:
+    """The forward PNG filters (specification, "Filter algorithms") on rows of packed bytes, one type per row."""
+    h, rb = rows.shape
+    out = bytearray()
+    prev = np.zeros(rb, np.int32)
+    for y in range(h):
+        cur = rows[y].astype(np.int32)
+        a = np.zeros(rb, np.int32)
+        c = np.zeros(rb, np.int32)
+        a[unit:] = cur[:rb - unit] if rb > unit else 0
+        c[unit:] = prev[:rb - unit] if rb > unit else 0
+        t = int(types[y])
+        if t == 0:
+            pred = 0
+        elif t == 1:
+            pred = a
+        elif t == 2:
+            pred = prev
+        elif t == 3:
+            pred = (a + prev) >> 1
+        else:
+            pa, pb, pc = np.abs(prev - c), np.abs(a - c), np.abs(a + prev - 2 * c)
+            pred = np.where((pa <= pb) & (pa <= pc), a, np.where(pb <= pc, prev, c))
+        out += bytes([t]) + ((cur - pred) & 255).astype(np.uint8).tobytes()
+        prev = cur
+    return bytes(out)
+
+
+def _adam7_stream(samples: np.ndarray, depth: int, rng) -> bytes:
+    """samples: H x W x C (8-bit) or H x W x 1 values below 2**depth -> the seven passes' filtered rows, random filter types."""
+    h, w, ch = samples.shape
+    out = b""
+    for (x0, y0, dx, dy) in _ADAM7:
+        sub = samples[y0::dy, x0::dx]
+        if sub.shape[0] == 0 or sub.shape[1] == 0:
+            continue
+        if depth == 8:
+            rows, unit = sub.reshape(sub.shape[0], -1), ch
+        else:
+            bits = ((sub[:, :, 0, None] >> np.arange(depth - 1, -1, -1)) & 1).reshape(sub.shape[0], -1).astype(np.uint8)
+            rows, unit = np.packbits(bits, axis=1), 1
+        out += _filtered(np.ascontiguousarray(rows), unit, rng.integers(0, 5, sub.shape[0]))
+    return out
+
+
+def _container2(raw: bytes, w: int, h: int, ctype: int, depth: int, interlace: int, plte: bytes = None, trns: bytes = None,
+                level: int = 6, chunk: int = 1 << 30) -> bytes:
+    def ch(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d))
+
+    z = zlib.compress(raw, level)
+    out = b"\x89PNG\r\n\x1a\n" + ch(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, interlace))
+    if plte is not None:
+        out += ch(b"PLTE", plte)
+    if trns is not None:
+        out += ch(b"tRNS", trns)
+    for o in range(0, len(z), chunk):
+        out += ch(b"IDAT", z[o:o + chunk])
+    return out + ch(b"IEND", b"")
+
+
+def interlaced(full: bool = False):
+    """Yields (name, file bytes, what the reference's hashes see): Adam7 files (no writer in Pillow -- built here, every filter
+    type in every pass) of every kind the decoder takes: 8-bit L / RGB / RGBA / LA, palette and grayscale of 1 / 2 / 4 / 8 bits;
+    sizes where some passes are empty (1x1 .. 4x4), where rows end inside a byte, and ordinary ones."""
+    rng = np.random.default_rng(12)
+    sizes = [(1, 1), (2, 1), (1, 2), (3, 2), (4, 4), (5, 5), (8, 8), (9, 17), (75, 53), (96, 80), (257, 129)] + ([(640, 333), (33, 1000), (1030, 40)] if full else [])
+    for (w, h) in sizes:
+        smooth = (w * h) > 5000
+        for ctype, chans in ((0, 1), (2, 3), (6, 4), (4, 2)):
+            if smooth:
+                yy, xx = np.mgrid[0:h, 0:w]
+                a = np.stack([(xx * 2 + yy) % 256, (yy * 3) % 256, (xx + yy // 2) % 256, (xx * yy // 7) % 256], -1).astype(np.uint8)[:, :, :chans]
+                a = (a + rng.integers(0, 4, a.shape)).astype(np.uint8)
+            else:
+                a = rng.integers(0, 256, (h, w, chans), dtype=np.uint8)
+            data = _container2(_adam7_stream(a, 8, rng), w, h, ctype, 8, 1, chunk=(1 << 30) if ctype != 2 else 37)
+            with Image.open(io.BytesIO(data)) as im:
+                ref = np.asarray(im.convert("L") if im.mode == "LA" else im)
+            yield f"adam7_c{ctype}_{w}x{h}", data, ref
+        for depth in (1, 2, 4, 8):
+            vals = rng.integers(0, 1 << depth, (h, w, 1), dtype=np.uint8)
+            for ctype in ((0, 3) if depth < 8 else (3,)):
+                plte = rng.integers(0, 256, 3 * (1 << depth), dtype=np.uint8).tobytes() if ctype == 3 else None
+                trns = bytes([0, 128]) if ctype == 3 and w % 2 else None
+                data = _container2(_adam7_stream(vals, depth, rng), w, h, ctype, depth, 1, plte=plte, trns=trns)
+                with Image.open(io.BytesIO(data)) as im:
+                    ref = np.asarray(im.convert("L"))
+                yield f"adam7_c{ctype}_d{depth}_{w}x{h}", data, ref
 
 
 def refused():

@@ -60,12 +60,12 @@ def damaged(rng, files, variants, kind, fmt="jpeg"):
 
 def pillow_pixels(blob):
     """Pillow's strict decode (LOAD_TRUNCATED_IMAGES off, as in the batch hasher's worker processes) or None.  Palette, bilevel
-    and sub-byte gray PNGs as the hashes see them: convert("L") (what ke_png_decode yields for those)."""
+    sub-byte gray and gray + alpha PNGs as the hashes see them: convert("L") (what ke_png_decode yields for those)."""
     saved, ImageFile.LOAD_TRUNCATED_IMAGES = ImageFile.LOAD_TRUNCATED_IMAGES, False
     try:
         im = Image.open(io.BytesIO(blob))
         im.load()
-        if im.format == "PNG" and (im.mode in ("P", "1") or (im.mode == "L" and blob[24] < 8)):
+        if im.format == "PNG" and (im.mode in ("P", "1", "LA") or (im.mode == "L" and blob[24] < 8)):
             return np.asarray(im.convert("L"))
         return np.asarray(im)
     except Exception:
@@ -80,7 +80,7 @@ def check(decode_batch, variants, seed, files=40, fmt="jpeg"):
     if fmt == "jpeg":
         pool = [c for c in J.supported() if c[2].shape[0] >= 16 and c[2].shape[1] >= 16]
     else:
-        pool = [c for c in list(P.supported()) + list(P.handmade()) + list(P.mapped()) if c[2].shape[0] >= 8]
+        pool = [c for c in list(P.supported()) + list(P.handmade()) + list(P.mapped()) + list(P.interlaced()) if c[2].shape[0] >= 8]
     pool = [pool[i] for i in rng.choice(len(pool), min(files, len(pool)), replace=False)]
     cases = taken = 0
     wrong = []

@@ -137,7 +137,7 @@ def test_fast_fill_takes_the_gpu_route_for_jpeg_files(tmp_path, monkeypatch):
 def test_png_decode_matches_pillow_in_one_mixed_batch(ctx):
     """ke_png_decode: 8-bit L / RGB / RGBA files of every compression level in one call -- stored, fixed and dynamic deflate
     blocks, all five filters -- equal to Pillow's pixels; palette / 16-bit / gray+alpha / damaged files reported per file."""
-    cases = list(P.supported(full=True)) + list(P.handmade(full=True)) + list(P.mapped(full=True))
+    cases = list(P.supported(full=True)) + list(P.handmade(full=True)) + list(P.mapped(full=True)) + list(P.interlaced(full=True))
     refused = list(P.refused())
     blobs = [c[1] for c in cases] + [r[1] for r in refused]
     out, status = ctx.png_decode(blobs)
@@ -162,7 +162,8 @@ def test_png_damage_is_reported_not_decoded(ctx):
     from PIL import Image
 
     rng = np.random.default_rng(21)
-    good = [c for c in P.supported() if c[2].shape[0] >= 64][:9] + list(P.handmade())[:6]
+    good = [c for c in P.supported() if c[2].shape[0] >= 64][:9] + list(P.handmade())[:6] + \
+        [c for c in P.interlaced() if c[2].shape[0] >= 53 and "_c2_" in c[0] or "_c0_96" in c[0] or "_c6_257" in c[0]]
     blobs, refs = [], []
     for name, data, ref in good:
         idat = data.index(b"IDAT") + 4

@@ -362,7 +362,10 @@ __device__ __forceinline__ uint32_t recon_pixel(int m1, int m2, int m3, int m4, 
 // MAPPED: palette files and grayscale below 8 bits.  The filters work on the packed bytes (one byte is the filter unit);
 // every byte then unpacks to 8 / depth samples, most significant bits first, and each sample goes out as the luma in the
 // image's table.
-template <int BPP, bool MAPPED, bool ADAM7>
+// WIDE: 16-bit samples.  The filters' unit is then 2 * BPP bytes: the loop runs over half pixels of BPP bytes whose left
+// neighbour is two places back, and what leaves is 8-bit (ke_png_parse.h: the samples' high bytes; grayscale clipped to 255;
+// gray + alpha as RGBA).
+template <int BPP, bool MAPPED, bool ADAM7, bool WIDE>
 __global__ __launch_bounds__(64) void ke_png_unfilter(const KePngDev *__restrict__ imgs, const uint8_t *__restrict__ raw,
                                                       uint8_t *__restrict__ out, int32_t *__restrict__ status,
                                                       const uint32_t *__restrict__ adler) {
@@ -370,7 +373,9 @@ __global__ __launch_bounds__(64) void ke_png_unfilter(const KePngDev *__restrict
     __shared__ uint8_t s_lut[MAPPED ? 256 : 4];
     const int64_t i = blockIdx.x;
     const KePngDev &d = imgs[i];
-    if (d.info.fbpp != BPP || (d.info.mapped != 0) != MAPPED || (d.info.interlace != 0) != ADAM7 || status[i] != KE_PNG_OK) return;
+    if (d.info.fbpp != BPP || (d.info.mapped != 0) != MAPPED || (d.info.interlace != 0) != ADAM7 || (d.info.depth == 16) != WIDE ||
+        status[i] != KE_PNG_OK)
+        return;
     const int lane = threadIdx.x;
     if (MAPPED) {
         for (int k = lane; k < 256; k += 64) s_lut[k] = d.info.lut[k];
@@ -388,7 +393,7 @@ __global__ __launch_bounds__(64) void ke_png_unfilter(const KePngDev *__restrict
         if (ADAM7) {
             geo = ke_adam7_pass(pass, d.info.width, d.info.height);
             if (geo.w == 0 || geo.h == 0) continue;
-            W = ((geo.w * BPP * (MAPPED ? d.info.depth : 8) + 7) >> 3) / BPP;
+            W = ((geo.w * BPP * (MAPPED ? d.info.depth : WIDE ? 16 : 8) + 7) >> 3) / BPP;
         }
         const int H = geo.h;
         const uint32_t rb = (uint32_t)W * BPP, stride = rb + 1;
@@ -399,7 +404,7 @@ __global__ __launch_bounds__(64) void ke_png_unfilter(const KePngDev *__restrict
         int row = lane, g = -lane;                        // this step's group; g < 0: not started
         uint32_t ft = 0;
         uint32_t o[4] = {0, 0, 0, 0};                     // the four pixels of the previous step (what lane + 1 sees above)
-        uint32_t up3 = 0;                                 // upper-left of the next group: the last pixel above of this one
+        uint32_t up3 = 0, up2 = 0;                        // upper-left of the next group: the last pixel(s) above of this one
         uint32_t a1 = 0, c32 = 0;                         // Adler: bytes, offset-weighted bytes of this row
         u32x4 ahead[kWords];                              // the filtered bytes of four groups
         uint32_t behind[4 * kWords];                      // the reconstructed bytes of four groups
@@ -424,8 +429,8 @@ __global__ __launch_bounds__(64) void ke_png_unfilter(const KePngDev *__restrict
                 if (g == 0) {
                     ft = rp[0];
                     bad |= ft > 4;
-                    up3 = 0;
-                    o[3] = 0;                             // nothing to the left
+                    up3 = up2 = 0;
+                    o[3] = o[2] = 0;                      // nothing to the left
                     a1 = ft; c32 = 0; b64 = 0;            // the filter byte sits at offset 0
                 }
                 const int valid = min(4, W - 4 * g);      // pixels of this group
@@ -471,14 +476,23 @@ __global__ __launch_bounds__(64) void ke_png_unfilter(const KePngDev *__restrict
                     }
                     x[k] = v;
                 }
-                uint32_t left = o[3], ul = up3;
                 const int m1 = -(int)(ft == 1), m2 = -(int)(ft == 2), m3 = -(int)(ft == 3), m4 = -(int)(ft >= 4);
+                if (WIDE) {
+                    const uint32_t l0 = o[2], l1 = o[3];
+                    o[0] = recon_pixel<BPP>(m1, m2, m3, m4, x[0], l0, up[0], up2);
+                    o[1] = recon_pixel<BPP>(m1, m2, m3, m4, x[1], l1, up[1], up3);
+                    o[2] = recon_pixel<BPP>(m1, m2, m3, m4, x[2], o[0], up[2], up[0]);
+                    o[3] = recon_pixel<BPP>(m1, m2, m3, m4, x[3], o[1], up[3], up[1]);
+                } else {
+                    uint32_t left = o[3], ul = up3;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    o[k] = recon_pixel<BPP>(m1, m2, m3, m4, x[k], left, up[k], ul);
-                    left = o[k];
-                    ul = up[k];
+                    for (int k = 0; k < 4; ++k) {
+                        o[k] = recon_pixel<BPP>(m1, m2, m3, m4, x[k], left, up[k], ul);
+                        left = o[k];
+                        ul = up[k];
+                    }
                 }
+                up2 = up[2];
                 up3 = up[3];
                 // the reconstructed bytes, in stream order
                 uint32_t ow[kWords];
@@ -495,7 +509,32 @@ __global__ __launch_bounds__(64) void ke_png_unfilter(const KePngDev *__restrict
                 } else {
                     ow[0] = o[0] | (o[1] << 8) | (o[2] << 16) | (o[3] << 24);
                 }
-                if (ADAM7) {
+                if (WIDE) {
+                    // two pixels per group, 8 bits per sample leave; with or without interlacing (geo: the whole image then)
+                    constexpr int kOut = BPP == 1 ? 1 : BPP == 3 ? 3 : 4;
+                    uint8_t *wp = dst + (size_t)(geo.y0 + row * geo.dy) * d.info.width * kOut;
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        if (2 * q < valid) {
+                            uint32_t s[2 * BPP];                  // the pixel's bytes in stream order
+#pragma unroll
+                            for (int e = 0; e < 2 * BPP; ++e) {
+                                const int at = q * 2 * BPP + e;
+                                s[e] = (ow[(at >> 2) % kWords] >> (8 * (at & 3))) & 255u;
+                            }
+                            uint8_t *pp = wp + (size_t)(geo.x0 + (2 * g + q) * geo.dx) * kOut;
+                            if (BPP == 1) {
+                                pp[0] = (uint8_t)(s[0] ? 255u : s[1]);
+                            } else if (BPP == 3) {
+                                pp[0] = (uint8_t)s[0]; pp[1] = (uint8_t)s[2 % (2 * BPP)]; pp[2] = (uint8_t)s[4 % (2 * BPP)];
+                            } else {
+                                const uint32_t v = BPP == 2 ? s[0] * 0x010101u | (s[2 % (2 * BPP)] << 24)
+                                                            : s[0] | (s[2 % (2 * BPP)] << 8) | (s[4 % (2 * BPP)] << 16) | (s[6 % (2 * BPP)] << 24);
+                                __builtin_memcpy(pp, &v, 4);
+                            }
+                        }
+                    }
+                } else if (ADAM7) {
                     // the pass's pixels go to (x0 + k dx, y0 + row dy) of the whole image, one at a time
                     const int px = d.info.width;
                     uint8_t *wp = dst + (size_t)(geo.y0 + row * geo.dy) * px * (MAPPED || BPP == 2 ? 1 : BPP);
@@ -748,22 +787,25 @@ KE_API int ke_png_decode(ke_ctx *ctx, const uint8_t *files, const uint64_t *offs
                            (const uint2 *)d_rec, (const int32_t *)d_status, (const uint32_t *)d_nrec);
         const size_t row_lds = (size_t)max_groups * 16;
         // one launch per kind present in the sub-batch (a workgroup whose image is of another kind returns at once)
-        bool kinds[10] = {};
+        // kinds: (bytes per filter unit -- per half of one for 16-bit files --, or palette / sub-byte) x interlaced x 16-bit
+        bool kinds[20] = {};
         for (const KePngDev &d : devs)
-            kinds[(d.info.mapped ? 3 : d.info.fbpp == 2 ? 4 : d.info.channels == 1 ? 0 : d.info.channels == 3 ? 1 : 2) + (d.info.interlace ? 5 : 0)] = true;
-#define KE_UNFILTER(BPP, MAPPED, ADAM7)                                                                                                    \
-    hipLaunchKernelGGL((ke_png_unfilter<BPP, MAPPED, ADAM7>), dim3((unsigned)m), dim3(64), row_lds, ctx->stream, (const KePngDev *)d_imgs,  \
-                       (const uint8_t *)d_raw, pixels_out, (int32_t *)d_status, (const uint32_t *)d_adler)
-        if (kinds[0]) KE_UNFILTER(1, false, false);
-        if (kinds[1]) KE_UNFILTER(3, false, false);
-        if (kinds[2]) KE_UNFILTER(4, false, false);
-        if (kinds[3]) KE_UNFILTER(1, true, false);
-        if (kinds[4]) KE_UNFILTER(2, false, false);
-        if (kinds[5]) KE_UNFILTER(1, false, true);
-        if (kinds[6]) KE_UNFILTER(3, false, true);
-        if (kinds[7]) KE_UNFILTER(4, false, true);
-        if (kinds[8]) KE_UNFILTER(1, true, true);
-        if (kinds[9]) KE_UNFILTER(2, false, true);
+            kinds[(d.info.mapped ? 4 : d.info.fbpp - 1) + (d.info.interlace ? 5 : 0) + (d.info.depth == 16 ? 10 : 0)] = true;
+#define KE_UNFILTER(BPP, MAPPED, ADAM7, WIDE)                                                                                       \
+    hipLaunchKernelGGL((ke_png_unfilter<BPP, MAPPED, ADAM7, WIDE>), dim3((unsigned)m), dim3(64), row_lds, ctx->stream,              \
+                       (const KePngDev *)d_imgs, (const uint8_t *)d_raw, pixels_out, (int32_t *)d_status, (const uint32_t *)d_adler)
+#define KE_UNFILTER_KINDS(AT, ADAM7, WIDE)                \
+    if (kinds[AT + 0]) KE_UNFILTER(1, false, ADAM7, WIDE); \
+    if (kinds[AT + 1]) KE_UNFILTER(2, false, ADAM7, WIDE); \
+    if (kinds[AT + 2]) KE_UNFILTER(3, false, ADAM7, WIDE); \
+    if (kinds[AT + 3]) KE_UNFILTER(4, false, ADAM7, WIDE)
+        KE_UNFILTER_KINDS(0, false, false);
+        if (kinds[4]) KE_UNFILTER(1, true, false, false);
+        KE_UNFILTER_KINDS(5, true, false);
+        if (kinds[9]) KE_UNFILTER(1, true, true, false);
+        KE_UNFILTER_KINDS(10, false, true);
+        KE_UNFILTER_KINDS(15, true, true);
+#undef KE_UNFILTER_KINDS
 #undef KE_UNFILTER
         KE_HIP(ctx, hipGetLastError());
         st.resize((size_t)m);

@@ -2,8 +2,7 @@
 // Pillow (oracle/keyes_png_cpu.cpp): zlib/deflate decompression (RFC 1950 / 1951) of the concatenated IDAT data and the five
 // scanline filters of the PNG specification (None, Sub, Up, Average, Paeth).  Lossless, so "the pixels Pillow yields" is a
 // matter of following the two specifications; what is decoded is what `Image.open(path)` hands the reference's batch hasher
-// (src/core/fastsig.py:31-34) for 8-bit grayscale, RGB and RGBA files, interlaced (Adam7) or not.  16-bit files are refused by
-// the parser and stay with Pillow.  Palette files and grayscale files of 1 / 2 / 4 bits are
+// (src/core/fastsig.py:31-34) for grayscale, RGB and RGBA files of 8 or 16 bits, interlaced (Adam7) or not.  Palette files and grayscale files of 1 / 2 / 4 bits are
 // decoded to the luma Pillow's `convert("L")` makes of them -- which is what the reference's hashes see (src/sig/phash.py:25):
 // samples unpacked most significant bits first, mapped through a 256-entry table (palette entry -> L by ImagingConvert's
 // rounded 16-bit weights; 1 / 2 / 4-bit gray scaled to 0..255).
@@ -36,7 +35,8 @@ struct KePngInfo {
     int32_t width, height, channels;     // channels of the decoded pixels: 1 (L), 3 (RGB), 4 (RGBA)
     uint32_t zoff, zlen;                 // the zlib stream (all IDAT payloads, concatenated) inside the staged stream bytes
     int32_t row_bytes;                   // filtered bytes per scanline (without the filter-type byte)
-    int32_t depth;                       // bits per sample in the file: 8, or 1 / 2 / 4 for the mapped kinds below
+    int32_t depth;                       // bits per sample in the file: 8, 1 / 2 / 4 for the mapped kinds below, or 16 -- then
+                                         // the filters' unit is 2 * fbpp bytes and the pixels that leave are 8-bit (ke_png_parse.h)
     int32_t mapped;                      // palette files and grayscale below 8 bits: samples are indices into `lut`, the
     uint8_t lut[256];                    // luma Pillow's convert("L") gives each of them (the reference hashes that)
     int32_t fbpp;                        // bytes per pixel in the file = the filters' unit: `channels`, except gray + alpha (2):

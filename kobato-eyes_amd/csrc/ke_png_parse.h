@@ -2,7 +2,7 @@
 // signature, IHDR, where the IDAT payloads lie (their concatenation is one zlib stream per image), IEND; chunk CRCs are
 // verified where Pillow's ChunkStream verifies them (a damaged file raises there and the reference drops it,
 // src/core/fastsig.py:36-37).  8-bit grayscale, RGB
-// and RGBA are taken, interlaced (Adam7) or not; 16-bit files are KE_PNG_UNSUPPORTED and stay with Pillow (palette / sub-byte
+// and RGBA are taken, interlaced (Adam7) or not, and 16-bit files as the 8-bit pixels Pillow opens them to (palette / sub-byte
 // gray / gray + alpha files decode to the luma convert("L") gives them).
 #pragma once
 
@@ -75,7 +75,12 @@ static inline void ke_parse_png(const uint8_t *p, size_t size, std::vector<KePng
             info.channels = (ctype == 0 || ctype == 3 || ctype == 4) ? 1 : ctype == 2 ? 3 : ctype == 6 ? 4 : 0;
             info.fbpp = ctype == 4 ? 2 : info.channels;
             const bool sub8 = (ctype == 0 || ctype == 3) && (depth == 1 || depth == 2 || depth == 4);
-            if (!(depth == 8 || sub8) || info.channels == 0 || lace > 1 || info.width > KE_PNG_MAX_WIDTH ||
+            // 16 bits per sample (not for palettes): Pillow opens such a file to 8-bit pixels -- RGB / RGBA from the samples' high
+            // bytes (raw modes "RGB;16B", "RGBA;16B"), gray + alpha to RGBA (L, L, L, A) the same way ("LA;16B"), gray to mode
+            // "I;16", which convert("L") and convert("RGB") clip to 255 (PngImagePlugin._MODES; ImagingConvert I;16 -> L)
+            const bool wide = depth == 16 && ctype != 3;
+            if (wide && ctype == 4) info.channels = 4;
+            if (!(depth == 8 || sub8 || wide) || info.channels == 0 || lace > 1 || info.width > (wide ? KE_PNG_MAX_WIDTH / 2 : KE_PNG_MAX_WIDTH) ||
                 (uint64_t)info.width * info.height > (1ull << 28)) {
                 info.status = KE_PNG_UNSUPPORTED;
                 if (!(depth == 1 || depth == 2 || depth == 4 || depth == 8 || depth == 16) || ctype > 6 || ctype == 1 || ctype == 5 || lace > 1)

@@ -57,8 +57,9 @@ int ko_png_decode(const uint8_t *file, uint64_t size, uint8_t *out) {
     if (raw.size() != want || ke_adler32(raw.data(), raw.size()) != adler) return KE_PNG_CORRUPT;
     // every pass (one for a file without interlacing) is a filtered image of its own: unfilter its rows, then put its samples
     // where they belong -- packed samples unpacked and mapped to luma, gray + alpha reduced to the gray samples
-    const int out_bpp = (info.mapped || info.fbpp != info.channels) ? 1 : info.channels;
-    const int unit = info.mapped ? 1 : info.fbpp;
+    const bool wide = info.depth == 16;                      // 16-bit samples, big-endian: 8-bit pixels leave (ke_png_parse.h)
+    const int out_bpp = wide ? info.channels : (info.mapped || info.fbpp != info.channels) ? 1 : info.channels;
+    const int unit = info.mapped ? 1 : info.fbpp * (wide ? 2 : 1);
     const uint8_t *at = raw.data();
     std::vector<uint8_t> rows;
     for (int pass = 0; pass < (info.interlace ? 7 : 1); ++pass) {
@@ -73,7 +74,12 @@ int ko_png_decode(const uint8_t *file, uint64_t size, uint8_t *out) {
             if (ke_png_unfilter_row(row[0], row + 1, y ? cur - rb : nullptr, cur, rb, unit) != KE_PNG_OK) return KE_PNG_CORRUPT;
             uint8_t *dst = out + ((size_t)(a.y0 + y * a.dy) * info.width + a.x0) * out_bpp;
             for (int x = 0; x < a.w; ++x, dst += (size_t)a.dx * out_bpp) {
-                if (info.mapped) {
+                if (wide) {
+                    const uint8_t *s = cur + (size_t)x * unit;
+                    if (info.fbpp == 1) dst[0] = s[0] ? 255 : s[1];                          // I;16 -> L: clipped
+                    else if (info.fbpp == 2) { dst[0] = dst[1] = dst[2] = s[0]; dst[3] = s[2]; }   // LA;16B -> RGBA
+                    else for (int c = 0; c < out_bpp; ++c) dst[c] = s[2 * c];                // the high bytes
+                } else if (info.mapped) {
                     const int bit = x * info.depth;
                     dst[0] = info.lut[(cur[bit >> 3] >> (8 - info.depth - (bit & 7))) & ((1u << info.depth) - 1u)];
                 } else if (out_bpp == 1) {

@@ -1,6 +1,6 @@
 """PNG files for the decoder tests, made with the installed Pillow: what the GPU decoder takes (8-bit L / RGB / RGBA, every
-compression level incl. stored blocks and optimised encoding, sizes from 1x1; palette, sub-byte, gray+alpha and Adam7 files)
-and what it hands back (16-bit, truncated, damaged)."""
+compression level incl. stored blocks and optimised encoding, sizes from 1x1; palette, sub-byte, gray+alpha, Adam7 and 16-bit files)
+and what it hands back (truncated, damaged, beyond its limits)."""
 from __future__ import annotations
 
 import io
@@ -224,6 +224,30 @@ def interlaced(full: bool = False):
                 yield f"adam7_c{ctype}_d{depth}_{w}x{h}", data, ref
 
 
+def wide(full: bool = False):
+    """Yields (name, file bytes, what Pillow opens the file to -- for grayscale what convert("L") makes of its mode "I;16"):
+    16-bit files of every colour type, with and without interlacing, every filter type (unit: 2 bytes per sample), samples
+    with independent high and low bytes."""
+    rng = np.random.default_rng(15)
+    sizes = [(1, 1), (2, 3), (5, 4), (9, 17), (64, 48), (131, 67)] + ([(640, 333), (3, 900), (1030, 40)] if full else [])
+    for (w, h) in sizes:
+        for ctype, chans in ((0, 1), (2, 3), (4, 2), (6, 4)):
+            a = rng.integers(0, 256, (h, w, 2 * chans), dtype=np.uint8)        # big-endian samples as bytes
+            if ctype == 0:
+                a[:, :, 0] = np.where(rng.random((h, w)) < 0.7, 0, a[:, :, 0])  # mostly below 256: convert("L") clips the rest
+            if w * h > 3000:                                                    # something deflate finds matches in
+                a[h // 4: h // 2] = a[h // 4]
+            for lace in (0, 1):
+                if lace:
+                    raw = _adam7_stream(a, 8, rng)
+                else:
+                    raw = _filtered(np.ascontiguousarray(a.reshape(h, -1)), 2 * chans, rng.integers(0, 5, h))
+                data = _container2(raw, w, h, ctype, 16, lace, chunk=(1 << 30) if ctype != 6 else 61)
+                with Image.open(io.BytesIO(data)) as im:
+                    ref = np.asarray(im.convert("L") if im.mode == "I;16" else im)
+                yield f"wide_c{ctype}_{w}x{h}_i{lace}", data, ref
+
+
 def refused():
     """Yields (name, file bytes, expected status): 1 = left to Pillow, 2 = damaged."""
     rng = np.random.default_rng(4)
@@ -234,9 +258,9 @@ def refused():
     cut = pal.index(b"PLTE") - 4
     n = struct.unpack(">I", pal[cut:cut + 4])[0]
     yield "palette_missing", pal[:cut] + pal[cut + 12 + n:], 2
-    b = io.BytesIO()
-    Image.fromarray(rng.integers(0, 65535, (20, 30)).astype(np.uint16)).save(b, "PNG")
-    yield "16bit", b.getvalue(), 1
+    rng.integers(0, 65535, (20, 30))                                               # (keeps the stream of random numbers of earlier rounds)
+    yield "16bit_beyond_the_row_limit", _container2(b"".join(b"\x00" + bytes(2 * 9000) for _ in range(2)), 9000, 2, 0, 16, 0), 1
+    yield "16bit_palette", _container2(b"\x00" + bytes(8), 4, 1, 3, 16, 0, plte=bytes(6)), 1
     good = _save(rng.integers(0, 256, (40, 50, 3), dtype=np.uint8))
     yield "bad_adler", good[:-17] + bytes([good[-17] ^ 0x40]) + good[-16:], 2     # last byte of the zlib trailer (IDAT's CRC and the 12 bytes of IEND follow)
     yield "truncated", good[: len(good) // 2], 2

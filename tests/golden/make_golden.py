@@ -820,6 +820,23 @@ def make_refine_turned():
     alpha = rng.integers(0, 256, base.shape[:2], dtype=np.uint8)
     put("rgba.png", Image.fromarray(np.dstack([near, alpha]), "RGBA"), "PNG")
     put("la.png", Image.fromarray(np.dstack([np.asarray(Image.fromarray(near).convert("L")), alpha]), "LA"), "PNG")
+    # 16-bit and Adam7 PNG files (no writer for them in Pillow: filter type 0 rows in a hand-made container): samples with the
+    # picture in the high byte and noise in the low one; 16-bit grayscale dark enough that only some samples pass 255
+    low = rng.integers(0, 256, base.shape, dtype=np.uint8)
+
+    def be16(hi, lo):
+        return np.stack([hi, lo], -1).reshape(hi.shape[0], hi.shape[1], -1)          # H x W x 2C bytes, big-endian samples
+
+    def rows0(a):
+        return b"".join(b"\x00" + np.ascontiguousarray(r).tobytes() for r in a)
+
+    h_, w_ = base.shape[:2]
+    files.append(("rgb16.png", _png_chunks(w_, h_, 16, 2, 0, rows0(be16(near, low)))))
+    g8 = np.asarray(Image.fromarray(near).convert("L"))
+    files.append(("gray16.png", _png_chunks(w_, h_, 16, 0, 0, rows0(be16((g8 > 200).astype(np.uint8)[:, :, None], g8[:, :, None])))))
+    files.append(("la16.png", _png_chunks(w_, h_, 16, 4, 0, rows0(be16(np.dstack([g8, alpha]), low[:, :, :2])))))
+    files.append(("rgba16_adam7.png", _png_chunks(w_, h_, 16, 6, 1, _adam7_rows(be16(np.dstack([near, alpha]), np.dstack([low, alpha]))))))
+    files.append(("rgb_adam7.png", _png_chunks(w_, h_, 8, 2, 1, _adam7_rows(near))))
     out = {"names": [n for n, _ in files], "cases": {}, "clusters": []}
     store = {"names": np.array(out["names"])}
     for k, (_, data) in enumerate(files):
@@ -836,10 +853,12 @@ def make_refine_turned():
                                   "thumb128_sha256": sha(thumbs[name]), "thumb32_sha256": sha(R._load_small_gray(p, 32))}
         out["mae"] = [[a, b, R._mae01(thumbs[a], thumbs[b])] for a, b in
                       [("upright.jpg", "turned1.jpg"), ("upright.jpg", "turned6.jpg"), ("turned3.jpg", "turned8.jpg"), ("upright.jpg", "rgba.png"),
-                       ("rgba.png", "la.png"), ("upright.jpg", "other.jpg")]]
+                       ("rgba.png", "la.png"), ("upright.jpg", "other.jpg"), ("rgba.png", "rgb16.png"), ("la.png", "la16.png"),
+                       ("rgba.png", "rgba16_adam7.png"), ("rgb_adam7.png", "rgb16.png"), ("la.png", "gray16.png")]]
         ids = {n: k + 1 for k, n in enumerate(paths)}
         groups = [(["upright.jpg"] + [f"turned{o}.jpg" for o in range(1, 9)], "upright.jpg"), (["rgba.png", "la.png", "other.jpg"], "rgba.png"),
-                  (["turned5.jpg", "other.jpg", "turned2.jpg"], "turned5.jpg")]
+                  (["turned5.jpg", "other.jpg", "turned2.jpg"], "turned5.jpg"),
+                  (["rgb16.png", "rgb_adam7.png", "rgba16_adam7.png", "la16.png", "gray16.png", "other.jpg"], "rgb16.png")]
         clusters = [Cl([E(F(ids[n], paths[n])) for n in members], ids[keeper]) for members, keeper in groups]
         out["cluster_inputs"] = [{"members": m, "keeper": k} for m, k in groups]
         for max_bits in (4, 400, 1024):

@@ -135,9 +135,11 @@ def test_fast_fill_takes_the_gpu_route_for_jpeg_files(tmp_path, monkeypatch):
 
 
 def test_png_decode_matches_pillow_in_one_mixed_batch(ctx):
-    """ke_png_decode: 8-bit L / RGB / RGBA files of every compression level in one call -- stored, fixed and dynamic deflate
-    blocks, all five filters -- equal to Pillow's pixels; palette / 16-bit / gray+alpha / damaged files reported per file."""
-    cases = list(P.supported(full=True)) + list(P.handmade(full=True)) + list(P.mapped(full=True)) + list(P.interlaced(full=True))
+    """ke_png_decode: files of every kind (8-bit L / RGB / RGBA / LA, palette and sub-byte, Adam7, 16-bit) and every compression
+    level in one call -- stored, fixed and dynamic deflate blocks, all five filters -- equal to what Pillow opens them to;
+    damaged files and files beyond the decoder's limits reported per file."""
+    cases = list(P.supported(full=True)) + list(P.handmade(full=True)) + list(P.mapped(full=True)) + list(P.interlaced(full=True)) + \
+        list(P.wide(full=True))
     refused = list(P.refused())
     blobs = [c[1] for c in cases] + [r[1] for r in refused]
     out, status = ctx.png_decode(blobs)

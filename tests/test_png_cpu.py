@@ -35,7 +35,7 @@ def _decode(L, data: bytes):
 def test_decoder_arithmetic_matches_pillow():
     L = _lib()
     n = 0
-    for name, data, ref in list(P.supported()) + list(P.handmade()) + list(P.mapped()) + list(P.interlaced()):
+    for name, data, ref in list(P.supported()) + list(P.handmade()) + list(P.mapped()) + list(P.interlaced()) + list(P.wide()):
         st, out = _decode(L, data)
         assert st == 0, name
         assert out.shape == ref.shape and np.array_equal(out, ref), name

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The batch-hasher seam end to end (`fast_fill_missing_signatures`, the drop-in for src/core/fastsig.py:102-126): N image files
 on disk -> signatures rows in SQLite.  Two runs of the same call: JPEG / PNG files decoded on the GPU (the default), and with
-`KE_GPU_JPEG=0 KE_GPU_PNG=0` (Pillow on the thread pool, pixels through the pinned staging buffers -- the route every other
+`KE_GPU_JPEG=0 KE_GPU_PNG=0 KE_GPU_BMP=0` (Pillow on the thread pool, pixels through the pinned staging buffers -- the route every other
 format takes); both hash on the GPU.
     python benchmarks/bench_fastsig.py [--images 16384 --format jpeg|png|mixed --content corpus|drawing]
 One JSON line."""
@@ -80,7 +80,7 @@ def main():
         with sqlite3.connect(db) as conn:
             assert conn.execute("SELECT COUNT(*) FROM signatures").fetchone()[0] == args.images
         sample = items[: args.pillow_sample]
-        os.environ["KE_GPU_JPEG"] = os.environ["KE_GPU_PNG"] = "0"
+        os.environ["KE_GPU_JPEG"] = os.environ["KE_GPU_PNG"] = os.environ["KE_GPU_BMP"] = "0"
         fastsig.fast_fill_missing_signatures(db, sample[:256], apply_to_db=False)
         t0 = time.perf_counter()
         rows_cpu = fastsig.fast_fill_missing_signatures(db, sample, apply_to_db=False)

@@ -195,6 +195,21 @@ int ke_png_probe(const uint8_t *files, const uint64_t *offsets, const uint64_t *
 int ke_png_decode(ke_ctx *ctx, const uint8_t *files, const uint64_t *offsets, const uint64_t *sizes, int64_t n,
                   uint8_t *pixels_out, const uint64_t *out_offsets, int32_t *status_out);
 
+/* ---- BMP files unpacked on the GPU: the same step for the uncompressed files Pillow's BmpImagePlugin opens with its "raw"
+ * decoder (src/dup/scanner.py:16-28 ranks the format among the keepers): 24-bit BGR and 32-bit BGRX as RGB, the 32-bit
+ * BITFIELDS layouts the plugin lists (byte permutations; RGBA where one of them is alpha), 8-bit palette files as the luma
+ * `convert("L")` makes of them -- what the reference's hashes see (src/sig/phash.py:25) -- with channels = 1.  The header is
+ * read as BmpImageFile._bitmap reads it (defaults for the colour count and the data offset, padded bottom-up rows unless the
+ * height's top byte is 0xFF); the files go to the device as they are and one kernel writes packed top-down rows.  OS/2
+ * headers, RLE, 1 / 4 / 16 bits, other masks: KE_JPEG_UNSUPPORTED_ (1) per file; pixel data that ends early:
+ * KE_JPEG_CORRUPT_ (2) (Pillow: "image file is truncated").  Arguments and conventions as ke_jpeg_probe / ke_jpeg_decode;
+ * channels is 1, 3 or 4.  ke_bmp_caveats reports no flags (the format has no orientation tag; alpha shows as channels = 4). */
+int ke_bmp_probe(const uint8_t *files, const uint64_t *offsets, const uint64_t *sizes, int64_t n, int32_t *widths,
+                 int32_t *heights, int32_t *channels, int32_t *status_out);
+int ke_bmp_decode(ke_ctx *ctx, const uint8_t *files, const uint64_t *offsets, const uint64_t *sizes, int64_t n,
+                  uint8_t *pixels_out, const uint64_t *out_offsets, int32_t *status_out);
+int ke_bmp_caveats(const uint8_t *files, const uint64_t *offsets, const uint64_t *sizes, int64_t n, int32_t *flags_out);
+
 /* What `Image.open` alone does not tell about a file but the reference's defensive loader acts on (src/utils/image_io.py:60-138:
  * EXIF orientation applied, alpha composited over white): per file a set of KE_CAVEAT_* bits, so that a caller who wants that
  * loader's pixels sends flagged files through it and only the rest through ke_jpeg_decode / ke_png_decode.  ORIENTATION: the

@@ -116,6 +116,8 @@ def _read_pixels(path_text: str, room: Optional[int] = None):
 
 JPEG_SUFFIXES = (".jpg", ".jpeg", ".jpe", ".jfif")
 PNG_SUFFIXES = (".png",)
+BMP_SUFFIXES = (".bmp",)
+GPU_KINDS = ("jpeg", "png", "bmp")           # the order in which a batch's files lie in the read-ahead buffer
 
 
 def _read_bytes(path_text: str):
@@ -398,25 +400,30 @@ class _Pipeline:
 
     # ---- the GPU decoders' share of a batch
     def _start_reads(self, start: int) -> dict:
-        """The JPEG / PNG files of the batch that begins at ``start``, on their way into memory while the batch before is on
-        the GPU.  Runs on a pool thread (the classification is a pass of the interpreter over the batch, the reading is the
-        library's): {"jpeg" / "png": positions (arrays, ascending), "blobs": position -> future of the file's bytes for a
-        stage without ``hash_files``, "ahead": the context's FilesAhead holding [JPEG files | PNG files] or None}."""
+        """The JPEG / PNG / BMP files of the batch that begins at ``start``, on their way into memory while the batch before is
+        on the GPU.  Runs on a pool thread (the classification is a pass of the interpreter over the batch, the reading is the
+        library's): {"jpeg" / "png" / "bmp": positions (arrays, ascending), "blobs": position -> future of the file's bytes for
+        a stage without ``hash_files``, "ahead": the context's FilesAhead holding [JPEG | PNG | BMP files] or None}."""
         gpu_jpeg = os.environ.get("KE_GPU_JPEG", "1") != "0"
         gpu_png = os.environ.get("KE_GPU_PNG", "1") != "0"
+        gpu_bmp = os.environ.get("KE_GPU_BMP", "1") != "0"
         by_path = hasattr(self.stage, "hash_files")          # the library reads the files itself, into page-locked memory
         stop = min(start + self.batch, len(self.tasks))
         tails = [p[-5:].lower() for p in self.paths[start:stop]]
-        kind = np.fromiter((1 if t.endswith(JPEG_SUFFIXES) else 2 if t.endswith(PNG_SUFFIXES) else 0 for t in tails), np.int8, stop - start)
+        kind = np.fromiter((1 if t.endswith(JPEG_SUFFIXES) else 2 if t.endswith(PNG_SUFFIXES) else 3 if t.endswith(BMP_SUFFIXES) else 0
+                            for t in tails), np.int8, stop - start)
         jpeg = start + np.nonzero(kind == 1)[0] if gpu_jpeg else np.zeros(0, np.int64)
         png = start + np.nonzero(kind == 2)[0] if gpu_png else np.zeros(0, np.int64)
-        reads = {"jpeg": jpeg, "png": png, "blobs": {}, "ahead": None}
+        bmp = start + np.nonzero(kind == 3)[0] if gpu_bmp else np.zeros(0, np.int64)
+        reads = {"jpeg": jpeg, "png": png, "bmp": bmp, "blobs": {}, "ahead": None}
+        order = np.concatenate([reads[k] for k in GPU_KINDS]).tolist()
         if not by_path:
-            reads["blobs"] = {int(k): self.pool.submit(_read_bytes, self.paths[k]) for k in np.concatenate([jpeg, png]).tolist()}
-        elif len(jpeg) + len(png) and hasattr(self.stage, "read_ahead") and os.environ.get("KE_READ_AHEAD", "1") != "0":
-            order = np.concatenate([jpeg, png]).tolist()
+            reads["blobs"] = {int(k): self.pool.submit(_read_bytes, self.paths[k]) for k in order}
+        elif order and hasattr(self.stage, "read_ahead") and os.environ.get("KE_READ_AHEAD", "1") != "0":
+            ends = np.cumsum([len(reads[k]) for k in GPU_KINDS]).tolist()
             try:
-                reads["ahead"] = self.stage.read_ahead([self.paths[k] for k in order], (("jpeg", 0, len(jpeg)), ("png", len(jpeg), len(order))))
+                reads["ahead"] = self.stage.read_ahead([self.paths[k] for k in order],
+                                                       tuple((k, e - len(reads[k]), e) for k, e in zip(GPU_KINDS, ends)))
             except Exception:
                 reads["ahead"] = None                      # the decode call reads the files itself
         return reads
@@ -466,7 +473,7 @@ class _Pipeline:
         refused: list = []
         first = 0
         try:
-            for kind in ("jpeg", "png"):
+            for kind in GPU_KINDS:
                 positions = reads[kind]
                 if len(positions) == 0:
                     continue
@@ -676,8 +683,8 @@ class _Pipeline:
                 ph, dh = np.zeros(stop - start, np.int64), np.zeros(stop - start, np.int64)
                 ok = np.zeros(stop - start, bool)
                 taken = np.zeros(stop - start, bool)
-                taken[reads["jpeg"] - start] = True
-                taken[reads["png"] - start] = True
+                for k in GPU_KINDS:
+                    taken[reads[k] - start] = True
                 png_skip = None
                 if reads["ahead"] is not None and len(reads["png"]):
                     png_skip = self._png_for_pillow(reads["ahead"], len(reads["jpeg"]), len(reads["jpeg"]) + len(reads["png"]))

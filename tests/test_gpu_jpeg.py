@@ -9,6 +9,7 @@ import pytest
 
 import _jpeg_cases as J
 import _png_cases as P
+import _bmp_cases as B
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -153,6 +154,44 @@ def test_png_decode_matches_pillow_in_one_mixed_batch(ctx):
     refs = [c[2] for c in cases if min(c[2].shape[:2]) >= 16][:60]
     for k, ref in enumerate(refs):
         assert st[k] == 0 and (int(ph[k]), int(dh[k])) == O.hash_image(ref), k
+
+
+def test_bmp_unpack_matches_pillow_in_one_mixed_batch(ctx):
+    """ke_bmp_decode: 24-bit, 32-bit (BGRX and every BITFIELDS layout Pillow lists), 8-bit palette and gray files, bottom-up
+    and top-down, every header size, data offsets with gaps -- equal to what the reference's hashes see of them through
+    Pillow; RLE / 1 / 4 / 16-bit / OS/2 files and truncated ones reported per file; header damage never decoded differently."""
+    import test_bmp_cpu as TB
+
+    cases = [c for c in list(B.supported(full=True)) + list(B.handmade(full=True))]
+    refused = list(B.refused())
+    blobs = [c[1] for c in cases] + [r[1] for r in refused]
+    out, status = ctx.bmp_decode(blobs)
+    taken = 0
+    for k, (name, _, ref) in enumerate(cases):
+        if ref is None:
+            assert status[k] != 0 and out[k] is None, name
+            continue
+        assert status[k] == 0, name
+        assert out[k].shape == ref.shape and np.array_equal(out[k], ref), name
+        taken += 1
+    for k, (name, _, expected) in enumerate(refused, len(cases)):
+        assert status[k] == expected and out[k] is None, name
+    assert taken > 150
+    big = [c for c in cases if c[2] is not None and min(c[2].shape[:2]) >= 16]
+    ph, dh, st = ctx.bmp_hash([c[1] for c in big])
+    for k, c in enumerate(big):
+        assert st[k] == 0 and (int(ph[k]), int(dh[k])) == O.hash_image(c[2]), c[0]
+    rng = np.random.default_rng(32)
+    pool = [c for c in cases if c[2] is not None and c[2].shape[0] <= 80]
+    damaged = list(TB.damaged(rng, pool, 12))
+    out, status = ctx.bmp_decode([d for _, d in damaged])
+    decoded = 0
+    for (name, data), px, st in zip(damaged, out, status):
+        if st == 0:
+            decoded += 1
+            ref = TB.strict_pillow(data)
+            assert ref is not None and ref.shape == px.shape and np.array_equal(ref, px), name
+    assert decoded > 100
 
 
 def test_png_damage_is_reported_not_decoded(ctx):

@@ -837,6 +837,11 @@ def make_refine_turned():
     files.append(("la16.png", _png_chunks(w_, h_, 16, 4, 0, rows0(be16(np.dstack([g8, alpha]), low[:, :, :2])))))
     files.append(("rgba16_adam7.png", _png_chunks(w_, h_, 16, 6, 1, _adam7_rows(be16(np.dstack([near, alpha]), np.dstack([low, alpha]))))))
     files.append(("rgb_adam7.png", _png_chunks(w_, h_, 8, 2, 1, _adam7_rows(near))))
+    # BMP as Pillow's writer makes it: 24-bit, 32-bit (read back as RGB), 8-bit palette, 8-bit gray
+    put("rgb.bmp", Image.fromarray(near), "BMP")
+    put("rgbx.bmp", Image.fromarray(np.dstack([near, alpha]), "RGBA"), "BMP")
+    put("pal.bmp", Image.fromarray(near).quantize(200), "BMP")
+    put("gray.bmp", Image.fromarray(g8), "BMP")
     out = {"names": [n for n, _ in files], "cases": {}, "clusters": []}
     store = {"names": np.array(out["names"])}
     for k, (_, data) in enumerate(files):
@@ -854,11 +859,13 @@ def make_refine_turned():
         out["mae"] = [[a, b, R._mae01(thumbs[a], thumbs[b])] for a, b in
                       [("upright.jpg", "turned1.jpg"), ("upright.jpg", "turned6.jpg"), ("turned3.jpg", "turned8.jpg"), ("upright.jpg", "rgba.png"),
                        ("rgba.png", "la.png"), ("upright.jpg", "other.jpg"), ("rgba.png", "rgb16.png"), ("la.png", "la16.png"),
-                       ("rgba.png", "rgba16_adam7.png"), ("rgb_adam7.png", "rgb16.png"), ("la.png", "gray16.png")]]
+                       ("rgba.png", "rgba16_adam7.png"), ("rgb_adam7.png", "rgb16.png"), ("la.png", "gray16.png"), ("rgba.png", "rgb.bmp"),
+                       ("rgb.bmp", "rgbx.bmp"), ("rgb.bmp", "pal.bmp"), ("la.png", "gray.bmp")]]
         ids = {n: k + 1 for k, n in enumerate(paths)}
         groups = [(["upright.jpg"] + [f"turned{o}.jpg" for o in range(1, 9)], "upright.jpg"), (["rgba.png", "la.png", "other.jpg"], "rgba.png"),
                   (["turned5.jpg", "other.jpg", "turned2.jpg"], "turned5.jpg"),
-                  (["rgb16.png", "rgb_adam7.png", "rgba16_adam7.png", "la16.png", "gray16.png", "other.jpg"], "rgb16.png")]
+                  (["rgb16.png", "rgb_adam7.png", "rgba16_adam7.png", "la16.png", "gray16.png", "other.jpg"], "rgb16.png"),
+                  (["rgb.bmp", "rgbx.bmp", "pal.bmp", "gray.bmp", "upright.jpg", "other.jpg"], "rgb.bmp")]
         clusters = [Cl([E(F(ids[n], paths[n])) for n in members], ids[keeper]) for members, keeper in groups]
         out["cluster_inputs"] = [{"members": m, "keeper": k} for m, k in groups]
         for max_bits in (4, 400, 1024):

@@ -269,16 +269,33 @@ def test_refine_pairs_decodes_on_the_gpu_only_what_the_loader_leaves_alone(K, tm
     alpha[:8] = 0
     alpha[8:16] = 255
     put(20, "alpha_any.png", Image.fromarray(np.dstack([noisy, alpha]), "RGBA"))
+    # the kinds added in round 3: BMP (RGB as it is, an alpha layout over white, a palette file through the loader), 16-bit and
+    # Adam7 PNG (no writer in Pillow: hand-made containers)
+    import _bmp_cases as B
+    import _png_cases as P
+
+    put(21, "d.bmp", Image.fromarray(noisy))
+    files[22] = tmp_path / "alpha.bmp"
+    files[22].write_bytes(B.bmp(320, 240, 32, B._rows(np.dstack([noisy[:, :, ::-1], alpha])), hs=124, comp=3, masks=(0xFF0000, 0xFF00, 0xFF, 0xFF000000)))
+    put(23, "pal.bmp", pal)
+    wide16 = np.stack([noisy, rng.integers(0, 256, noisy.shape, dtype=np.uint8)], -1).reshape(240, 320, 6)
+    files[24] = tmp_path / "rgb16.png"
+    files[24].write_bytes(P._container2(P._filtered(np.ascontiguousarray(wide16.reshape(240, -1)), 6, rng.integers(0, 5, 240)), 320, 240, 2, 16, 0))
+    files[25] = tmp_path / "rgba_adam7.png"
+    files[25].write_bytes(P._container2(P._adam7_stream(np.dstack([noisy, alpha]), 8, rng), 320, 240, 6, 8, 1))
     pairs = [(a, b, files[a], files[b]) for a, b in [(0, 1), (0, 2), (1, 2), (0, 3), (3, 2), (0, 4), (4, 2), (0, 5), (5, 1), (6, 0), (7, 2),
                                                       (6, 7), (8, 0), (8, 8), (9, 0), (9, 2), (12, 0), (13, 1), (14, 0), (15, 3), (17, 3),
-                                                      (18, 15), (20, 4), (20, 2)]]
+                                                      (18, 15), (20, 4), (20, 2), (21, 2), (22, 20), (23, 7), (24, 2), (25, 20), (21, 0)]]
     th = K.RefinementThresholds(ssim=0.8)
     one_by_one = [K.refine_pair(a, b, pa, pb, thresholds=th) for a, b, pa, pb in pairs]
     stats = {}
     assert K.refine_pairs(pairs, thresholds=th, stats=stats) == one_by_one
-    # a.jpg, b.jpg, c.png, upright.jpg as they are; rotated.jpg, the six turned*.jpg, alpha.png and alpha_any.png normalised
-    # on the device; gray, palette and the 4100-pixel-wide file go through the loader
-    assert stats["decodes"] == 17 and stats["gpu_decodes"] == 13 and stats["gpu_normalised"] == 9, stats
+    # a.jpg, b.jpg, c.png, upright.jpg, d.bmp, rgb16.png as they are; rotated.jpg, the six turned*.jpg, alpha.png, alpha_any.png,
+    # alpha.bmp and rgba_adam7.png normalised on the device; gray, palette (PNG and BMP) and the 4100-pixel-wide file go through
+    # the loader
+    assert stats["decodes"] == 22 and stats["gpu_decodes"] == 17 and stats["gpu_normalised"] == 11, stats
+    by = {(a, b): m for (a, b, _, _), m in zip(pairs, one_by_one)}
+    assert all(by[k].ssim > 0.999999 for k in ((21, 2), (24, 2), (22, 20), (25, 20)))         # same pixels, other container
     assert any(m.is_duplicate for m in one_by_one) and any(not m.is_duplicate for m in one_by_one)
     os.environ["KE_GPU_REFINE_DECODE"] = "0"
     try:

@@ -228,6 +228,13 @@ int ke_png_caveats(const uint8_t *files, const uint64_t *offsets, const uint64_t
 int ke_normalise_rgb(ke_ctx *ctx, const uint8_t *src, const uint64_t *src_offsets, const int32_t *widths, const int32_t *heights,
                      const int32_t *channels, const int32_t *orientations, int64_t n, uint8_t *dst, const uint64_t *dst_offsets);
 
+/* The loader's shrink for an image with a side over 4096 (src/utils/image_io.py:122-124: img.thumbnail((4096, 4096), LANCZOS)),
+ * likewise on the device: RGB (width x height at src) -> RGB (out_w x out_h at dst), each band through the resampler that serves
+ * the hashes (Pillow's two-pass integer resample, bit-exact); filter as ke_resize_luma_uniform.  The caller computes
+ * (out_w, out_h) as Image.thumbnail does (aspect preserved).  src and dst are device memory. */
+int ke_thumbnail_rgb(ke_ctx *ctx, const uint8_t *src, int32_t width, int32_t height, int32_t out_w, int32_t out_h, int32_t filter,
+                     uint8_t *dst);
+
 /* Debug/parity hook: the resampled luma tiles the hashes are computed from
  * (reference sig.phash._to_grayscale, src/sig/phash.py:21-26).  tile32_out: n*1024 bytes
  * ([y][x]); tile98_out: n*72 bytes (8 rows x 9 columns); either may be NULL. */

@@ -29,7 +29,7 @@ EXPORTS = (
     "ke_band_pairs_after_size",
     "ke_stage_create", "ke_stage_create_shared", "ke_stage_destroy", "ke_stage_acquire", "ke_stage_submit_hash", "ke_stage_wait",
     "ke_comm_unique_id", "ke_comm_create", "ke_comm_destroy", "ke_allgather_u64", "ke_allgather_hashes", "ke_allgather_edges",
-    "ke_interleave_shards", "ke_host_alloc", "ke_host_free", "ke_host_pack", "ke_host_read_files", "ke_jpeg_probe", "ke_jpeg_decode", "ke_png_probe", "ke_png_decode", "ke_jpeg_caveats", "ke_png_caveats", "ke_bmp_probe", "ke_bmp_decode", "ke_bmp_caveats", "ke_normalise_rgb", "ke_cluster_labels", "ke_ssim_pairs_uniform", "ke_ssim_pairs", "ke_ssim_set_mode", "ke_resize_luma_uniform", "ke_fit_luma_uniform", "ke_tile_ahash", "ke_sad_pairs", "ke_synth_rgb",
+    "ke_interleave_shards", "ke_host_alloc", "ke_host_free", "ke_host_pack", "ke_host_read_files", "ke_jpeg_probe", "ke_jpeg_decode", "ke_png_probe", "ke_png_decode", "ke_jpeg_caveats", "ke_png_caveats", "ke_bmp_probe", "ke_bmp_decode", "ke_bmp_caveats", "ke_normalise_rgb", "ke_thumbnail_rgb", "ke_cluster_labels", "ke_ssim_pairs_uniform", "ke_ssim_pairs", "ke_ssim_set_mode", "ke_resize_luma_uniform", "ke_fit_luma_uniform", "ke_tile_ahash", "ke_sad_pairs", "ke_synth_rgb",
     "ke_synth_rgb_indexed",
     "ke_synth_hashes", "ke_last_kernel_ms",
 )
@@ -135,6 +135,7 @@ def load_library() -> C.CDLL:
         lib.ke_bmp_decode.argtypes = [vp, vp, vp, vp, i64, vp, vp, vp]
         lib.ke_bmp_caveats.argtypes = [vp, vp, vp, i64, vp]
         lib.ke_normalise_rgb.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, vp, vp]
+        lib.ke_thumbnail_rgb.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
         lib.ke_band_pairs_after_size.argtypes = [vp, vp, vp, i64, i32, i32, dbl, i64, vp]
         lib.ke_hamming_scan.argtypes = [vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, dbl, i64, vp, i64,
                                         C.POINTER(i64), vp]
@@ -155,7 +156,7 @@ def load_library() -> C.CDLL:
                      "ke_hash_images", "ke_hash_uniform", "ke_hash_images_ex", "ke_hash_uniform_ex", "ke_luma_tiles_uniform", "ke_hamming_scan", "ke_band_pairs_after_size",
                      "ke_stage_create", "ke_stage_create_shared", "ke_stage_destroy", "ke_stage_acquire", "ke_stage_submit_hash", "ke_stage_wait",
                      "ke_comm_unique_id", "ke_comm_create", "ke_comm_destroy", "ke_allgather_u64", "ke_allgather_hashes", "ke_allgather_edges",
-                     "ke_interleave_shards", "ke_host_alloc", "ke_host_free", "ke_host_pack", "ke_host_read_files", "ke_jpeg_probe", "ke_jpeg_decode", "ke_png_probe", "ke_png_decode", "ke_jpeg_caveats", "ke_png_caveats", "ke_bmp_probe", "ke_bmp_decode", "ke_bmp_caveats", "ke_normalise_rgb", "ke_cluster_labels", "ke_ssim_pairs_uniform", "ke_ssim_pairs", "ke_ssim_set_mode", "ke_resize_luma_uniform", "ke_fit_luma_uniform", "ke_tile_ahash",
+                     "ke_interleave_shards", "ke_host_alloc", "ke_host_free", "ke_host_pack", "ke_host_read_files", "ke_jpeg_probe", "ke_jpeg_decode", "ke_png_probe", "ke_png_decode", "ke_jpeg_caveats", "ke_png_caveats", "ke_bmp_probe", "ke_bmp_decode", "ke_bmp_caveats", "ke_normalise_rgb", "ke_thumbnail_rgb", "ke_cluster_labels", "ke_ssim_pairs_uniform", "ke_ssim_pairs", "ke_ssim_set_mode", "ke_resize_luma_uniform", "ke_fit_luma_uniform", "ke_tile_ahash",
                      "ke_sad_pairs", "ke_synth_rgb", "ke_synth_rgb_indexed", "ke_synth_hashes"):
             getattr(lib, name).restype = C.c_int
         _lib = lib
@@ -693,6 +694,30 @@ class Context:
             self.free(dev)
             raise
         return dev, do, ow, oh
+
+    def thumbnail_rgb(self, src: int, width: int, height: int, box: int, filter: int = 0):
+        """An RGB image on the device -> what ``Image.thumbnail((box, box), LANCZOS)`` makes of it, in a device buffer of its own
+        (the caller frees it): (device ptr, width, height).  The size is Image.thumbnail's (aspect preserved, PIL/Image.py
+        ``preserve_aspect_ratio``); ke_thumbnail_rgb resamples each band as Pillow does."""
+        import math
+
+        def round_aspect(number, key):
+            return max(min(math.floor(number), math.ceil(number), key=key), 1)
+
+        x = y = box
+        aspect = width / height
+        if x / y >= aspect:
+            x = round_aspect(y * aspect, key=lambda n: abs(aspect - n / y))
+        else:
+            y = round_aspect(x / aspect, key=lambda n: 0 if n == 0 else abs(aspect - x / n))
+        dev = self.malloc(x * y * 3 + 64)
+        try:
+            with self._lock:
+                self._check(self._lib.ke_thumbnail_rgb(self._h, src, width, height, x, y, filter, dev), "ke_thumbnail_rgb")
+        except Exception:
+            self.free(dev)
+            raise
+        return dev, x, y
 
     def release_decode_buffers(self) -> None:
         """Give back the page-locked packing buffer and the device decode buffer (they are kept between calls otherwise)."""

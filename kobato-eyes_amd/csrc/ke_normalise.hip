@@ -7,6 +7,10 @@
 //     background, then convert("RGB").  Pillow's AlphaComposite.c in integers: with a destination alpha of 255 the two
 //     coefficients are sa * 128 and 255 * 128 - sa * 128, the channel is (c * coef1 + 255 * coef2 + 0x4000) divided by 255
 //     through ((t >> 8) + t) >> 8 and shifted down by 7; a source alpha of 0 leaves the background.
+//   * img.thumbnail((4096, 4096), LANCZOS) for a side over 4096 (src/utils/image_io.py:122-124): Pillow's two-pass resample
+//     works on every band of an RGB image with the arithmetic it uses for a single-band one, so the image is split into three
+//     planes, each goes through the resampler that serves the hashes (ke_launch_resize_group: bit-exact with Pillow's
+//     integer resample), and the three results are interleaved again (ke_thumbnail_rgb).
 // Without this, every phone photograph (they all carry an orientation tag) and every RGBA PNG left the GPU route of the refine
 // stage and was decoded a second time by Pillow on the host.
 #include "ke_internal.h"
@@ -61,7 +65,49 @@ __global__ __launch_bounds__(256) void ke_normalise_kernel(const uint8_t *__rest
     }
 }
 
+// interleaved RGB <-> three planes
+__global__ __launch_bounds__(256) void ke_split_rgb(const uint8_t *__restrict__ src, int64_t pixels, uint8_t *__restrict__ planes) {
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < pixels; e += (int64_t)gridDim.x * 256) {
+        const uint8_t *p = src + 3 * e;
+        planes[e] = p[0];
+        planes[pixels + e] = p[1];
+        planes[2 * pixels + e] = p[2];
+    }
+}
+
+__global__ __launch_bounds__(256) void ke_merge_rgb(const uint8_t *__restrict__ planes, int64_t pixels, uint8_t *__restrict__ dst) {
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < pixels; e += (int64_t)gridDim.x * 256) {
+        uint8_t *q = dst + 3 * e;
+        q[0] = planes[e];
+        q[1] = planes[pixels + e];
+        q[2] = planes[2 * pixels + e];
+    }
+}
+
 }  // namespace
+
+KE_API int ke_thumbnail_rgb(ke_ctx *ctx, const uint8_t *src, int32_t width, int32_t height, int32_t out_w, int32_t out_h, int32_t filter,
+                            uint8_t *dst) {
+    if (!ctx) return KE_EINVAL;
+    if (!src || !dst) return ke_fail(ctx, KE_EINVAL, "NULL argument");
+    if (width <= 0 || height <= 0 || out_w <= 0 || out_h <= 0) return ke_fail(ctx, KE_EINVAL, "sizes must be positive");
+    if (filter != KE_FILTER_LANCZOS && filter != KE_FILTER_BILINEAR && filter != KE_FILTER_BICUBIC)
+        return ke_fail(ctx, KE_EINVAL, "unknown filter %d", filter);
+    if (!ke_is_device_ptr(src) || !ke_is_device_ptr(dst)) return ke_fail(ctx, KE_EINVAL, "src and dst are device memory");
+    KE_HIP(ctx, hipSetDevice(ctx->device));
+    const int64_t in_px = (int64_t)width * height, out_px = (int64_t)out_w * out_h;
+    void *planes_in, *planes_out;
+    KE_TRY(ke_reserve(ctx, KE_BUF_SSIM_AUX, (size_t)(3 * in_px) + 64, &planes_in));
+    KE_TRY(ke_reserve(ctx, KE_BUF_SSIM_IN, (size_t)(3 * out_px) + 64, &planes_out));
+    const unsigned gin = (unsigned)std::min<int64_t>((in_px + 255) / 256, 1 << 16), gout = (unsigned)std::min<int64_t>((out_px + 255) / 256, 1 << 16);
+    hipLaunchKernelGGL(ke_split_rgb, dim3(gin), dim3(256), 0, ctx->stream, src, in_px, (uint8_t *)planes_in);
+    KeHashGroup g{(const uint8_t *)planes_in, nullptr, (uint64_t)in_px, nullptr, 3, width, height, 1};
+    KE_TRY(ke_launch_resize_group(ctx, g, out_w, out_h, filter, (uint8_t *)planes_out, nullptr));
+    hipLaunchKernelGGL(ke_merge_rgb, dim3(gout), dim3(256), 0, ctx->stream, (const uint8_t *)planes_out, out_px, dst);
+    KE_HIP(ctx, hipGetLastError());
+    KE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return KE_OK;
+}
 
 KE_API int ke_normalise_rgb(ke_ctx *ctx, const uint8_t *src, const uint64_t *src_offsets, const int32_t *widths, const int32_t *heights,
                             const int32_t *channels, const int32_t *orientations, int64_t n, uint8_t *dst, const uint64_t *dst_offsets) {

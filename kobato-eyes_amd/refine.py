@@ -145,6 +145,27 @@ def refine_pairs(pairs: Sequence[tuple], *, thresholds: Optional[RefinementThres
                     placed[paths[k]] = (dev2 + int(o2), ww, hh)
                 count["gpu_decodes"] += len(fix)
                 count["gpu_normalised"] = count.get("gpu_normalised", 0) + len(fix)
+            # a side over MAX_SIDE: the loader's img.thumbnail((MAX_SIDE, MAX_SIDE), LANCZOS) (src/utils/image_io.py:122-124), after
+            # the turn.  Below twice that size neither JPEG draft mode nor thumbnail's reducing_gap changes what is resampled
+            # (both act from a factor of two on); larger files and those with an alpha channel stay with the loader.
+            longest = np.maximum(w, h)
+            big = (st == 0) & (c == 3) & (longest > MAX_SIDE) & (longest < 2 * MAX_SIDE - 256)
+            plain = big & ((flags & 3) == 0)
+            turned = big & ((flags & 3) == 1) & (orient >= 2) & (orient <= 8) if kind == "jpeg" else np.zeros(len(paths), bool)
+            for k in np.nonzero(plain | turned)[0].tolist():
+                addr, ww, hh, held = dev + int(off[k]), int(w[k]), int(h[k]), None
+                try:
+                    if turned[k]:
+                        held, o2, w2, h2 = ctx.normalise_rgb(dev, off[k:k + 1], w[k:k + 1], h[k:k + 1], c[k:k + 1], orient[k:k + 1])
+                        addr, ww, hh = held + int(o2[0]), int(w2[0]), int(h2[0])
+                    small, sw, sh = ctx.thumbnail_rgb(addr, ww, hh, MAX_SIDE)
+                finally:
+                    if held is not None:
+                        ctx.free(held)
+                buffers.append(small)
+                placed[paths[k]] = (small, sw, sh)
+                count["gpu_decodes"] += 1
+                count["gpu_shrunk"] = count.get("gpu_shrunk", 0) + 1
 
     def run(chunk: list, placed: dict, arrays: dict, buffers: list) -> None:
         """One ``ke_ssim_pairs`` call for the pairs of this run (the library groups them: one fit launch per (source size,

@@ -283,17 +283,27 @@ def test_refine_pairs_decodes_on_the_gpu_only_what_the_loader_leaves_alone(K, tm
     files[24].write_bytes(P._container2(P._filtered(np.ascontiguousarray(wide16.reshape(240, -1)), 6, rng.integers(0, 5, 240)), 320, 240, 2, 16, 0))
     files[25] = tmp_path / "rgba_adam7.png"
     files[25].write_bytes(P._container2(P._adam7_stream(np.dstack([noisy, alpha]), 8, rng), 320, 240, 6, 8, 1))
+    # a side over 4096: the loader's thumbnail((4096, 4096), LANCZOS) on the device (ke_thumbnail_rgb), after the turn where
+    # there is one; beyond twice that size the loader itself (draft mode, reducing_gap)
+    large = np.asarray(Image.fromarray(base).resize((5000, 3400), Image.Resampling.BICUBIC))
+    put(26, "large.jpg", Image.fromarray(large), quality=80)
+    ex6 = Image.Exif()
+    ex6[0x0112] = 6
+    put(27, "large_turned.jpg", Image.fromarray(np.ascontiguousarray(large.transpose(1, 0, 2)[:, ::-1])), quality=80, exif=ex6.tobytes())
+    put(28, "large.png", Image.fromarray(np.repeat(np.repeat(noisy, 14, 0), 14, 1)[:3000, :4400]), compress_level=1)
+    put(29, "huge.jpg", Image.fromarray(np.repeat(np.repeat(base, 26, 0), 26, 1)[:6000, :8300]), quality=60)
     pairs = [(a, b, files[a], files[b]) for a, b in [(0, 1), (0, 2), (1, 2), (0, 3), (3, 2), (0, 4), (4, 2), (0, 5), (5, 1), (6, 0), (7, 2),
                                                       (6, 7), (8, 0), (8, 8), (9, 0), (9, 2), (12, 0), (13, 1), (14, 0), (15, 3), (17, 3),
-                                                      (18, 15), (20, 4), (20, 2), (21, 2), (22, 20), (23, 7), (24, 2), (25, 20), (21, 0)]]
+                                                      (18, 15), (20, 4), (20, 2), (21, 2), (22, 20), (23, 7), (24, 2), (25, 20), (21, 0),
+                                                      (26, 0), (27, 26), (28, 26), (29, 26)]]
     th = K.RefinementThresholds(ssim=0.8)
     one_by_one = [K.refine_pair(a, b, pa, pb, thresholds=th) for a, b, pa, pb in pairs]
     stats = {}
     assert K.refine_pairs(pairs, thresholds=th, stats=stats) == one_by_one
     # a.jpg, b.jpg, c.png, upright.jpg, d.bmp, rgb16.png as they are; rotated.jpg, the six turned*.jpg, alpha.png, alpha_any.png,
-    # alpha.bmp and rgba_adam7.png normalised on the device; gray, palette (PNG and BMP) and the 4100-pixel-wide file go through
-    # the loader
-    assert stats["decodes"] == 22 and stats["gpu_decodes"] == 17 and stats["gpu_normalised"] == 11, stats
+    # alpha.bmp and rgba_adam7.png normalised on the device; the 4100-pixel-wide file and the three large ones shrunk on the
+    # device; gray, palette (PNG and BMP) and the 8300-pixel-wide file go through the loader
+    assert stats["decodes"] == 26 and stats["gpu_decodes"] == 21 and stats["gpu_normalised"] == 11 and stats["gpu_shrunk"] == 4, stats
     by = {(a, b): m for (a, b, _, _), m in zip(pairs, one_by_one)}
     assert all(by[k].ssim > 0.999999 for k in ((21, 2), (24, 2), (22, 20), (25, 20)))         # same pixels, other container
     assert any(m.is_duplicate for m in one_by_one) and any(not m.is_duplicate for m in one_by_one)

@@ -924,3 +924,32 @@ def test_loader_normalisation_on_the_device(ctx):
         ctx.free(src)
     with pytest.raises(ValueError):
         ctx.normalise_rgb(src, [0], [4], [4], [3], [9])
+
+
+def test_loader_thumbnail_on_the_device(ctx):
+    """ke_thumbnail_rgb == Pillow's Image.thumbnail((box, box), LANCZOS) of an RGB image, byte for byte: landscape, portrait, a
+    strip that only shrinks along one axis, sizes where the aspect rounding decides the short side (the reference's loader,
+    src/utils/image_io.py:122-124, with box = 4096; smaller boxes keep the test quick)."""
+    from PIL import Image
+
+    rng = np.random.default_rng(29)
+    for (w, h, box) in [(4500, 3100, 4096), (3000, 4400, 4096), (4100, 40, 4096), (777, 1033, 512), (1201, 300, 1024), (2, 600, 512), (301, 299, 256)]:
+        yy, xx = np.mgrid[0:h, 0:w]
+        px = np.stack([(xx * 7 + yy * 3) % 256, (xx // 3 + yy * 5) % 256, (xx * yy // 11) % 256], -1).astype(np.uint8)
+        px ^= rng.integers(0, 32, px.shape, dtype=np.uint8)
+        im = Image.fromarray(px)
+        im.thumbnail((box, box), Image.Resampling.LANCZOS)
+        exp = np.asarray(im)
+        src = ctx.malloc(px.nbytes + 64)
+        try:
+            ctx.memcpy(src, px, px.nbytes)
+            dev, ow, oh = ctx.thumbnail_rgb(src, w, h, box)
+            try:
+                assert (oh, ow, 3) == exp.shape, (w, h, box)
+                got = np.empty(exp.shape, np.uint8)
+                ctx.memcpy(got, dev, got.nbytes)
+                assert np.array_equal(got, exp), (w, h, box)
+            finally:
+                ctx.free(dev)
+        finally:
+            ctx.free(src)

@@ -26,8 +26,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--images", type=int, default=16384)
     ap.add_argument("--side", type=int, default=512)
-    ap.add_argument("--format", choices=["jpeg", "png", "mixed", "bmp", "webp", "tiff"], default="jpeg",
-                    help="bmp / webp / tiff: formats outside the GPU decoders -- the whole batch takes the Pillow route (decoder processes)")
+    ap.add_argument("--format", choices=["jpeg", "png", "mixed", "bmp", "webp", "tiff", "collection"], default="jpeg",
+                    help="webp / tiff: formats outside the GPU decoders -- the whole batch takes the Pillow route (decoder processes); "
+                         "collection: 70 %% JPEG, 20 %% PNG, 4 %% BMP, 3 %% WebP, 3 %% TIFF in one call (the Pillow share runs beside the GPU share)")
     ap.add_argument("--distinct", type=int, default=128, help="distinct images behind the files")
     ap.add_argument("--content", choices=["corpus", "drawing"], default="corpus")
     ap.add_argument("--pillow-sample", type=int, default=4096, help="files of the batch given to the Pillow-route run")
@@ -46,7 +47,9 @@ def main():
         px[:, ::48, :, :] = 0
         px[:, :, ::64, :] = 0
     encoded = {"jpeg": [], "png": [], "bmp": [], "webp": [], "tiff": []}
-    wanted = ("jpeg", "png") if args.format == "mixed" else (args.format,)
+    wanted = ("jpeg", "png") if args.format == "mixed" else ("jpeg", "png", "bmp", "webp", "tiff") if args.format == "collection" else (args.format,)
+    mix = ["jpeg"] * 70 + ["png"] * 20 + ["bmp"] * 4 + ["webp"] * 3 + ["tiff"] * 3
+    np.random.default_rng(5).shuffle(mix)
     for k in range(distinct):
         for fmt, kw in (("jpeg", {"quality": 85, "subsampling": 2}), ("png", {}), ("bmp", {}), ("webp", {"quality": 85, "method": 0}), ("tiff", {})):
             if fmt not in wanted:
@@ -58,7 +61,7 @@ def main():
     try:
         items, nbytes = [], 0
         for i in range(args.images):
-            fmt = args.format if args.format != "mixed" else ("jpeg", "png")[i & 1]
+            fmt = ("jpeg", "png")[i & 1] if args.format == "mixed" else mix[i % 100] if args.format == "collection" else args.format
             path = os.path.join(root, f"f{i:07d}.{'jpg' if fmt == 'jpeg' else fmt}")
             data = encoded[fmt][i % distinct]
             with open(path, "wb") as fh:

@@ -40,6 +40,10 @@ if [ "${2:-}" = "more" ]; then
         set -- $spec
         run python3 "$root/benchmarks/bench_fastsig.py" --format "$1" --side "$2" --distinct "$3" --images "$4" --pillow-sample "$4" >> "$out/${tag}_fastsig_pillow_route.jsonl" 2>> "$out/${tag}_decode_phases.err"
     done
+    # a collection of mixed formats in one call (70 % JPEG, 20 % PNG, 4 % BMP, 3 % WebP, 3 % TIFF): the GPU share and the Pillow share side by side
+    : > "$out/${tag}_fastsig_collection.jsonl"
+    run python3 "$root/benchmarks/bench_fastsig.py" --format collection --images 32768 --pillow-sample 8192 >> "$out/${tag}_fastsig_collection.jsonl" 2>> "$out/${tag}_decode_phases.err"
+    run python3 "$root/benchmarks/bench_fastsig.py" --format collection --content drawing --images 65536 --pillow-sample 8192 >> "$out/${tag}_fastsig_collection.jsonl" 2>> "$out/${tag}_decode_phases.err"
     # BMP: unpacked on the GPU (ke_bmp_decode) against the same files through the Pillow route
     : > "$out/${tag}_fastsig_bmp.jsonl"
     for spec in "3500 16 256 256" "512 256 16384 4096" "1024 64 4096 1024"; do

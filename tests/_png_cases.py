@@ -161,11 +161,12 @@ def _filtered(rows: np.ndarray, unit: int, types) -> bytes:
     return bytes(out)
 
 
-def _adam7_stream(samples: np.ndarray, depth: int, rng) -> bytes:
-    """samples: H x W x C (8-bit) or H x W x 1 values below 2**depth -> the seven passes' filtered rows, random filter types."""
+def _adam7_stream(samples: np.ndarray, depth: int, rng, passes=_ADAM7) -> bytes:
+    """samples: H x W x C (8-bit) or H x W x 1 values below 2**depth -> the seven passes' filtered rows, random filter types
+    (passes=((0, 0, 1, 1),): the rows of a file without interlacing)."""
     h, w, ch = samples.shape
     out = b""
-    for (x0, y0, dx, dy) in _ADAM7:
+    for (x0, y0, dx, dy) in passes:
         sub = samples[y0::dy, x0::dx]
         if sub.shape[0] == 0 or sub.shape[1] == 0:
             continue
@@ -278,6 +279,32 @@ def refused():
         return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d))
 
     yield "idat_text_idat", whole[:z_at] + ch(b"IDAT", z[: zlen // 2]) + ch(b"tEXt", b"k\x00v") + ch(b"IDAT", z[zlen // 2:]) + ch(b"IEND", b""), 2
+
+
+def random_handmade(n: int, seed: int = 0):
+    """n random files of every colour type x bit depth x interlacing the decoder takes, every filter type, sizes up to
+    120 x 90, IDAT data in chunks of random size: (name, file bytes, what the reference's hashes see)."""
+    rng = np.random.default_rng(seed)
+    kinds = [(0, 1), (0, 2), (0, 4), (0, 8), (0, 16), (2, 8), (2, 16), (3, 1), (3, 2), (3, 4), (3, 8), (4, 8), (4, 16), (6, 8), (6, 16)]
+    for k in range(n):
+        w, h = int(rng.integers(1, 121)), int(rng.integers(1, 91))
+        ctype, depth = kinds[int(rng.integers(0, len(kinds)))]
+        lace = int(rng.integers(0, 2))
+        chans = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[ctype]
+        if depth >= 8:
+            a = rng.integers(0, 256, (h, w, chans * depth // 8), dtype=np.uint8)
+            if rng.integers(0, 2):                                  # smooth content: matches, long filter chains
+                a = (np.cumsum(rng.integers(0, 3, a.shape), 1) % 256).astype(np.uint8)
+            if ctype == 0 and depth == 16:
+                a[:, :, 0] = np.where(rng.random((h, w)) < 0.7, 0, a[:, :, 0])
+            raw = _adam7_stream(a, 8, rng, _ADAM7 if lace else ((0, 0, 1, 1),))
+        else:
+            raw = _adam7_stream(rng.integers(0, 1 << depth, (h, w, 1), dtype=np.uint8), depth, rng, _ADAM7 if lace else ((0, 0, 1, 1),))
+        plte = rng.integers(0, 256, 3 * int(rng.integers(1, (1 << depth) + 1)), dtype=np.uint8).tobytes() if ctype == 3 else None
+        data = _container2(raw, w, h, ctype, depth, lace, plte=plte, level=int(rng.integers(0, 10)), chunk=int(rng.choice([7, 100, 8192, 1 << 30])))
+        with Image.open(io.BytesIO(data)) as im:
+            ref = np.asarray(im.convert("L") if im.mode in ("P", "1", "LA", "I;16") or (im.mode == "L" and depth < 8) else im)
+        yield f"handmade{k}_c{ctype}_d{depth}_i{lace}_{w}x{h}", data, ref
 
 
 def random_cases(n: int, seed: int = 0):

@@ -105,3 +105,16 @@ def test_random_files_decode_as_pillow_does():
         assert status == 0 and out.shape == ref.shape and np.array_equal(out, ref)
 
     check()
+
+
+def test_random_handmade_files_decode_as_pillow_does():
+    """What Pillow's writer never produces -- interlacing, 16 bits, sub-byte grayscale, short palettes, every filter type in any
+    row, IDAT data in chunks of a few bytes -- in random combinations (tests/_png_cases.random_handmade)."""
+    L = _lib()
+    n = 0
+    for name, data, ref in P.random_handmade(400, 17):
+        st, out = _decode(L, data)
+        assert st == 0, name
+        assert out.shape == ref.shape and np.array_equal(out, ref), name
+        n += 1
+    assert n == 400

@@ -26,7 +26,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--images", type=int, default=16384)
     ap.add_argument("--side", type=int, default=512)
-    ap.add_argument("--format", choices=["jpeg", "png", "mixed", "bmp", "webp", "tiff", "collection"], default="jpeg",
+    ap.add_argument("--format", choices=["jpeg", "png", "mixed", "bmp", "gif", "webp", "tiff", "collection"], default="jpeg",
                     help="webp / tiff: formats outside the GPU decoders -- the whole batch takes the Pillow route (decoder processes); "
                          "collection: 70 %% JPEG, 20 %% PNG, 4 %% BMP, 3 %% WebP, 3 %% TIFF in one call (the Pillow share runs beside the GPU share)")
     ap.add_argument("--distinct", type=int, default=128, help="distinct images behind the files")
@@ -46,12 +46,12 @@ def main():
         px = np.repeat(np.repeat(cells, 16, 1), 16, 2)[:, :s, :s].copy()
         px[:, ::48, :, :] = 0
         px[:, :, ::64, :] = 0
-    encoded = {"jpeg": [], "png": [], "bmp": [], "webp": [], "tiff": []}
+    encoded = {"jpeg": [], "png": [], "bmp": [], "gif": [], "webp": [], "tiff": []}
     wanted = ("jpeg", "png") if args.format == "mixed" else ("jpeg", "png", "bmp", "webp", "tiff") if args.format == "collection" else (args.format,)
     mix = ["jpeg"] * 70 + ["png"] * 20 + ["bmp"] * 4 + ["webp"] * 3 + ["tiff"] * 3
     np.random.default_rng(5).shuffle(mix)
     for k in range(distinct):
-        for fmt, kw in (("jpeg", {"quality": 85, "subsampling": 2}), ("png", {}), ("bmp", {}), ("webp", {"quality": 85, "method": 0}), ("tiff", {})):
+        for fmt, kw in (("jpeg", {"quality": 85, "subsampling": 2}), ("png", {}), ("bmp", {}), ("gif", {}), ("webp", {"quality": 85, "method": 0}), ("tiff", {})):
             if fmt not in wanted:
                 continue
             b = io.BytesIO()
@@ -83,7 +83,7 @@ def main():
         with sqlite3.connect(db) as conn:
             assert conn.execute("SELECT COUNT(*) FROM signatures").fetchone()[0] == args.images
         sample = items[: args.pillow_sample]
-        os.environ["KE_GPU_JPEG"] = os.environ["KE_GPU_PNG"] = os.environ["KE_GPU_BMP"] = "0"
+        os.environ["KE_GPU_JPEG"] = os.environ["KE_GPU_PNG"] = os.environ["KE_GPU_BMP"] = os.environ["KE_GPU_GIF"] = "0"
         fastsig.fast_fill_missing_signatures(db, sample[:256], apply_to_db=False)
         t0 = time.perf_counter()
         rows_cpu = fastsig.fast_fill_missing_signatures(db, sample, apply_to_db=False)

@@ -210,6 +210,22 @@ int ke_bmp_decode(ke_ctx *ctx, const uint8_t *files, const uint64_t *offsets, co
                   uint8_t *pixels_out, const uint64_t *out_offsets, int32_t *status_out);
 int ke_bmp_caveats(const uint8_t *files, const uint64_t *offsets, const uint64_t *sizes, int64_t n, int32_t *flags_out);
 
+/* ---- GIF files on the GPU: the same step for the first frame of a GIF file -- what Image.open shows, also of an animation --
+ * as the luma `convert("L")` makes of it (src/sig/phash.py:25: what the reference's hashes see), channels = 1: palette index ->
+ * luma of the local or global palette entry (no palette or an identity gray ramp: the index).  The container is walked as
+ * GifImagePlugin walks it, the LZW stream read as Pillow's GifDecode.c reads it (whole sub-blocks only; over when the last
+ * pixel is written); one thread per image walks the codes (a string is a copy from earlier output, recorded), one wave per
+ * image makes the copies, a last kernel maps indices to luma and puts interlaced rows in place.  A first frame that does not
+ * cover the logical screen, code sizes outside 2..8, an end code or the end of the block list before the last pixel, frames
+ * of more than 2^23 pixels: KE_JPEG_UNSUPPORTED_ (1) per file (Pillow decides); data that ends early: KE_JPEG_CORRUPT_ (2).
+ * Arguments and conventions as ke_jpeg_probe / ke_jpeg_decode.  For the hashing seams only: the reference's SSIM loader turns a
+ * palette file into RGB, not luma.  ke_gif_caveats reports no flags. */
+int ke_gif_probe(const uint8_t *files, const uint64_t *offsets, const uint64_t *sizes, int64_t n, int32_t *widths,
+                 int32_t *heights, int32_t *channels, int32_t *status_out);
+int ke_gif_decode(ke_ctx *ctx, const uint8_t *files, const uint64_t *offsets, const uint64_t *sizes, int64_t n,
+                  uint8_t *pixels_out, const uint64_t *out_offsets, int32_t *status_out);
+int ke_gif_caveats(const uint8_t *files, const uint64_t *offsets, const uint64_t *sizes, int64_t n, int32_t *flags_out);
+
 /* What `Image.open` alone does not tell about a file but the reference's defensive loader acts on (src/utils/image_io.py:60-138:
  * EXIF orientation applied, alpha composited over white): per file a set of KE_CAVEAT_* bits, so that a caller who wants that
  * loader's pixels sends flagged files through it and only the rest through ke_jpeg_decode / ke_png_decode.  ORIENTATION: the

@@ -44,6 +44,12 @@ if [ "${2:-}" = "more" ]; then
     : > "$out/${tag}_fastsig_collection.jsonl"
     run python3 "$root/benchmarks/bench_fastsig.py" --format collection --images 32768 --pillow-sample 8192 >> "$out/${tag}_fastsig_collection.jsonl" 2>> "$out/${tag}_decode_phases.err"
     run python3 "$root/benchmarks/bench_fastsig.py" --format collection --content drawing --images 65536 --pillow-sample 8192 >> "$out/${tag}_fastsig_collection.jsonl" 2>> "$out/${tag}_decode_phases.err"
+    # GIF: first frame decoded on the GPU (ke_gif_decode) against the same files through the Pillow route
+    : > "$out/${tag}_fastsig_gif.jsonl"
+    for spec in "corpus 4096 4096" "corpus 32768 8192" "drawing 65536 8192"; do
+        set -- $spec
+        run python3 "$root/benchmarks/bench_fastsig.py" --format gif --content "$1" --images "$2" --pillow-sample "$3" >> "$out/${tag}_fastsig_gif.jsonl" 2>> "$out/${tag}_decode_phases.err"
+    done
     # BMP: unpacked on the GPU (ke_bmp_decode) against the same files through the Pillow route
     : > "$out/${tag}_fastsig_bmp.jsonl"
     for spec in "3500 16 256 256" "512 256 16384 4096" "1024 64 4096 1024"; do

@@ -4,12 +4,15 @@ markers together) -- the right per-file refusal for the rest, and the hashes of 
 leaving the GPU against the oracle on Pillow's pixels."""
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import pytest
 
 import _jpeg_cases as J
 import _png_cases as P
 import _bmp_cases as B
+import _gif_cases as GF
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -192,6 +195,59 @@ def test_bmp_unpack_matches_pillow_in_one_mixed_batch(ctx):
             ref = TB.strict_pillow(data)
             assert ref is not None and ref.shape == px.shape and np.array_equal(ref, px), name
     assert decoded > 100
+
+
+def test_gif_first_frame_matches_pillow_in_one_mixed_batch(ctx, tmp_path):
+    """ke_gif_decode: Pillow-written GIFs (palette, gray, interlaced, optimised, transparent, animated) and hand-made streams
+    (clear codes at any distance or never, long runs, 3-byte sub-blocks, local / short / no palettes, nothing behind the last
+    pixel) in one call -- the luma the reference's hashes see of the first frame; frames that do not cover the screen, early
+    end codes and truncated data reported per file; damaged files never decoded differently from Pillow; .gif files take the
+    route in the batch hasher."""
+    import test_gif_cpu as TG
+
+    cases = list(GF.supported(full=True)) + list(GF.handmade(full=True))
+    refused = list(GF.refused())
+    out, status = ctx.gif_decode([c[1] for c in cases] + [r[1] for r in refused])
+    taken = 0
+    for k, (name, _, ref) in enumerate(cases):
+        if ref is None or name.startswith(GF.LEFT_TO_PILLOW):
+            assert status[k] != 0 and out[k] is None, name
+            continue
+        assert status[k] == 0, name
+        assert out[k].shape == ref.shape and np.array_equal(out[k], ref), name
+        taken += 1
+    for k, (name, _, expected) in enumerate(refused, len(cases)):
+        assert status[k] == expected and out[k] is None, name
+    assert taken > 300
+    big = [c for c in cases if c[2] is not None and not c[0].startswith(GF.LEFT_TO_PILLOW) and min(c[2].shape) >= 16]
+    ph, dh, st = ctx.gif_hash([c[1] for c in big])
+    for k, c in enumerate(big):
+        assert st[k] == 0 and (int(ph[k]), int(dh[k])) == O.hash_image(c[2]), c[0]
+    rng = np.random.default_rng(34)
+    pool = [c for c in cases if c[2] is not None and c[2].size <= 8000]
+    damaged = list(TG.damaged(rng, pool, 20))
+    out, status = ctx.gif_decode([d for _, d in damaged])
+    decoded = 0
+    for (name, data), px, st in zip(damaged, out, status):
+        if st == 0:
+            decoded += 1
+            ref = TG.strict_pillow(data)
+            assert ref is not None and ref.shape == px.shape and np.array_equal(ref, px), name
+    assert decoded > 200
+    # the batch hasher: .gif files on the GPU route == the Pillow route, row for row
+    from kobato_eyes_amd import fastsig as K
+
+    items = []
+    for k, c in enumerate(big[:40] + [c for c in cases if c[0].startswith(GF.LEFT_TO_PILLOW)][:3]):
+        p = tmp_path / f"{k:03d}.gif"
+        p.write_bytes(c[1])
+        items.append((500 + k, str(p)))
+    rows = K.compute_signatures_mp(items, max_workers=4, chunksize=16)
+    os.environ["KE_GPU_GIF"] = "0"
+    try:
+        assert rows == K.compute_signatures_mp(items, max_workers=4, chunksize=16) and len(rows) >= 40
+    finally:
+        del os.environ["KE_GPU_GIF"]
 
 
 def test_png_damage_is_reported_not_decoded(ctx):

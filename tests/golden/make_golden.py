@@ -842,6 +842,10 @@ def make_refine_turned():
     put("rgbx.bmp", Image.fromarray(np.dstack([near, alpha]), "RGBA"), "BMP")
     put("pal.bmp", Image.fromarray(near).quantize(200), "BMP")
     put("gray.bmp", Image.fromarray(g8), "BMP")
+    # GIF: the first frame is what the stage sees (palette -> luma), of a still and of an animation
+    put("still.gif", Image.fromarray(near).quantize(256), "GIF")
+    put("anim.gif", Image.fromarray(near).quantize(64), "GIF", save_all=True, append_images=[Image.fromarray(other).quantize(64)], duration=60, loop=0)
+    put("gray.gif", Image.fromarray(g8), "GIF", interlace=False)
     out = {"names": [n for n, _ in files], "cases": {}, "clusters": []}
     store = {"names": np.array(out["names"])}
     for k, (_, data) in enumerate(files):
@@ -860,12 +864,14 @@ def make_refine_turned():
                       [("upright.jpg", "turned1.jpg"), ("upright.jpg", "turned6.jpg"), ("turned3.jpg", "turned8.jpg"), ("upright.jpg", "rgba.png"),
                        ("rgba.png", "la.png"), ("upright.jpg", "other.jpg"), ("rgba.png", "rgb16.png"), ("la.png", "la16.png"),
                        ("rgba.png", "rgba16_adam7.png"), ("rgb_adam7.png", "rgb16.png"), ("la.png", "gray16.png"), ("rgba.png", "rgb.bmp"),
-                       ("rgb.bmp", "rgbx.bmp"), ("rgb.bmp", "pal.bmp"), ("la.png", "gray.bmp")]]
+                       ("rgb.bmp", "rgbx.bmp"), ("rgb.bmp", "pal.bmp"), ("la.png", "gray.bmp"), ("pal.bmp", "still.gif"),
+                       ("still.gif", "anim.gif"), ("gray.bmp", "gray.gif")]]
         ids = {n: k + 1 for k, n in enumerate(paths)}
         groups = [(["upright.jpg"] + [f"turned{o}.jpg" for o in range(1, 9)], "upright.jpg"), (["rgba.png", "la.png", "other.jpg"], "rgba.png"),
                   (["turned5.jpg", "other.jpg", "turned2.jpg"], "turned5.jpg"),
                   (["rgb16.png", "rgb_adam7.png", "rgba16_adam7.png", "la16.png", "gray16.png", "other.jpg"], "rgb16.png"),
-                  (["rgb.bmp", "rgbx.bmp", "pal.bmp", "gray.bmp", "upright.jpg", "other.jpg"], "rgb.bmp")]
+                  (["rgb.bmp", "rgbx.bmp", "pal.bmp", "gray.bmp", "upright.jpg", "other.jpg"], "rgb.bmp"),
+                  (["still.gif", "anim.gif", "gray.gif", "rgb.bmp", "other.jpg"], "still.gif")]
         clusters = [Cl([E(F(ids[n], paths[n])) for n in members], ids[keeper]) for members, keeper in groups]
         out["cluster_inputs"] = [{"members": m, "keeper": k} for m, k in groups]
         for max_bits in (4, 400, 1024):

@@ -25,7 +25,7 @@ def main():
     ap.add_argument("--side", type=int, default=512)
     ap.add_argument("--quality", type=int, default=85)
     ap.add_argument("--subsampling", type=int, default=2)
-    ap.add_argument("--format", choices=["jpeg", "png"], default="jpeg")
+    ap.add_argument("--format", choices=["jpeg", "png", "gif", "bmp"], default="jpeg")
     ap.add_argument("--distinct", type=int, default=4096,
                     help="distinct images encoded (the batch cycles through them; few copies of each, so that the lanes of a wave hold different images)")
     ap.add_argument("--progressive", action="store_true", help="JPEG: progressive files (libjpeg's default scan script)")
@@ -74,7 +74,9 @@ def main():
         b = io.BytesIO()
         if args.format == "png" and args.interlaced:
             return adam7(px[k])
-        if args.format == "png":
+        if args.format in ("gif", "bmp"):
+            Image.fromarray(px[k]).save(b, args.format.upper())
+        elif args.format == "png":
             Image.fromarray(px[k]).save(b, "PNG")
         else:
             Image.fromarray(px[k]).save(b, "JPEG", quality=args.quality, subsampling=args.subsampling, progressive=args.progressive)

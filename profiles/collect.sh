@@ -50,6 +50,11 @@ if [ "${2:-}" = "more" ]; then
         set -- $spec
         run python3 "$root/benchmarks/bench_fastsig.py" --format gif --content "$1" --images "$2" --pillow-sample "$3" >> "$out/${tag}_fastsig_gif.jsonl" 2>> "$out/${tag}_decode_phases.err"
     done
+    : > "$out/${tag}_decode_gif.jsonl"
+    for spec in "corpus 1024" "corpus 4096" "corpus 16384" "corpus 65536" "drawing 65536"; do
+        set -- $spec
+        run python3 "$root/benchmarks/bench_jpeg.py" --format gif --content "$1" --images "$2" >> "$out/${tag}_decode_gif.jsonl" 2>> "$out/${tag}_decode_phases.err"
+    done
     # BMP: unpacked on the GPU (ke_bmp_decode) against the same files through the Pillow route
     : > "$out/${tag}_fastsig_bmp.jsonl"
     for spec in "3500 16 256 256" "512 256 16384 4096" "1024 64 4096 1024"; do

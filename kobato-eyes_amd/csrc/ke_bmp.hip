@@ -132,9 +132,12 @@ KE_API int ke_bmp_decode(ke_ctx *ctx, const uint8_t *files, const uint64_t *offs
     devs.reserve((size_t)n);
     uint64_t lo = ~0ull, hi = 0;
     int max_height = 0;
+    std::vector<KeBmpInfo> infos((size_t)n);                     // the headers are read on the host's threads
+    ke_parallel_ranges(n, [&](int64_t a, int64_t b, int) {
+        for (int64_t i = a; i < b; ++i) ke_parse_bmp(files + offsets[i], (size_t)sizes[i], infos[(size_t)i]);
+    });
     for (int64_t i = 0; i < n; ++i) {
-        KeBmpInfo info;
-        ke_parse_bmp(files + offsets[i], (size_t)sizes[i], info);
+        const KeBmpInfo &info = infos[(size_t)i];
         status_out[i] = info.status;
         if (info.status != KE_BMP_OK) continue;
         KeBmpDev d;

@@ -170,9 +170,12 @@ KE_API int ke_gif_decode(ke_ctx *ctx, const uint8_t *files, const uint64_t *offs
     std::vector<Item> items;
     items.reserve((size_t)n);
     uint64_t lo = ~0ull, hi = 0;
+    std::vector<KeGifInfo> infos((size_t)n);                     // the containers are walked on the host's threads
+    ke_parallel_ranges(n, [&](int64_t a, int64_t b, int) {
+        for (int64_t i = a; i < b; ++i) ke_parse_gif(files + offsets[i], (size_t)sizes[i], infos[(size_t)i]);
+    });
     for (int64_t i = 0; i < n; ++i) {
-        KeGifInfo info;
-        ke_parse_gif(files + offsets[i], (size_t)sizes[i], info);
+        const KeGifInfo &info = infos[(size_t)i];
         status_out[i] = info.status;
         if (info.status != KE_GIF_OK) continue;
         Item it;

@@ -83,7 +83,7 @@ def main():
         with sqlite3.connect(db) as conn:
             assert conn.execute("SELECT COUNT(*) FROM signatures").fetchone()[0] == args.images
         sample = items[: args.pillow_sample]
-        os.environ["KE_GPU_JPEG"] = os.environ["KE_GPU_PNG"] = os.environ["KE_GPU_BMP"] = os.environ["KE_GPU_GIF"] = "0"
+        os.environ["KE_GPU_JPEG"] = os.environ["KE_GPU_PNG"] = os.environ["KE_GPU_BMP"] = os.environ["KE_GPU_GIF"] = os.environ["KE_GPU_TIFF"] = "0"
         fastsig.fast_fill_missing_signatures(db, sample[:256], apply_to_db=False)
         t0 = time.perf_counter()
         rows_cpu = fastsig.fast_fill_missing_signatures(db, sample, apply_to_db=False)

@@ -226,6 +226,21 @@ int ke_gif_decode(ke_ctx *ctx, const uint8_t *files, const uint64_t *offsets, co
                   uint8_t *pixels_out, const uint64_t *out_offsets, int32_t *status_out);
 int ke_gif_caveats(const uint8_t *files, const uint64_t *offsets, const uint64_t *sizes, int64_t n, int32_t *flags_out);
 
+/* ---- TIFF files unpacked on the GPU: the same step for the uncompressed 8-bit files Pillow's TiffImagePlugin opens with its own
+ * "raw" decoder (compressed TIFF is libtiff's there and stays with Pillow): gray (BlackIsZero; WhiteIsZero inverted), RGB, RGB
+ * with unassociated alpha (RGBA) or an unspecified fourth sample (dropped), palette files as the luma `convert("L")` makes of
+ * them (src/sig/phash.py:25), channels = 1.  The first directory is read as ImageFileDirectory_v2.load reads it (both byte
+ * orders), the layout derived as TiffImageFile._setup derives it (strips of RowsPerStrip rows); the files go to the device as
+ * they are and one kernel gathers the strips into packed rows.  A whitelist: other compression / planar layout / fill order /
+ * bit depths / sample formats, tiles, an orientation other than 1, EXIF / GPS directories or an XMP packet (Pillow applies an
+ * orientation found there at load time), a strip count that does not match the rows: KE_JPEG_UNSUPPORTED_ (1) per file; a
+ * strip that ends behind the file: KE_JPEG_CORRUPT_ (2).  Arguments and conventions as ke_jpeg_probe / ke_jpeg_decode. */
+int ke_tiff_probe(const uint8_t *files, const uint64_t *offsets, const uint64_t *sizes, int64_t n, int32_t *widths,
+                  int32_t *heights, int32_t *channels, int32_t *status_out);
+int ke_tiff_decode(ke_ctx *ctx, const uint8_t *files, const uint64_t *offsets, const uint64_t *sizes, int64_t n,
+                   uint8_t *pixels_out, const uint64_t *out_offsets, int32_t *status_out);
+int ke_tiff_caveats(const uint8_t *files, const uint64_t *offsets, const uint64_t *sizes, int64_t n, int32_t *flags_out);
+
 /* What `Image.open` alone does not tell about a file but the reference's defensive loader acts on (src/utils/image_io.py:60-138:
  * EXIF orientation applied, alpha composited over white): per file a set of KE_CAVEAT_* bits, so that a caller who wants that
  * loader's pixels sends flagged files through it and only the rest through ke_jpeg_decode / ke_png_decode.  ORIENTATION: the

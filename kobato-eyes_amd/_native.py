@@ -29,7 +29,7 @@ EXPORTS = (
     "ke_band_pairs_after_size",
     "ke_stage_create", "ke_stage_create_shared", "ke_stage_destroy", "ke_stage_acquire", "ke_stage_submit_hash", "ke_stage_wait",
     "ke_comm_unique_id", "ke_comm_create", "ke_comm_destroy", "ke_allgather_u64", "ke_allgather_hashes", "ke_allgather_edges",
-    "ke_interleave_shards", "ke_host_alloc", "ke_host_free", "ke_host_pack", "ke_host_read_files", "ke_jpeg_probe", "ke_jpeg_decode", "ke_png_probe", "ke_png_decode", "ke_jpeg_caveats", "ke_png_caveats", "ke_bmp_probe", "ke_bmp_decode", "ke_bmp_caveats", "ke_gif_probe", "ke_gif_decode", "ke_gif_caveats", "ke_normalise_rgb", "ke_thumbnail_rgb", "ke_cluster_labels", "ke_ssim_pairs_uniform", "ke_ssim_pairs", "ke_ssim_set_mode", "ke_resize_luma_uniform", "ke_fit_luma_uniform", "ke_tile_ahash", "ke_sad_pairs", "ke_synth_rgb",
+    "ke_interleave_shards", "ke_host_alloc", "ke_host_free", "ke_host_pack", "ke_host_read_files", "ke_jpeg_probe", "ke_jpeg_decode", "ke_png_probe", "ke_png_decode", "ke_jpeg_caveats", "ke_png_caveats", "ke_bmp_probe", "ke_bmp_decode", "ke_bmp_caveats", "ke_gif_probe", "ke_gif_decode", "ke_gif_caveats", "ke_tiff_probe", "ke_tiff_decode", "ke_tiff_caveats", "ke_normalise_rgb", "ke_thumbnail_rgb", "ke_cluster_labels", "ke_ssim_pairs_uniform", "ke_ssim_pairs", "ke_ssim_set_mode", "ke_resize_luma_uniform", "ke_fit_luma_uniform", "ke_tile_ahash", "ke_sad_pairs", "ke_synth_rgb",
     "ke_synth_rgb_indexed",
     "ke_synth_hashes", "ke_last_kernel_ms",
 )
@@ -137,6 +137,9 @@ def load_library() -> C.CDLL:
         lib.ke_gif_probe.argtypes = [vp, vp, vp, i64, vp, vp, vp, vp]
         lib.ke_gif_decode.argtypes = [vp, vp, vp, vp, i64, vp, vp, vp]
         lib.ke_gif_caveats.argtypes = [vp, vp, vp, i64, vp]
+        lib.ke_tiff_probe.argtypes = [vp, vp, vp, i64, vp, vp, vp, vp]
+        lib.ke_tiff_decode.argtypes = [vp, vp, vp, vp, i64, vp, vp, vp]
+        lib.ke_tiff_caveats.argtypes = [vp, vp, vp, i64, vp]
         lib.ke_normalise_rgb.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, vp, vp]
         lib.ke_thumbnail_rgb.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
         lib.ke_band_pairs_after_size.argtypes = [vp, vp, vp, i64, i32, i32, dbl, i64, vp]
@@ -159,7 +162,7 @@ def load_library() -> C.CDLL:
                      "ke_hash_images", "ke_hash_uniform", "ke_hash_images_ex", "ke_hash_uniform_ex", "ke_luma_tiles_uniform", "ke_hamming_scan", "ke_band_pairs_after_size",
                      "ke_stage_create", "ke_stage_create_shared", "ke_stage_destroy", "ke_stage_acquire", "ke_stage_submit_hash", "ke_stage_wait",
                      "ke_comm_unique_id", "ke_comm_create", "ke_comm_destroy", "ke_allgather_u64", "ke_allgather_hashes", "ke_allgather_edges",
-                     "ke_interleave_shards", "ke_host_alloc", "ke_host_free", "ke_host_pack", "ke_host_read_files", "ke_jpeg_probe", "ke_jpeg_decode", "ke_png_probe", "ke_png_decode", "ke_jpeg_caveats", "ke_png_caveats", "ke_bmp_probe", "ke_bmp_decode", "ke_bmp_caveats", "ke_gif_probe", "ke_gif_decode", "ke_gif_caveats", "ke_normalise_rgb", "ke_thumbnail_rgb", "ke_cluster_labels", "ke_ssim_pairs_uniform", "ke_ssim_pairs", "ke_ssim_set_mode", "ke_resize_luma_uniform", "ke_fit_luma_uniform", "ke_tile_ahash",
+                     "ke_interleave_shards", "ke_host_alloc", "ke_host_free", "ke_host_pack", "ke_host_read_files", "ke_jpeg_probe", "ke_jpeg_decode", "ke_png_probe", "ke_png_decode", "ke_jpeg_caveats", "ke_png_caveats", "ke_bmp_probe", "ke_bmp_decode", "ke_bmp_caveats", "ke_gif_probe", "ke_gif_decode", "ke_gif_caveats", "ke_tiff_probe", "ke_tiff_decode", "ke_tiff_caveats", "ke_normalise_rgb", "ke_thumbnail_rgb", "ke_cluster_labels", "ke_ssim_pairs_uniform", "ke_ssim_pairs", "ke_ssim_set_mode", "ke_resize_luma_uniform", "ke_fit_luma_uniform", "ke_tile_ahash",
                      "ke_sad_pairs", "ke_synth_rgb", "ke_synth_rgb_indexed", "ke_synth_hashes"):
             getattr(lib, name).restype = C.c_int
         _lib = lib
@@ -573,6 +576,17 @@ class Context:
 
     def gif_hash(self, blobs, *, want_dhash=True):
         return self.jpeg_hash(blobs, want_dhash=want_dhash, kind="gif")
+
+    def tiff_probe(self, blobs):
+        return self.jpeg_probe(blobs, "tiff")
+
+    def tiff_decode(self, blobs):
+        """Pixels of uncompressed 8-bit TIFF files unpacked on the GPU (HxW gray or luma of a palette file, HxWx3, HxWx4), None
+        where the unpacker refused the file."""
+        return self.jpeg_decode(blobs, "tiff")
+
+    def tiff_hash(self, blobs, *, want_dhash=True):
+        return self.jpeg_hash(blobs, want_dhash=want_dhash, kind="tiff")
 
     def _jpeg_to_device(self, blobs, kind: str = "jpeg", *, paths=None, ahead=None, skip=None):
         """Decode what the GPU decoder takes into the context's decode buffer (device memory, grown on demand and kept:

@@ -118,7 +118,8 @@ JPEG_SUFFIXES = (".jpg", ".jpeg", ".jpe", ".jfif")
 PNG_SUFFIXES = (".png",)
 BMP_SUFFIXES = (".bmp",)
 GIF_SUFFIXES = (".gif",)
-GPU_KINDS = ("jpeg", "png", "bmp", "gif")           # the order in which a batch's files lie in the read-ahead buffer
+TIFF_SUFFIXES = (".tif", ".tiff")
+GPU_KINDS = ("jpeg", "png", "bmp", "gif", "tiff")           # the order in which a batch's files lie in the read-ahead buffer
 
 
 def _read_bytes(path_text: str):
@@ -401,24 +402,26 @@ class _Pipeline:
 
     # ---- the GPU decoders' share of a batch
     def _start_reads(self, start: int) -> dict:
-        """The JPEG / PNG / BMP / GIF files of the batch that begins at ``start``, on their way into memory while the batch before is
+        """The JPEG / PNG / BMP / GIF / TIFF files of the batch that begins at ``start``, on their way into memory while the batch before is
         on the GPU.  Runs on a pool thread (the classification is a pass of the interpreter over the batch, the reading is the
-        library's): {"jpeg" / "png" / "bmp" / "gif": positions (arrays, ascending), "blobs": position -> future of the file's bytes for
-        a stage without ``hash_files``, "ahead": the context's FilesAhead holding [JPEG | PNG | BMP | GIF files] or None}."""
+        library's): {"jpeg" / "png" / "bmp" / "gif" / "tiff": positions (arrays, ascending), "blobs": position -> future of the file's bytes for
+        a stage without ``hash_files``, "ahead": the context's FilesAhead holding [JPEG | PNG | BMP | GIF | TIFF files] or None}."""
         gpu_jpeg = os.environ.get("KE_GPU_JPEG", "1") != "0"
         gpu_png = os.environ.get("KE_GPU_PNG", "1") != "0"
         gpu_bmp = os.environ.get("KE_GPU_BMP", "1") != "0"
         gpu_gif = os.environ.get("KE_GPU_GIF", "1") != "0"
+        gpu_tiff = os.environ.get("KE_GPU_TIFF", "1") != "0"
         by_path = hasattr(self.stage, "hash_files")          # the library reads the files itself, into page-locked memory
         stop = min(start + self.batch, len(self.tasks))
         tails = [p[-5:].lower() for p in self.paths[start:stop]]
-        kind = np.fromiter((1 if t.endswith(JPEG_SUFFIXES) else 2 if t.endswith(PNG_SUFFIXES) else 3 if t.endswith(BMP_SUFFIXES) else 4 if t.endswith(GIF_SUFFIXES) else 0
+        kind = np.fromiter((1 if t.endswith(JPEG_SUFFIXES) else 2 if t.endswith(PNG_SUFFIXES) else 3 if t.endswith(BMP_SUFFIXES) else 4 if t.endswith(GIF_SUFFIXES) else 5 if t.endswith(TIFF_SUFFIXES) else 0
                             for t in tails), np.int8, stop - start)
         jpeg = start + np.nonzero(kind == 1)[0] if gpu_jpeg else np.zeros(0, np.int64)
         png = start + np.nonzero(kind == 2)[0] if gpu_png else np.zeros(0, np.int64)
         bmp = start + np.nonzero(kind == 3)[0] if gpu_bmp else np.zeros(0, np.int64)
         gif = start + np.nonzero(kind == 4)[0] if gpu_gif else np.zeros(0, np.int64)
-        reads = {"jpeg": jpeg, "png": png, "bmp": bmp, "gif": gif, "blobs": {}, "ahead": None}
+        tiff = start + np.nonzero(kind == 5)[0] if gpu_tiff else np.zeros(0, np.int64)
+        reads = {"jpeg": jpeg, "png": png, "bmp": bmp, "gif": gif, "tiff": tiff, "blobs": {}, "ahead": None}
         order = np.concatenate([reads[k] for k in GPU_KINDS]).tolist()
         if not by_path:
             reads["blobs"] = {int(k): self.pool.submit(_read_bytes, self.paths[k]) for k in order}

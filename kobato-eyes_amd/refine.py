@@ -113,9 +113,11 @@ def refine_pairs(pairs: Sequence[tuple], *, thresholds: Optional[RefinementThres
             gpu_kinds["png"] = (".png",)
         if os.environ.get("KE_GPU_BMP", "1") != "0":
             gpu_kinds["bmp"] = (".bmp",)
+        if os.environ.get("KE_GPU_TIFF", "1") != "0":
+            gpu_kinds["tiff"] = (".tif", ".tiff")
 
     def decode_on_gpu(need: list, placed: dict, buffers: list) -> None:
-        """JPEG / PNG / BMP files whose pixels the reference's loader would hand over exactly as Image.open yields them -- RGB, no
+        """JPEG / PNG / BMP / TIFF files whose pixels the reference's loader would hand over exactly as Image.open yields them -- RGB, no
         EXIF orientation to apply, nothing to shrink (src/utils/image_io.py:107-138 are all no-ops then) -- are decoded on the
         GPU and stay there: placed[path] = (device address, width, height).  Everything else is left for Pillow."""
         for kind, suffixes in gpu_kinds.items():
@@ -136,7 +138,7 @@ def refine_pairs(pairs: Sequence[tuple], *, thresholds: Optional[RefinementThres
             # orientation of a JPEG file applied (every camera writes one), an RGBA PNG composited over white
             orient = (flags >> 8) & 15
             turn = fits & (c == 3) & ((flags & 3) == 1) & (orient >= 2) & (orient <= 8) if kind == "jpeg" else np.zeros(len(paths), bool)
-            over = fits & (c == 4) & ((flags & 3) == 0) if kind in ("png", "bmp") else np.zeros(len(paths), bool)
+            over = fits & (c == 4) & ((flags & 3) == 0) if kind in ("png", "bmp", "tiff") else np.zeros(len(paths), bool)
             fix = np.nonzero(turn | over)[0]
             if len(fix):
                 dev2, off2, w2, h2 = ctx.normalise_rgb(dev, off[fix], w[fix], h[fix], c[fix], np.where(turn[fix], orient[fix], 1))

@@ -70,11 +70,11 @@ def _thumbnails(arrays: Sequence[np.ndarray], side: int, device: int) -> list:
     return out
 
 
-_GPU_SUFFIXES = {"jpeg": (".jpg", ".jpeg", ".jpe", ".jfif"), "png": (".png",), "bmp": (".bmp",), "gif": (".gif",)}
+_GPU_SUFFIXES = {"jpeg": (".jpg", ".jpeg", ".jpe", ".jfif"), "png": (".png",), "bmp": (".bmp",), "gif": (".gif",), "tiff": (".tif", ".tiff")}
 
 
 def _thumbnails_decoded_on_gpu(paths: Sequence[Path], side: int, device: int) -> dict:
-    """{path: side x side BILINEAR luma thumbnail} for the JPEG / PNG / BMP / GIF files whose pixels ``_decode`` would return exactly as
+    """{path: side x side BILINEAR luma thumbnail} for the JPEG / PNG / BMP / GIF / TIFF files whose pixels ``_decode`` would return exactly as
     the GPU decoders do -- every kind they take, unless the file carries an EXIF orientation to apply (ke_*_caveats).  The
     files are read, decoded and shrunk without their pixels ever being in host memory; files left out (other formats,
     refused, damaged, turned) are for ``_decode``.  ``KE_GPU_REFINE_DECODE=0`` turns the route off."""
@@ -84,7 +84,7 @@ def _thumbnails_decoded_on_gpu(paths: Sequence[Path], side: int, device: int) ->
     ctx = _native.get_context(device)
     not_laid = np.uint64(0xFFFFFFFFFFFFFFFF)
     for kind, suffixes in _GPU_SUFFIXES.items():
-        if os.environ.get({"jpeg": "KE_GPU_JPEG", "png": "KE_GPU_PNG", "bmp": "KE_GPU_BMP", "gif": "KE_GPU_GIF"}[kind], "1") == "0":
+        if os.environ.get({"jpeg": "KE_GPU_JPEG", "png": "KE_GPU_PNG", "bmp": "KE_GPU_BMP", "gif": "KE_GPU_GIF", "tiff": "KE_GPU_TIFF"}[kind], "1") == "0":
             continue
         mine = [p for p in paths if str(p).lower().endswith(suffixes)]
         at = 0

@@ -36,7 +36,7 @@ if [ "${2:-}" = "more" ]; then
     run python3 "$root/benchmarks/decode_phases.py" 4096,16384,32768,65536 > "$out/${tag}_decode_phases.jsonl" 2> "$out/${tag}_decode_phases.err"
     # the Pillow route (formats outside the GPU decoders; decoder processes into shared page-locked buffers), small and camera-sized images
     : > "$out/${tag}_fastsig_pillow_route.jsonl"
-    for spec in "webp 512 128 8192" "webp 2048 32 1024" "tiff 1024 64 2048"; do
+    for spec in "webp 512 128 8192" "webp 2048 32 1024"; do
         set -- $spec
         run python3 "$root/benchmarks/bench_fastsig.py" --format "$1" --side "$2" --distinct "$3" --images "$4" --pillow-sample "$4" >> "$out/${tag}_fastsig_pillow_route.jsonl" 2>> "$out/${tag}_decode_phases.err"
     done
@@ -54,6 +54,12 @@ if [ "${2:-}" = "more" ]; then
     for spec in "corpus 1024" "corpus 4096" "corpus 16384" "corpus 65536" "drawing 65536"; do
         set -- $spec
         run python3 "$root/benchmarks/bench_jpeg.py" --format gif --content "$1" --images "$2" >> "$out/${tag}_decode_gif.jsonl" 2>> "$out/${tag}_decode_phases.err"
+    done
+    # TIFF without compression: unpacked on the GPU (ke_tiff_decode) against the same files through the Pillow route
+    : > "$out/${tag}_fastsig_tiff.jsonl"
+    for spec in "512 256 16384 4096" "1024 64 4096 1024"; do
+        set -- $spec
+        run python3 "$root/benchmarks/bench_fastsig.py" --format tiff --side "$1" --distinct "$2" --images "$3" --pillow-sample "$4" >> "$out/${tag}_fastsig_tiff.jsonl" 2>> "$out/${tag}_decode_phases.err"
     done
     # BMP: unpacked on the GPU (ke_bmp_decode) against the same files through the Pillow route
     : > "$out/${tag}_fastsig_bmp.jsonl"

@@ -31,7 +31,7 @@ if os.path.exists(os.path.join(g, f"{tag}_decode.jsonl")):
             shutil.copy(sorted(found, key=os.path.getmtime)[-1], os.path.join(here, f"{tag}_{fmt}_decode_kernel_stats.csv"))
 # round 3 extras (collect.sh <tag> more): copied as they are, JSON lines filtered from whatever else the programs printed
 for name in (f"{tag}_bench_dhash.json", f"{tag}_bench_selflaunch.json", f"{tag}_mixed.jsonl", f"{tag}_kernels.jsonl", f"{tag}_scanner.jsonl",
-             f"{tag}_decode_phases.jsonl", f"{tag}_fastsig_pillow_route.jsonl", f"{tag}_fastsig_bmp.jsonl", f"{tag}_fastsig_gif.jsonl", f"{tag}_decode_gif.jsonl", f"{tag}_fastsig_collection.jsonl"):
+             f"{tag}_decode_phases.jsonl", f"{tag}_fastsig_pillow_route.jsonl", f"{tag}_fastsig_bmp.jsonl", f"{tag}_fastsig_gif.jsonl", f"{tag}_fastsig_tiff.jsonl", f"{tag}_decode_gif.jsonl", f"{tag}_fastsig_collection.jsonl"):
     src = os.path.join(g, name)
     if os.path.exists(src):
         open(os.path.join(here, name), "w").writelines(l for l in open(src) if l.startswith("{"))

@@ -257,7 +257,7 @@ def write_worker_corpus(td):
 
 def refine_turned_golden():
     """(json, {name: file bytes}): the reference's shipped refine stage run on files the loader has to normalise first
-    (JPEG files of every EXIF orientation, RGBA / gray + alpha / 16-bit / Adam7 PNG, BMP, GIF; make_golden.make_refine_turned)."""
+    (JPEG files of every EXIF orientation, RGBA / gray + alpha / 16-bit / Adam7 PNG, BMP, GIF, TIFF; make_golden.make_refine_turned)."""
     with open(os.path.join(GOLDEN, "refine_turned_golden.json")) as fh:
         g = json.load(fh)
     z = np.load(os.path.join(GOLDEN, "refine_turned_corpus.npz"))

@@ -846,6 +846,11 @@ def make_refine_turned():
     put("still.gif", Image.fromarray(near).quantize(256), "GIF")
     put("anim.gif", Image.fromarray(near).quantize(64), "GIF", save_all=True, append_images=[Image.fromarray(other).quantize(64)], duration=60, loop=0)
     put("gray.gif", Image.fromarray(g8), "GIF", interlace=False)
+    # TIFF without compression (Pillow's own raw decoder): RGB, RGBA (unassociated alpha), gray, palette
+    put("rgb.tif", Image.fromarray(near), "TIFF")
+    put("rgba.tiff", Image.fromarray(np.dstack([near, alpha]), "RGBA"), "TIFF")
+    put("gray.tif", Image.fromarray(g8), "TIFF")
+    put("pal.tif", Image.fromarray(near).quantize(200), "TIFF")
     out = {"names": [n for n, _ in files], "cases": {}, "clusters": []}
     store = {"names": np.array(out["names"])}
     for k, (_, data) in enumerate(files):
@@ -865,13 +870,15 @@ def make_refine_turned():
                        ("rgba.png", "la.png"), ("upright.jpg", "other.jpg"), ("rgba.png", "rgb16.png"), ("la.png", "la16.png"),
                        ("rgba.png", "rgba16_adam7.png"), ("rgb_adam7.png", "rgb16.png"), ("la.png", "gray16.png"), ("rgba.png", "rgb.bmp"),
                        ("rgb.bmp", "rgbx.bmp"), ("rgb.bmp", "pal.bmp"), ("la.png", "gray.bmp"), ("pal.bmp", "still.gif"),
-                       ("still.gif", "anim.gif"), ("gray.bmp", "gray.gif")]]
+                       ("still.gif", "anim.gif"), ("gray.bmp", "gray.gif"), ("rgb.bmp", "rgb.tif"), ("rgba.png", "rgba.tiff"),
+                       ("gray.gif", "gray.tif"), ("pal.bmp", "pal.tif")]]
         ids = {n: k + 1 for k, n in enumerate(paths)}
         groups = [(["upright.jpg"] + [f"turned{o}.jpg" for o in range(1, 9)], "upright.jpg"), (["rgba.png", "la.png", "other.jpg"], "rgba.png"),
                   (["turned5.jpg", "other.jpg", "turned2.jpg"], "turned5.jpg"),
                   (["rgb16.png", "rgb_adam7.png", "rgba16_adam7.png", "la16.png", "gray16.png", "other.jpg"], "rgb16.png"),
                   (["rgb.bmp", "rgbx.bmp", "pal.bmp", "gray.bmp", "upright.jpg", "other.jpg"], "rgb.bmp"),
-                  (["still.gif", "anim.gif", "gray.gif", "rgb.bmp", "other.jpg"], "still.gif")]
+                  (["still.gif", "anim.gif", "gray.gif", "rgb.bmp", "other.jpg"], "still.gif"),
+                  (["rgb.tif", "rgba.tiff", "gray.tif", "pal.tif", "upright.jpg", "other.jpg"], "rgb.tif")]
         clusters = [Cl([E(F(ids[n], paths[n])) for n in members], ids[keeper]) for members, keeper in groups]
         out["cluster_inputs"] = [{"members": m, "keeper": k} for m, k in groups]
         for max_bits in (4, 400, 1024):

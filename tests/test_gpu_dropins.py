@@ -292,10 +292,13 @@ def test_refine_pairs_decodes_on_the_gpu_only_what_the_loader_leaves_alone(K, tm
     put(27, "large_turned.jpg", Image.fromarray(np.ascontiguousarray(large.transpose(1, 0, 2)[:, ::-1])), quality=80, exif=ex6.tobytes())
     put(28, "large.png", Image.fromarray(np.repeat(np.repeat(noisy, 14, 0), 14, 1)[:3000, :4400]), compress_level=1)
     put(29, "huge.jpg", Image.fromarray(np.repeat(np.repeat(base, 26, 0), 26, 1)[:6000, :8300]), quality=60)
+    put(30, "e.tif", Image.fromarray(noisy))                                       # uncompressed: the GPU route; RGBA over white on the device
+    put(31, "alpha.tiff", Image.fromarray(np.dstack([noisy, alpha]), "RGBA"))
+    put(32, "lzw.tif", Image.fromarray(noisy), compression="tiff_lzw")             # libtiff's in Pillow: the loader
     pairs = [(a, b, files[a], files[b]) for a, b in [(0, 1), (0, 2), (1, 2), (0, 3), (3, 2), (0, 4), (4, 2), (0, 5), (5, 1), (6, 0), (7, 2),
                                                       (6, 7), (8, 0), (8, 8), (9, 0), (9, 2), (12, 0), (13, 1), (14, 0), (15, 3), (17, 3),
                                                       (18, 15), (20, 4), (20, 2), (21, 2), (22, 20), (23, 7), (24, 2), (25, 20), (21, 0),
-                                                      (26, 0), (27, 26), (28, 26), (29, 26)]]
+                                                      (26, 0), (27, 26), (28, 26), (29, 26), (30, 2), (31, 20), (32, 30)]]
     th = K.RefinementThresholds(ssim=0.8)
     one_by_one = [K.refine_pair(a, b, pa, pb, thresholds=th) for a, b, pa, pb in pairs]
     stats = {}
@@ -303,9 +306,9 @@ def test_refine_pairs_decodes_on_the_gpu_only_what_the_loader_leaves_alone(K, tm
     # a.jpg, b.jpg, c.png, upright.jpg, d.bmp, rgb16.png as they are; rotated.jpg, the six turned*.jpg, alpha.png, alpha_any.png,
     # alpha.bmp and rgba_adam7.png normalised on the device; the 4100-pixel-wide file and the three large ones shrunk on the
     # device; gray, palette (PNG and BMP) and the 8300-pixel-wide file go through the loader
-    assert stats["decodes"] == 26 and stats["gpu_decodes"] == 21 and stats["gpu_normalised"] == 11 and stats["gpu_shrunk"] == 4, stats
+    assert stats["decodes"] == 29 and stats["gpu_decodes"] == 23 and stats["gpu_normalised"] == 12 and stats["gpu_shrunk"] == 4, stats
     by = {(a, b): m for (a, b, _, _), m in zip(pairs, one_by_one)}
-    assert all(by[k].ssim > 0.999999 for k in ((21, 2), (24, 2), (22, 20), (25, 20)))         # same pixels, other container
+    assert all(by[k].ssim > 0.999999 for k in ((21, 2), (24, 2), (22, 20), (25, 20), (30, 2), (31, 20), (32, 30)))    # same pixels, other container
     assert any(m.is_duplicate for m in one_by_one) and any(not m.is_duplicate for m in one_by_one)
     os.environ["KE_GPU_REFINE_DECODE"] = "0"
     try:

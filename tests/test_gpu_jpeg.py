@@ -13,6 +13,7 @@ import _jpeg_cases as J
 import _png_cases as P
 import _bmp_cases as B
 import _gif_cases as GF
+import _tiff_cases as TF
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -248,6 +249,58 @@ def test_gif_first_frame_matches_pillow_in_one_mixed_batch(ctx, tmp_path):
         assert rows == K.compute_signatures_mp(items, max_workers=4, chunksize=16) and len(rows) >= 40
     finally:
         del os.environ["KE_GPU_GIF"]
+
+
+def test_tiff_unpack_matches_pillow_in_one_mixed_batch(ctx, tmp_path):
+    """ke_tiff_decode: uncompressed 8-bit TIFFs -- Pillow-written gray / RGB / RGBA / palette files and hand-made directories
+    (both byte orders, strips of 1 / 3 / all rows, SHORT and LONG fields, WhiteIsZero, an unspecified fourth sample, duplicate and
+    unknown-type entries) -- equal to what the reference's hashes see of them through Pillow; compressed / planar / turned /
+    premultiplied files and truncated strips reported per file; damaged directories never decoded differently; .tif files take
+    the route in the batch hasher."""
+    import test_tiff_cpu as TT
+
+    cases = list(TF.supported(full=True)) + list(TF.handmade(full=True))
+    refused = [r for r in TF.refused() if r[2] is not None]
+    out, status = ctx.tiff_decode([c[1] for c in cases] + [r[1] for r in refused])
+    taken = 0
+    for k, (name, _, ref) in enumerate(cases):
+        if ref is None or name.startswith(TF.LEFT_TO_PILLOW):
+            assert status[k] != 0 and out[k] is None, name
+            continue
+        assert status[k] == 0, name
+        assert out[k].shape == ref.shape and np.array_equal(out[k], ref), name
+        taken += 1
+    for k, (name, _, expected) in enumerate(refused, len(cases)):
+        assert status[k] == expected and out[k] is None, name
+    assert taken > 120
+    big = [c for c in cases if c[2] is not None and not c[0].startswith(TF.LEFT_TO_PILLOW) and min(c[2].shape[:2]) >= 16]
+    ph, dh, st = ctx.tiff_hash([c[1] for c in big])
+    for k, c in enumerate(big):
+        assert st[k] == 0 and (int(ph[k]), int(dh[k])) == O.hash_image(c[2]), c[0]
+    rng = np.random.default_rng(36)
+    pool = [c for c in cases if c[2] is not None and c[2].shape[0] <= 80]
+    damaged = list(TT.damaged(rng, pool, 15))
+    out, status = ctx.tiff_decode([d for _, d in damaged])
+    decoded = 0
+    for (name, data), px, st in zip(damaged, out, status):
+        if st == 0:
+            decoded += 1
+            ref = TT.strict_pillow(data)
+            assert ref is not None and ref.shape == px.shape and np.array_equal(ref, px), name
+    assert decoded > 150
+    from kobato_eyes_amd import fastsig as K
+
+    items = []
+    for k, c in enumerate(big[:40] + [c for c in cases if c[0].startswith(TF.LEFT_TO_PILLOW)][:5]):
+        p = tmp_path / f"{k:03d}.{'tif' if k % 2 else 'tiff'}"
+        p.write_bytes(c[1])
+        items.append((700 + k, str(p)))
+    rows = K.compute_signatures_mp(items, max_workers=4, chunksize=16)
+    os.environ["KE_GPU_TIFF"] = "0"
+    try:
+        assert rows == K.compute_signatures_mp(items, max_workers=4, chunksize=16) and len(rows) >= 40
+    finally:
+        del os.environ["KE_GPU_TIFF"]
 
 
 def test_png_damage_is_reported_not_decoded(ctx):

@@ -474,7 +474,7 @@ def test_batches_read_ahead_reach_the_decoders_in_their_own_order(tmp_path, monk
 
         def read_ahead(self, paths, spans=()):
             jpegs = sum(p.endswith("jpg") for p in paths)
-            assert tuple(spans) == (("jpeg", 0, jpegs), ("png", jpegs, len(paths)), ("bmp", len(paths), len(paths)), ("gif", len(paths), len(paths)))
+            assert tuple(spans) == (("jpeg", 0, jpegs), ("png", jpegs, len(paths)), ("bmp", len(paths), len(paths)), ("gif", len(paths), len(paths)), ("tiff", len(paths), len(paths)))
             log["taken"] += 1
             if log["taken"] == 2:                              # "both buffers taken": this batch is read inside the call
                 return None

@@ -434,9 +434,9 @@ class _Pipeline:
                 reads["ahead"] = None                      # the decode call reads the files itself
         return reads
 
-    def _png_for_pillow(self, held, lo: int, hi: int):
-        """Which PNG files of a batch the decoder processes should take instead of the GPU (a mask over files lo..hi of the
-        read-ahead buffer, or None = the GPU takes them all).
+    def _png_for_pillow(self, held, lo: int, hi: int, kind: str = "png"):
+        """Which PNG (or GIF) files of a batch the decoder processes should take instead of the GPU (a mask over files lo..hi of
+        the read-ahead buffer, or None = the GPU takes them all).
 
         ``ke_png_inflate`` is one lane per stream and a deflate stream is sequential, so a batch takes as long as its longest
         stream whatever its size -- about 0.45 us per symbol, i.e. 0.9 us per compressed byte of a textured image -- while a
@@ -444,11 +444,12 @@ class _Pipeline:
         the GPU, 6.2 s on 16 host threads; 512 of them: 5.7 s against 1.5 s.  With the sizes known (the files are in memory,
         their headers parsed) the k largest files go to the processes, k minimising the larger of (longest stream left for the
         GPU) and (decoded bytes moved to the processes) in those terms -- the two shares are worked off side by side.  KE_PNG_GPU_US_PER_BYTE / KE_PILLOW_MB_PER_S set the two rates;
-        KE_PNG_GPU_US_PER_BYTE=0 sends every PNG file to the GPU, as before."""
-        gpu_rate = float(os.environ.get("KE_PNG_GPU_US_PER_BYTE", "0.9")) * 1e-6
+        KE_PNG_GPU_US_PER_BYTE=0 sends every PNG file to the GPU, as before.  The LZW walk of ``ke_gif_codes`` has the same shape (one lane per
+        stream, ~0.65 us per code = 0.75 us per compressed byte: a 512 x 512 frame is 40 ms whatever the batch; KE_GIF_GPU_US_PER_BYTE)."""
+        gpu_rate = float(os.environ.get("KE_PNG_GPU_US_PER_BYTE", "0.9") if kind == "png" else os.environ.get("KE_GIF_GPU_US_PER_BYTE", "0.75")) * 1e-6
         if gpu_rate <= 0.0:
             return None
-        known = getattr(held, "probed", {}).get(("png", lo, hi))
+        known = getattr(held, "probed", {}).get((kind, lo, hi))
         if known is None:
             return None
         w, h, c, st = known
@@ -470,10 +471,11 @@ class _Pipeline:
         mask[order[:k]] = True
         return mask
 
-    def _decode_on_gpu(self, reads: dict, start: int, ph: np.ndarray, dh: np.ndarray, ok: np.ndarray, png_skip=None) -> list:
+    def _decode_on_gpu(self, reads: dict, start: int, ph: np.ndarray, dh: np.ndarray, ok: np.ndarray, skips=None) -> list:
         """Fills ph / dh / ok (indexed by position - start) for the files the GPU decoders take; returns the positions they
-        left to Pillow (``png_skip``: PNG files the caller has given to the decoder processes already -- not decoded here, not
-        returned)."""
+        left to Pillow (``skips``: {kind: mask} of the PNG / GIF files the caller has given to the decoder processes already --
+        not decoded here, not returned)."""
+        skips = skips or {}
         by_path = hasattr(self.stage, "hash_files")
         held = reads["ahead"]
         refused: list = []
@@ -494,7 +496,7 @@ class _Pipeline:
                         continue
                 try:
                     if held is not None:                   # this kind's files are lo .. first of the buffer
-                        skip = png_skip if kind == "png" else None
+                        skip = skips.get(kind)
                         if skip is not None and skip.all():
                             continue
                         p, d, st = self.stage.hash_ahead(held, lo, first, kind) if skip is None else \
@@ -511,7 +513,7 @@ class _Pipeline:
                 ph[at] = np.asarray(p, np.uint64).view(np.int64)[good]
                 dh[at] = np.asarray(d, np.uint64).view(np.int64)[good]
                 ok[at] = True
-                left = ~good if (kind != "png" or png_skip is None) else (~good & ~png_skip)
+                left = ~good if skips.get(kind) is None else (~good & ~skips[kind])
                 refused.extend(positions[left].tolist())   # outside the GPU decoder: Pillow decodes it, as the reference does
         finally:
             if held is not None:
@@ -691,10 +693,17 @@ class _Pipeline:
                 taken = np.zeros(stop - start, bool)
                 for k in GPU_KINDS:
                     taken[reads[k] - start] = True
-                png_skip = None
-                if reads["ahead"] is not None and len(reads["png"]):
-                    png_skip = self._png_for_pillow(reads["ahead"], len(reads["jpeg"]), len(reads["jpeg"]) + len(reads["png"]))
-                todo = (start + np.nonzero(~taken)[0]).tolist() + (reads["png"][png_skip].tolist() if png_skip is not None else [])
+                skips = {}
+                if reads["ahead"] is not None:
+                    ends = np.cumsum([len(reads[k]) for k in GPU_KINDS]).tolist()
+                    for kind, e in zip(GPU_KINDS, ends):
+                        if kind in ("png", "gif") and len(reads[kind]):
+                            mask = self._png_for_pillow(reads["ahead"], e - len(reads[kind]), e, kind)
+                            if mask is not None:
+                                skips[kind] = mask
+                todo = (start + np.nonzero(~taken)[0]).tolist()
+                for kind, mask in skips.items():
+                    todo += reads[kind][mask].tolist()
                 # the Pillow share (other formats, the PNG files given to the processes) beside the GPU decoders' share: its
                 # staging route has a context of its own, so neither waits for the other's calls
                 out: dict = {}
@@ -709,7 +718,7 @@ class _Pipeline:
                     side = threading.Thread(target=pillow_share, name="ke-pillow-share")
                     side.start()
                 try:
-                    refused = self._decode_on_gpu(reads, start, ph, dh, ok, png_skip)
+                    refused = self._decode_on_gpu(reads, start, ph, dh, ok, skips)
                 finally:
                     if side is not None:
                         side.join()

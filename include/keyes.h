@@ -185,9 +185,10 @@ int ke_jpeg_decode(ke_ctx *ctx, const uint8_t *files, const uint64_t *offsets, c
  * filters and checks the stream's Adler-32; throughput comes from the batch.  Chunk CRCs are verified where Pillow verifies
  * them (every chunk but IDAT).  An interlaced file is seven reduced images one after another in the stream: the same kernels,
  * the unfilter pass run once per reduced image and its pixels scattered to their places.  8-bit gray + alpha files decode to
- * their gray samples, what convert("L") makes of mode "LA".  16-bit files decode to the 8-bit pixels Pillow opens them to: the
+ * their gray samples, what convert("L") makes of mode "LA".  Of an animated PNG frame 0 is decoded -- the IDAT image, what Image.open
+ * shows (acTL once, at most one fcTL in front of IDAT and that one for the whole image; other forms: status 1).  16-bit files decode to the 8-bit pixels Pillow opens them to: the
  * samples' high bytes for RGB / RGBA, RGBA (L, L, L, A) for gray + alpha, and for grayscale (Pillow: mode "I;16") the value
- * clipped to 255 that convert("L") / convert("RGB") make of it.  Animated files, rows wider than 16384 pixels (8192 at 16 bits):
+ * clipped to 255 that convert("L") / convert("RGB") make of it.  Rows wider than 16384 pixels (8192 at 16 bits):
  * KE_JPEG_UNSUPPORTED_ (1) per file, damaged ones KE_JPEG_CORRUPT_ (2).  Arguments and conventions as ke_jpeg_probe /
  * ke_jpeg_decode; channels is 1, 3 or 4. */
 int ke_png_probe(const uint8_t *files, const uint64_t *offsets, const uint64_t *sizes, int64_t n, int32_t *widths,

@@ -2,8 +2,8 @@
 // signature, IHDR, where the IDAT payloads lie (their concatenation is one zlib stream per image), IEND; chunk CRCs are
 // verified where Pillow's ChunkStream verifies them (a damaged file raises there and the reference drops it,
 // src/core/fastsig.py:36-37).  8-bit grayscale, RGB
-// and RGBA are taken, interlaced (Adam7) or not, and 16-bit files as the 8-bit pixels Pillow opens them to (palette / sub-byte
-// gray / gray + alpha files decode to the luma convert("L") gives them).
+// and RGBA are taken, interlaced (Adam7) or not, 16-bit files as the 8-bit pixels Pillow opens them to (palette / sub-byte
+// gray / gray + alpha files decode to the luma convert("L") gives them), and of an animated PNG frame 0, which is what Image.open shows.
 #pragma once
 
 #include <cstring>
@@ -58,9 +58,23 @@ static inline void ke_parse_png(const uint8_t *p, size_t size, std::vector<KePng
     auto be32 = [&](size_t o) { return ((uint32_t)p[o] << 24) | ((uint32_t)p[o + 1] << 16) | ((uint32_t)p[o + 2] << 8) | p[o + 3]; };
     size_t pos = 8;
     bool have_ihdr = false, ended = false, palette = false, have_plte = false, idat_closed = false;
+    // animated PNG: Image.open shows frame 0, which is the IDAT image (the "default image", or the first frame when an fcTL chunk
+    // stands in front of it -- its region must then be the whole image, or Pillow decodes the stream into that region only).
+    // PngImageFile.load_end stops at the next frame's fcTL without looking at anything behind it.
+    bool have_actl = false, have_fctl = false;
+    uint32_t actl_frames = 0;
     const size_t s0 = segs ? segs->size() : 0;
     uint64_t zlen = 0;
-    while (pos + 12 <= size) {
+    auto animated = [&]() { return have_actl && (uint64_t)actl_frames + (have_fctl ? 0 : 1) > 1; };
+    while (pos + 12 <= size || (pos + 8 <= size && zlen != 0 && animated())) {
+        if (segs && zlen != 0 && animated() && std::memcmp(p + pos + 4, "IDAT", 4) != 0) {
+            // the first chunk behind the image data of an animation: the next frame's fcTL (Pillow stops there, whatever
+            // follows) or IEND; any other chunk there is handled by code paths this parser does not mirror
+            if (std::memcmp(p + pos + 4, "fcTL", 4) == 0 || std::memcmp(p + pos + 4, "IEND", 4) == 0) ended = true;
+            else { info.status = KE_PNG_UNSUPPORTED; segs->resize(s0); return; }
+            break;
+        }
+        if (pos + 12 > size) break;
         const uint32_t len = be32(pos);
         if (len > 0x7fffffffu || pos + 12 + (size_t)len > size) break;
         const uint8_t *type = p + pos + 4, *data = p + pos + 8;
@@ -123,14 +137,32 @@ static inline void ke_parse_png(const uint8_t *p, size_t size, std::vector<KePng
         } else if (std::memcmp(type, "IEND", 4) == 0) {
             ended = true;
             break;
-        } else if (std::memcmp(type, "acTL", 4) == 0) {
-            info.status = KE_PNG_UNSUPPORTED;          // animated PNG: Pillow's frame handling decides what is seen
-            segs->resize(s0);
-            return;
+        } else if (std::memcmp(type, "acTL", 4) == 0 || std::memcmp(type, "fcTL", 4) == 0 || std::memcmp(type, "fdAT", 4) == 0) {
+            // in front of the image data: one acTL with a sane frame count, at most one fcTL (sequence number 0, the whole image);
+            // anything else about these chunks -- repeated, malformed, fdAT before IDAT, any of them behind the image data of a
+            // file that is not animated -- is Pillow's to judge
+            bool fine = zlen == 0;
+            if (fine && type[0] == 'a') {
+                fine = !have_actl && !have_fctl && len == 8 && be32(pos + 8) != 0 && be32(pos + 8) <= 0x7FFFFFFFu;
+                have_actl = true;
+                actl_frames = fine ? be32(pos + 8) : 0;
+            } else if (fine && type[1] == 'c') {
+                fine = !have_fctl && len == 26 && be32(pos + 8) == 0 && be32(pos + 12) == (uint32_t)info.width &&
+                       be32(pos + 16) == (uint32_t)info.height && be32(pos + 20) == 0 && be32(pos + 24) == 0;
+                have_fctl = true;
+            } else {
+                fine = false;
+            }
+            if (!fine) {
+                info.status = KE_PNG_UNSUPPORTED;
+                segs->resize(s0);
+                return;
+            }
         }
         if (!idat && zlen != 0) idat_closed = true;
         pos += 12 + (size_t)len;
     }
+    if (zlen != 0 && animated() && pos + 8 > size) ended = true;      // an animation whose file ends behind frame 0's data: Pillow stops reading too
     if (!have_ihdr || zlen == 0 || zlen > 0xF0000000ull || !ended) {   // no IEND: truncated (Pillow raises unless LOAD_TRUNCATED_IMAGES)
         if (segs) segs->resize(s0);
         return;

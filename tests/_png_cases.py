@@ -249,6 +249,53 @@ def wide(full: bool = False):
                 yield f"wide_c{ctype}_{w}x{h}_i{lace}", data, ref
 
 
+def animated(full: bool = False):
+    """Yields (name, file bytes, what the reference's hashes see: frame 0 as Image.open shows it) for animated PNG files written
+    by Pillow (the first frame is the IDAT image, or a separate default image is), and hand-edited ones: the file cut right
+    behind frame 0's data, and what the decoder leaves to Pillow (expected = None: a first frame smaller than the image,
+    a frame count of zero, a second acTL)."""
+    rng = np.random.default_rng(21)
+    sizes = [(7, 5), (64, 48), (101, 77)] + ([(300, 200)] if full else [])
+    for (w, h) in sizes:
+        frames = [rng.integers(0, 256, (h, w, 4), dtype=np.uint8) for _ in range(3)]
+        frames[1][: h // 2] = frames[0][: h // 2]
+        for mode in ("RGB", "RGBA", "L", "P"):
+            ims = [Image.fromarray(f).convert("RGB").quantize(64) if mode == "P" else Image.fromarray(f).convert(mode) for f in frames]
+            for default_image in (False, True):
+                b = io.BytesIO()
+                ims[0].save(b, "PNG", save_all=True, append_images=ims[1:], default_image=default_image, duration=80, loop=0)
+                data = b.getvalue()
+                with Image.open(io.BytesIO(data)) as im:
+                    assert im.n_frames > 1
+                    ref = np.asarray(im.convert("L") if im.mode in ("P", "1") else im)
+                yield f"apng_{mode}_{w}x{h}_default{int(default_image)}", data, ref
+                if mode == "RGB":
+                    # nothing behind frame 0's data: Pillow stops reading at the next frame anyway
+                    cut = data.index(b"fcTL", data.index(b"IDAT")) - 4
+                    yield f"apng_cut_behind_frame0_{w}x{h}_default{int(default_image)}", data[:cut], ref
+                    yield f"apng_cut_inside_next_fctl_{w}x{h}_default{int(default_image)}", data[:cut + 14], ref
+    # left to Pillow
+    b = io.BytesIO()
+    ims = [Image.fromarray(rng.integers(0, 256, (40, 50, 3), dtype=np.uint8)) for _ in range(2)]
+    ims[0].save(b, "PNG", save_all=True, append_images=ims[1:])
+    data = b.getvalue()
+
+    def rechunk(at, body):
+        n = struct.unpack(">I", data[at - 4:at])[0]
+        t = data[at:at + 4]
+        return data[:at + 4] + body + struct.pack(">I", zlib.crc32(t + body)) + data[at + 8 + n:]
+
+    a = data.index(b"acTL")
+    f = data.index(b"fcTL")
+    fc = data[f + 4:f + 30]
+    yield "apng_zero_frames", rechunk(a, struct.pack(">II", 0, 0)), None
+    yield "apng_first_frame_smaller", rechunk(f, fc[:4] + struct.pack(">IIII", 30, 40, 0, 0) + fc[20:]), None
+    yield "apng_first_frame_offset", rechunk(f, fc[:4] + struct.pack(">IIII", 49, 40, 1, 0) + fc[20:]), None
+    yield "apng_sequence_from_1", rechunk(f, struct.pack(">I", 1) + fc[4:]), None
+    actl = data[a - 4:a + 16]
+    yield "apng_two_actl", data[:a - 4] + actl + actl + data[a + 16:], None
+
+
 def refused():
     """Yields (name, file bytes, expected status): 1 = left to Pillow, 2 = damaged."""
     rng = np.random.default_rng(4)

@@ -80,7 +80,7 @@ def check(decode_batch, variants, seed, files=40, fmt="jpeg"):
     if fmt == "jpeg":
         pool = [c for c in J.supported() if c[2].shape[0] >= 16 and c[2].shape[1] >= 16]
     else:
-        pool = [c for c in list(P.supported()) + list(P.handmade()) + list(P.mapped()) + list(P.interlaced()) + list(P.wide()) if c[2].shape[0] >= 8]
+        pool = [c for c in list(P.supported()) + list(P.handmade()) + list(P.mapped()) + list(P.interlaced()) + list(P.wide()) + [c for c in P.animated() if c[2] is not None] if c[2].shape[0] >= 8]
     pool = [pool[i] for i in rng.choice(len(pool), min(files, len(pool)), replace=False)]
     cases = taken = 0
     wrong = []

@@ -144,8 +144,8 @@ def test_png_decode_matches_pillow_in_one_mixed_batch(ctx):
     level in one call -- stored, fixed and dynamic deflate blocks, all five filters -- equal to what Pillow opens them to;
     damaged files and files beyond the decoder's limits reported per file."""
     cases = list(P.supported(full=True)) + list(P.handmade(full=True)) + list(P.mapped(full=True)) + list(P.interlaced(full=True)) + \
-        list(P.wide(full=True))
-    refused = list(P.refused())
+        list(P.wide(full=True)) + [c for c in P.animated(full=True) if c[2] is not None]
+    refused = list(P.refused()) + [(c[0], c[1], 1) for c in P.animated() if c[2] is None]
     blobs = [c[1] for c in cases] + [r[1] for r in refused]
     out, status = ctx.png_decode(blobs)
     for k, (name, _, ref) in enumerate(cases):

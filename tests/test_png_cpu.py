@@ -118,3 +118,23 @@ def test_random_handmade_files_decode_as_pillow_does():
         assert out.shape == ref.shape and np.array_equal(out, ref), name
         n += 1
     assert n == 400
+
+
+def test_animated_files_yield_frame_0():
+    """Animated PNG: what Image.open shows is frame 0 -- the IDAT image; files in forms the parser does not mirror are refused
+    (and whatever it takes is what Pillow shows, also when Pillow itself refuses the hand-edited file: then it must not be taken)."""
+    import io
+
+    from PIL import Image
+
+    L = _lib()
+    n = 0
+    for name, data, ref in P.animated():
+        st, out = _decode(L, data)
+        if ref is None:
+            assert st != 0, name
+            continue
+        assert st == 0, name
+        assert out.shape == ref.shape and np.array_equal(out, ref), name
+        n += 1
+    assert n >= 30

@@ -153,6 +153,7 @@ static inline void ke_parse_tiff(const uint8_t *p, size_t size, std::vector<uint
     } else if ((uint64_t)count != ((uint64_t)H + rows - 1) / rows) {
         return;                                                    // fewer strips leave rows blank, more start over at the top: Pillow's business
     }
+    if (count > (1u << 20)) return;                                // (a strip per row of a 1-pixel-wide giant: not worth a gigabyte of offsets)
     const uint64_t stride = (uint64_t)W * spp;
     for (uint32_t s = 0; s < count; ++s) {
         const uint64_t off = value(so, first + s);

@@ -142,3 +142,19 @@ def random_cases(n: int, seed: int = 0):
             kw["subsampling"] = int(rng.integers(0, 3))
         data = _save(a[:, :, 1] if gray else a, **kw)
         yield f"random{k}_{w}x{h}_{kw}", data, np.asarray(Image.open(io.BytesIO(data)))
+
+
+def scripted(n: int, seed: int = 0):
+    """n progressive files with random legal scan scripts (tests/_jpeg_prog_encoder.py: what Pillow's writer never produces and
+    other encoders -- mozjpeg -- do): (name, file bytes, pixels as Pillow decodes them)."""
+    import _jpeg_prog_encoder as E
+
+    rng = np.random.default_rng(seed)
+    for k in range(n):
+        w, h = int(rng.integers(1, 90)), int(rng.integers(1, 70))
+        gray = bool(rng.integers(0, 5) == 0)
+        sampling = ("444", "422", "420", "440")[int(rng.integers(0, 4))]
+        data, script = E.random_file(rng, w, h, sampling, gray)
+        with Image.open(io.BytesIO(data)) as im:
+            ref = np.asarray(im)
+        yield f"scripted{k}_{'gray' if gray else sampling}_{w}x{h}_{len(script)}scans", data, ref

@@ -432,10 +432,11 @@ def test_jpeg_damage_is_survived(ctx, monkeypatch):
 
 
 def test_random_files_in_one_batch(ctx):
-    """300 random JPEGs, 300 random PNGs from Pillow's writer and 400 hand-made ones (interlacing, 16 bits, sub-byte gray, short
+    """300 random JPEGs from Pillow's writer and 250 progressive ones with random scan scripts (what other encoders produce),
+    300 random PNGs from Pillow's writer and 400 hand-made ones (interlacing, 16 bits, sub-byte gray, short
     palettes, any filter in any row) -- every kind the decoders take, random sizes, qualities, scripts, compression levels -- in
     one call each: Pillow's pixels, file by file."""
-    for cases, decode in ((list(J.random_cases(300, 41)), ctx.jpeg_decode),
+    for cases, decode in ((list(J.random_cases(300, 41)) + list(J.scripted(250, 44)), ctx.jpeg_decode),
                           (list(P.random_cases(300, 42)) + list(P.random_handmade(400, 43)), ctx.png_decode)):
         out, status = decode([c[1] for c in cases])
         for k, (name, _, ref) in enumerate(cases):

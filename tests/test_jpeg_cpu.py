@@ -128,3 +128,17 @@ def test_random_files_decode_as_pillow_does():
         assert status == 0 and out.shape == ref.shape and np.array_equal(out, ref)
 
     check()
+
+
+def test_progressive_files_with_any_scan_script_decode_as_pillow_does():
+    """Pillow's writer only knows libjpeg's default progression; other encoders (mozjpeg: what most image hosts serve) cut and
+    order their scans differently.  120 files with random legal scripts (tests/_jpeg_prog_encoder.py: DC scans for one, some or
+    all components, AC bands cut anywhere, successive approximation from any bit, scans shuffled as far as T.81 allows)."""
+    L = _lib()
+    n = 0
+    for name, data, ref in J.scripted(120, 5):
+        st, out = _decode(L, data)
+        assert st == 0, name
+        assert out.shape == ref.shape and np.array_equal(out, ref), name
+        n += 1
+    assert n == 120

@@ -116,7 +116,7 @@ def _read_pixels(path_text: str, room: Optional[int] = None):
 
 
 JPEG_SUFFIXES = (".jpg", ".jpeg", ".jpe", ".jfif")
-PNG_SUFFIXES = (".png",)
+PNG_SUFFIXES = (".png", ".apng")
 BMP_SUFFIXES = (".bmp",)
 GIF_SUFFIXES = (".gif",)
 TIFF_SUFFIXES = (".tif", ".tiff")

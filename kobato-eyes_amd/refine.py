@@ -110,7 +110,7 @@ def refine_pairs(pairs: Sequence[tuple], *, thresholds: Optional[RefinementThres
         if os.environ.get("KE_GPU_JPEG", "1") != "0":
             gpu_kinds["jpeg"] = (".jpg", ".jpeg", ".jpe", ".jfif")
         if os.environ.get("KE_GPU_PNG", "1") != "0":
-            gpu_kinds["png"] = (".png",)
+            gpu_kinds["png"] = (".png", ".apng")
         if os.environ.get("KE_GPU_BMP", "1") != "0":
             gpu_kinds["bmp"] = (".bmp",)
         if os.environ.get("KE_GPU_TIFF", "1") != "0":

@@ -70,7 +70,7 @@ def _thumbnails(arrays: Sequence[np.ndarray], side: int, device: int) -> list:
     return out
 
 
-_GPU_SUFFIXES = {"jpeg": (".jpg", ".jpeg", ".jpe", ".jfif"), "png": (".png",), "bmp": (".bmp",), "gif": (".gif",), "tiff": (".tif", ".tiff")}
+_GPU_SUFFIXES = {"jpeg": (".jpg", ".jpeg", ".jpe", ".jfif"), "png": (".png", ".apng"), "bmp": (".bmp",), "gif": (".gif",), "tiff": (".tif", ".tiff")}
 
 
 def _thumbnails_decoded_on_gpu(paths: Sequence[Path], side: int, device: int) -> dict:
